@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the FEM hot path: fused energy loss + gradient (one pass) on BASELINE.json configs[1]'s mesh.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: launched by torch.distributed.run)
+
+One "step" = one evaluation of the Poisson energy loss AND its gradient wrt u (forward + backward of the
+reference's loss body IBN_2D.py:116-134 / e2_cib_neumann-style nu field) over one batch of synthetic nodal
+fields already resident in HBM: 2-D Q1, 512 x 512 nodes, 3 x 3 Gauss points, B samples per GPU (weak
+scaling: each rank owns its own batch shard, like the reference's DDP; the only exchange is the all-reduce
+of the scalar loss).  metric = elements * gauss_pts / s summed over ranks.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (HIP-event time of the dominant kernel vs the HBM
+peak of MI355X_MICROARCH.md) and `cpu_baseline` (the CPU oracle = port of the reference formulation, timed
+on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+ALG_BYTES_PER_NODE = 16        # read u, nu, f + write grad_u, fp32
+
+
+def make_inputs(shape, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(shape, generator=g)
+    nu = 0.5 + torch.rand(shape, generator=g)
+    f = torch.rand(shape, generator=g)
+    bc = torch.zeros(shape, dtype=torch.uint8)
+    for d in range(2, len(shape)):
+        idx = [slice(None)] * len(shape)
+        idx[d] = 0
+        bc[tuple(idx)] = 1
+        idx[d] = -1
+        bc[tuple(idx)] = 1
+    return [t.to(dev) if dev is not None else t for t in (u, nu, f, bc)]
+
+
+def cpu_baseline(kw, c, budget_s=20.0):
+    """Time the oracle (torch-CPU port of the reference op sequence: per-GP conv + cat + elementwise + autograd
+    backward) on a bounded sample: batch 2 of the same mesh, as many iterations as fit the budget."""
+    from oracle.fem_oracle import Oracle
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    o = Oracle(**kw)
+    Bs = 2
+    shape = (Bs, 1, *[kw["domain_size"]] * kw.get("nsd", 2))
+    u, nu, f, bc = make_inputs(shape, None, 42)
+    bcf = bc.float()
+    units = Bs * int(torch.tensor(o.spec.nel).prod()) * o.spec.ngp_total
+
+    def step():
+        ur = u.clone().requires_grad_(True)
+        loss = o.energy(ur, nu, f, dirichlet=[(bcf, 0.0)], c=c)
+        loss.backward()
+        return float(loss)
+
+    step()
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        step()
+        it += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or it >= 50:
+            break
+    return {"value": units * it / el, "unit": "elements*gauss_pts/s", "cores": ncores, "kind": "port",
+            "sample": f"oracle/fem_oracle.py energy fwd+bwd, batch {Bs} of the same mesh, {it} iters in {el:.1f}s, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--ngp", type=int, default=3)
+    ap.add_argument("--nsd", type=int, default=2)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM
+    kw = dict(domain_size=args.size, ngp_1d=args.ngp, nsd=args.nsd)
+    cls = DiffNet3DFEM if args.nsd == 3 else DiffNet2DFEM
+    m = cls(None, **kw).to(dev)
+    B = args.batch
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f, bc = make_inputs(shape, dev, 42 + rank)
+    c = 1.0
+    units_per_step = B * m.geom.nelem_total * m.geom.ngp_total
+    dirichlet = [(bc, 0.0)]
+    total_loss = torch.zeros((), device=dev)
+
+    def step():
+        loss, grad = m.energy_loss_and_grad(u, nu, f, dirichlet=dirichlet, c=c)
+        if dist is not None:
+            dist.all_reduce(loss)          # global mean of the loss: the path's only exchange step
+        total_loss.add_(loss)
+        return loss, grad
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+
+    # dominant-kernel time: HIP events on the launch stream around each dn_poisson_apply (fused kernel + the
+    # tiny fixed-order reduction kernel), K launches
+    from diffnet_amd import ops
+    K = min(args.steps, 100)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    scale = 1.0 / (B * m.geom.nelem_total)
+    for a, b in evs:
+        a.record()
+        ops.poisson_apply(m.geom, u, nu, f, None, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale)
+        b.record()
+    torch.cuda.synchronize()
+    kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    alg_bytes = ALG_BYTES_PER_NODE * B * m.geom.nnode_total
+    achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        value = units_per_step * world * args.steps / dt
+        out = {
+            "metric": "elements*gauss_pts/sec (FEM loss+grad)", "value": value, "unit": "elements*gauss_pts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.nsd}-D Poisson energy loss + gradient wrt u, Q1, {args.size}^{args.nsd} nodes, "
+                                   f"{args.ngp}^{args.nsd} Gauss pts, batch {B}/GPU, nu+f nodal fields, u8 Dirichlet mask, "
+                                   "fused single pass (BASELINE.json configs[1] mesh)",
+                       "batch_per_gpu": B, "nodes": list(m.geom.node_shape), "parallelism": f"batch-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "dn_poisson_apply (poisson kernel + finalize)", "kernel_avg_ms": kern_avg_ms,
+                         "kernel_min_ms": kern_ms[0], "algorithmic_bytes": alg_bytes},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(kw, c)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

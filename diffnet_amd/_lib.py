@@ -1,0 +1,96 @@
+"""ctypes binding of libdiffnet_hip.so (the C ABI declared in include/diffnet_hip.h).
+
+The library is the product: there is no CPU fallback.  `lib()` raises if the shared object is
+missing or does not export the full ABI.  Loading needs no GPU (symbols are checked on CPU boxes
+too); compute entry points need device pointers.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdiffnet_hip.so")
+ABI_VERSION = 1
+
+DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE"}
+
+
+class DnMesh(C.Structure):
+    _fields_ = [("nsd", C.c_int32), ("degree", C.c_int32), ("ngp", C.c_int32), ("batch", C.c_int32),
+                ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("scale", C.c_float * 3), ("gpw", C.c_float * 4),
+                ("basis", (C.c_float * 4) * 4), ("dbasis", (C.c_float * 4) * 4)]
+
+
+class DnDirichlet(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("field", C.c_void_p), ("value", C.c_float),
+                ("mask_is_u8", C.c_int32), ("mask_batched", C.c_int32), ("field_batched", C.c_int32)]
+
+
+class DnPoissonArgs(C.Structure):
+    _fields_ = [("u", C.c_void_p), ("nu", C.c_void_p), ("f", C.c_void_p), ("f_gp", C.c_void_p),
+                ("nu_batched", C.c_int32), ("f_batched", C.c_int32),
+                ("bc", DnDirichlet * 2),
+                ("alpha", C.c_float), ("beta", C.c_float), ("c", C.c_float), ("wscale", C.c_float),
+                ("out_scale", C.c_float),
+                ("out", C.c_void_p), ("energy", C.c_void_p), ("sumsq", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
+I32x3 = C.c_int32 * 3
+
+# name -> (restype, argtypes); must list every symbol of include/diffnet_hip.h
+SYMBOLS = {
+    "dn_abi_version": (C.c_int, []),
+    "dn_build_info": (C.c_char_p, []),
+    "dn_poisson_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
+    "dn_poisson_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnPoissonArgs), C.c_void_p]),
+    "dn_gauss_pt_eval_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_void_p]),
+    "dn_gauss_pt_eval_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_void_p]),
+    "dn_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32, C.c_int32, C.c_int32,
+                              C.c_void_p]),
+    "dn_assemble_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32, C.c_int32,
+                                  C.c_void_p]),
+}
+
+_LIB = None
+
+
+class DiffNetHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises DiffNetHipError when the library is unusable."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise DiffNetHipError(
+            f"{LIB_PATH} is missing: build it with `python -m diffnet_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the FEM hot path.")
+    try:
+        h = C.CDLL(LIB_PATH)
+    except OSError as e:   # pragma: no cover - depends on the box
+        raise DiffNetHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise DiffNetHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = h.dn_abi_version()
+    if v != ABI_VERSION:
+        raise DiffNetHipError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
+    _LIB = h
+    return h
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise DiffNetHipError(f"{what}: {DN_E.get(rc, rc)} (argument not supported by the HIP kernels)")
+    raise DiffNetHipError(f"{what}: hipError_t {rc}")

@@ -1,0 +1,76 @@
+"""PDE base class -- same constructor kwargs, attributes and default hooks as the reference's
+`DiffNet/base.py:6-55`, so user subclasses (IBN_2D.py, examples/*) drop in unchanged.
+
+When pytorch_lightning is importable `PDE` is a real LightningModule; otherwise a minimal
+stand-in (`torch.nn.Module` + no-op `log`) keeps everything else usable (tests, bench, the
+built-in fit loop in diffnet_amd.trainer) without Lightning.
+"""
+import torch
+
+try:  # Lightning is optional at run time (absent on the build and GPU boxes)
+    from pytorch_lightning.core import LightningModule as _Base
+    HAVE_LIGHTNING = True
+except Exception:  # pragma: no cover - depends on the environment
+    HAVE_LIGHTNING = False
+
+    class _Base(torch.nn.Module):
+        """Subset of the LightningModule surface the reference scripts touch on the module itself."""
+
+        current_epoch = 0
+        logger = None
+
+        def __init__(self):
+            super().__init__()
+            self.logged = {}
+
+        def log(self, name, value, *args, **kwargs):
+            self.logged[name] = value.detach() if isinstance(value, torch.Tensor) else value
+
+        def log_dict(self, d, *args, **kwargs):
+            for k, v in d.items():
+                self.log(k, v)
+
+
+class PDE(_Base):
+    """kwargs (reference names): nsd, domain_size, domain_sizes (X,Y,Z), domain_length, domain_lengths,
+    batch_size, n_workers, learning_rate.  A second positional `dataset` is accepted (and stored) because
+    64 legacy scripts of the reference still pass one ("ctor arity drift")."""
+
+    def __init__(self, network, dataset=None, **kwargs):
+        super().__init__()
+        self.kwargs = kwargs
+        self.network = network
+        if dataset is not None:
+            self.dataset = dataset
+        g = kwargs.get
+        self.nsd = g('nsd', 2)
+        self.batch_size = g('batch_size', 64)
+        self.n_workers = g('n_workers', 1)
+        self.learning_rate = g('learning_rate', 3e-4)
+        self.domain_length = g('domain_length', 1.)
+        self.domain_size = g('domain_size', 64)
+        self.domain_lengths_nd = g('domain_lengths', (self.domain_length,) * 3)
+        self.domain_sizes_nd = g('domain_sizes', (self.domain_size,) * 3)
+        if self.nsd >= 2:
+            self.domain_lengthX, self.domain_lengthY = self.domain_lengths_nd[0], self.domain_lengths_nd[1]
+            self.domain_sizeX, self.domain_sizeY = self.domain_sizes_nd[0], self.domain_sizes_nd[1]
+        if self.nsd >= 3:
+            self.domain_lengthZ = self.domain_lengths_nd[2]
+            self.domain_sizeZ = self.domain_sizes_nd[2]
+
+    def loss(self, u, inputs_tensor, forcing_tensor):
+        raise NotImplementedError
+
+    def forward(self, batch):
+        inputs_tensor, forcing_tensor = batch
+        return self.network(inputs_tensor), inputs_tensor, forcing_tensor
+
+    def training_step(self, batch, batch_idx):
+        u, inputs_tensor, forcing_tensor = self.forward(batch)
+        loss_val = self.loss(u, inputs_tensor, forcing_tensor).mean()
+        self.log('PDE_loss', loss_val.item())
+        self.log('loss', loss_val.item())
+        return loss_val
+
+    def configure_optimizers(self):
+        return [torch.optim.Adam(self.network.parameters(), lr=self.learning_rate)], []

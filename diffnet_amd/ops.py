@@ -1,0 +1,334 @@
+"""Torch-facing wrappers around the C ABI (include/diffnet_hip.h): device pointers + the current HIP
+stream are handed to libdiffnet_hip.so; autograd.Function classes pair each forward kernel with
+its adjoint kernel so user `loss()` bodies compose with ordinary torch ops.
+
+No CPU fallback: every op requires fp32 CUDA(HIP) tensors and raises otherwise.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import DnDirichlet, DnMesh, DnPoissonArgs, I32x3, DiffNetHipError
+
+
+def _require(t, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise DiffNetHipError(f"{name} is on {t.device}: the FEM ops run on the GPU only (no CPU fallback); move it with .cuda()")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name} must have {ndim} dims, got shape {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ------------------------------------------------------------------------------------------------
+# generic gauss_pt_eval / assembly
+# ------------------------------------------------------------------------------------------------
+def _sizes_xyz(t, nsd):
+    s = list(t.shape[2:])          # (z, y, x) order in memory
+    s = s[::-1] + [1] * (3 - nsd)  # -> (x, y, z)
+    return I32x3(*s)
+
+
+class _GaussPtEval(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tables, nsd, nbf, stride):
+        x = _require(x, "tensor", nsd + 2)
+        if x.shape[1] != 1:
+            raise ValueError(f"gauss_pt_eval expects a single-channel field (B,1,...), got {tuple(x.shape)}")
+        G = tables.shape[0]
+        out_sp = [(n - nbf) // stride + 1 for n in x.shape[2:]]
+        if min(out_sp) < 1:
+            raise ValueError(f"field {tuple(x.shape)} smaller than the {nbf}-node element")
+        out = torch.empty((x.shape[0], G, *out_sp), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().dn_gauss_pt_eval_fwd(_p(x), _p(tables), _p(out), x.shape[0], nsd, _sizes_xyz(x, nsd), nbf, stride, G,
+                                             _stream(x))
+        _lib.check(rc, "dn_gauss_pt_eval_fwd")
+        ctx.save_for_backward(tables)
+        ctx.meta = (tuple(x.shape), nsd, nbf, stride)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (tables,) = ctx.saved_tensors
+        shape, nsd, nbf, stride = ctx.meta
+        gout = _require(gout, "grad_output")
+        gin = torch.empty(shape, dtype=torch.float32, device=gout.device)
+        sizes = I32x3(*(list(shape[2:])[::-1] + [1] * (3 - nsd)))
+        rc = _lib.lib().dn_gauss_pt_eval_bwd(_p(gout), _p(tables), _p(gin), shape[0], nsd, sizes, nbf, stride, tables.shape[0],
+                                             _stream(gout))
+        _lib.check(rc, "dn_gauss_pt_eval_bwd")
+        return gin, None, None, None, None
+
+
+def stack_tables(N, nsd):
+    """(G, nbf^nsd) contiguous fp32 table from a list / ParameterList of (1,1,*nbf) kernels."""
+    ts = [t.detach().reshape(-1) for t in N]
+    return torch.stack(ts, 0).contiguous().float()
+
+
+def gauss_pt_eval(tensor, N, nsd=2, stride=1):
+    """Drop-in for DiffNet/DiffNetFEM.py:7-18 on the GPU: all len(N) Gauss-point channels in one launch.
+    `N`: sequence of (1,1,*nbf) kernels, or an already stacked (G, nbf^nsd) tensor."""
+    if nsd not in (1, 2, 3):
+        raise UnboundLocalError("nsd must be 1, 2 or 3")   # the reference fails with UnboundLocalError here
+    if isinstance(N, torch.Tensor) and N.dim() == 2:
+        tables = N
+        nbf = round(N.shape[1] ** (1.0 / nsd))
+    else:
+        nbf = N[0].shape[-1]
+        tables = stack_tables(N, nsd)
+    if tables.device != tensor.device:
+        tables = tables.to(tensor.device)
+    return _GaussPtEval.apply(tensor, tables, nsd, nbf, stride)
+
+
+class _Assemble(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r_split, nsd, nbf, base):
+        r_split = _require(r_split, "R_split", nsd + 2)
+        stride = nbf - 1
+        if r_split.shape[1] != nbf ** nsd:
+            raise ValueError(f"R_split must have {nbf ** nsd} local-basis channels, got {r_split.shape[1]}")
+        node_sp = [n * stride + 1 for n in r_split.shape[2:]]
+        if base is not None:
+            out = _require(base, "Aglobal", nsd + 2).clone()
+            if list(out.shape[2:]) != node_sp or out.shape[0] != r_split.shape[0]:
+                raise ValueError("Aglobal shape does not match R_split")
+        else:
+            out = torch.empty((r_split.shape[0], 1, *node_sp), dtype=torch.float32, device=r_split.device)
+        rc = _lib.lib().dn_assemble(_p(r_split), _p(out), r_split.shape[0], nsd, _sizes_xyz(out, nsd), nbf, stride,
+                                    1 if base is not None else 0, _stream(out))
+        _lib.check(rc, "dn_assemble")
+        ctx.meta = (tuple(r_split.shape), nsd, nbf, base is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        shape, nsd, nbf, has_base = ctx.meta
+        gout = _require(gout, "grad_output")
+        gs = torch.empty(shape, dtype=torch.float32, device=gout.device)
+        rc = _lib.lib().dn_assemble_bwd(_p(gout), _p(gs), shape[0], nsd, _sizes_xyz(gout, nsd), nbf, nbf - 1, _stream(gout))
+        _lib.check(rc, "dn_assemble_bwd")
+        return gs, None, None, (gout if has_base else None)
+
+
+def assemble(r_split, nsd, nbf=2, out=None):
+    """Element->node assembly (Q1_2D/3D_vector_assembly of the reference scripts, any degree):
+    returns `out + scatter_add(r_split)` (out = zeros when omitted).  Deterministic gather form."""
+    return _Assemble.apply(r_split, nsd, nbf, out)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused Poisson operator
+# ------------------------------------------------------------------------------------------------
+class Dirichlet:
+    """u <- where(mask > 0.5, value, u); `value` a python float or a nodal field tensor."""
+
+    def __init__(self, mask, value=0.0):
+        self.mask = mask
+        self.value = value
+
+
+def _norm_dirichlet(dirichlet):
+    out = []
+    for d in dirichlet or ():
+        if isinstance(d, Dirichlet):
+            out.append(d)
+        else:
+            m, v = d
+            out.append(Dirichlet(m, v))
+    if len(out) > 2:
+        raise ValueError("at most two Dirichlet conditions per call are supported; merge masks beforehand")
+    return out
+
+
+_WS = {}
+
+
+def _workspace(dev, nbytes):
+    key = (dev.index, )
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _WS[key] = ws
+    return ws
+
+
+def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
+                  out_scale=1.0, want_out=True, want_sums=True):
+    """One launch of dn_poisson_apply.  Returns (out | None, sums | None) where sums is a float64 device
+    tensor [energy, sum(out_unscaled^2)].  See include/diffnet_hip.h for the operator definition."""
+    nsd = geom.nsd
+    u = _require(u, "u", nsd + 2)
+    B = u.shape[0]
+    node_shape = tuple(geom.node_shape)            # (ny, nx) or (nz, ny, nx)
+    if tuple(u.shape[1:]) != (1, *node_shape):
+        raise ValueError(f"u has shape {tuple(u.shape)}, expected (B,1,{','.join(map(str, node_shape))})")
+    keep = [u]
+    args = DnPoissonArgs()
+    args.u = u.data_ptr()
+
+    def field(t, name, allow_gp=False):
+        t = _require(t, name, nsd + 2)
+        if t.shape[0] not in (1, B):
+            raise ValueError(f"{name} batch {t.shape[0]} does not broadcast to {B}")
+        keep.append(t)
+        return t, int(t.shape[0] == B)
+
+    if nu is not None:
+        nu, nb_ = field(nu, "nu")
+        if tuple(nu.shape[1:]) != (1, *node_shape):
+            raise ValueError("nu must be a nodal field")
+        args.nu, args.nu_batched = nu.data_ptr(), nb_
+    if f is not None and f_gp is not None:
+        raise ValueError("give either nodal f or f_gp, not both")
+    if f is not None:
+        f, fb = field(f, "f")
+        if tuple(f.shape[1:]) != (1, *node_shape):
+            raise ValueError("f must be a nodal field")
+        args.f, args.f_batched = f.data_ptr(), fb
+    if f_gp is not None:
+        f_gp, fb = field(f_gp, "f_gp")
+        if tuple(f_gp.shape[1:]) != (geom.ngp_total, *geom.elem_shape):
+            raise ValueError(f"f_gp must have shape (B|1,{geom.ngp_total},{geom.elem_shape})")
+        args.f_gp, args.f_batched = f_gp.data_ptr(), fb
+    for k, d in enumerate(_norm_dirichlet(dirichlet)):
+        m = d.mask
+        if not isinstance(m, torch.Tensor) or not m.is_cuda:
+            raise DiffNetHipError("Dirichlet mask must be a CUDA tensor")
+        if m.dtype == torch.bool:
+            m = m.to(torch.uint8)
+        if m.dtype not in (torch.float32, torch.uint8):
+            raise TypeError("Dirichlet mask must be float32, uint8 or bool")
+        m = m.contiguous()
+        if m.dim() != nsd + 2 or tuple(m.shape[1:]) != (1, *node_shape) or m.shape[0] not in (1, B):
+            raise ValueError(f"Dirichlet mask shape {tuple(m.shape)} does not match u")
+        keep.append(m)
+        bc = args.bc[k]
+        bc.mask = m.data_ptr()
+        bc.mask_is_u8 = int(m.dtype == torch.uint8)
+        bc.mask_batched = int(m.shape[0] == B)
+        if isinstance(d.value, torch.Tensor):
+            v = d.value
+            if v.dim() == nsd:
+                v = v[(None,) * 2]
+            v = _require(v.to(u.device) if not v.is_cuda else v, "Dirichlet value", nsd + 2)
+            if tuple(v.shape[1:]) != (1, *node_shape) or v.shape[0] not in (1, B):
+                raise ValueError("Dirichlet value field shape does not match u")
+            keep.append(v)
+            bc.field = v.data_ptr()
+            bc.field_batched = int(v.shape[0] == B)
+        else:
+            bc.value = float(d.value)
+    args.alpha, args.beta, args.c, args.wscale, args.out_scale = alpha, beta, c, wscale, out_scale
+    mesh = geom.mesh_struct(B)
+    out = torch.empty_like(u) if want_out else None
+    sums = None
+    if out is not None:
+        args.out = out.data_ptr()
+    if want_sums:
+        sums = torch.empty(2, dtype=torch.float64, device=u.device)
+        nbytes = _lib.lib().dn_poisson_workspace_bytes(C.byref(mesh))
+        if nbytes < 0:
+            _lib.check(int(nbytes), "dn_poisson_workspace_bytes")
+        ws = _workspace(u.device, nbytes)
+        keep.append(ws)
+        args.energy = sums.data_ptr()
+        args.sumsq = sums.data_ptr() + 8
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    rc = _lib.lib().dn_poisson_apply(C.byref(mesh), C.byref(args), _stream(u))
+    _lib.check(rc, "dn_poisson_apply")
+    return out, sums
+
+
+class _EnergyLoss(torch.autograd.Function):
+    """Fused energy loss: forward and the gradient wrt u come out of the same single pass."""
+
+    @staticmethod
+    def forward(ctx, u, geom, nu, f, f_gp, dirichlet, c, jac):
+        B = u.shape[0]
+        scale = 1.0 / (B * geom.nelem_total)
+        grad, sums = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac,
+                                   out_scale=scale, want_out=True, want_sums=True)
+        ctx.save_for_backward(grad)
+        return (sums[0] * scale).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return grad * gout, None, None, None, None, None, None, None
+
+
+def energy_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0):
+    """mean_{b,e} sum_g gpw_g*jac*(c*nu_g*|grad u|_g^2 - u_g*f_g), differentiable wrt u (see _EnergyLoss)."""
+    return _EnergyLoss.apply(u, geom, nu, f, f_gp, tuple(_norm_dirichlet(dirichlet)), float(c), float(jac))
+
+
+def energy_loss_and_grad(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0):
+    """(loss, dloss/du) from ONE kernel pass, outside autograd -- the form an optimiser loop wants and the
+    form bench.py measures (16 algorithmic bytes per node: read u, nu, f; write grad)."""
+    B = u.shape[0]
+    scale = 1.0 / (B * geom.nelem_total)
+    grad, sums = poisson_apply(geom, u.detach(), nu, f, f_gp, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac,
+                               out_scale=scale, want_out=True, want_sums=True)
+    return (sums[0] * scale).to(torch.float32), grad
+
+
+class _Residual(torch.autograd.Function):
+    """Assembled weak-form residual R (zero on Dirichlet nodes).  The operator is symmetric in u, so the
+    backward pass is the same kernel applied to the incoming cotangent with f dropped."""
+
+    @staticmethod
+    def forward(ctx, u, geom, nu, f, f_gp, dirichlet, jac):
+        R, _ = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=1.0, beta=1.0, c=0.0, wscale=jac, out_scale=1.0,
+                             want_out=True, want_sums=False)
+        ctx.geom, ctx.nu, ctx.dirichlet, ctx.jac = geom, nu, dirichlet, jac
+        return R
+
+    @staticmethod
+    def backward(ctx, gR):
+        homog = tuple(Dirichlet(d.mask, 0.0) for d in ctx.dirichlet)
+        g, _ = poisson_apply(ctx.geom, gR.contiguous(), ctx.nu, None, None, homog, alpha=1.0, beta=0.0, c=0.0,
+                             wscale=ctx.jac, out_scale=1.0, want_out=True, want_sums=False)
+        return g, None, None, None, None, None, None
+
+
+def residual(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
+    return _Residual.apply(u, geom, nu, f, f_gp, tuple(_norm_dirichlet(dirichlet)), float(jac))
+
+
+class _ResidualLoss(torch.autograd.Function):
+    """sum(R^2) with R from the fused residual kernel; the sum of squares is reduced in the same launch."""
+
+    @staticmethod
+    def forward(ctx, u, geom, nu, f, f_gp, dirichlet, jac):
+        R, sums = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=1.0, beta=1.0, c=0.0, wscale=jac, out_scale=1.0,
+                                want_out=True, want_sums=True)
+        ctx.save_for_backward(R)
+        ctx.geom, ctx.nu, ctx.dirichlet, ctx.jac = geom, nu, dirichlet, jac
+        return sums[1].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (R,) = ctx.saved_tensors
+        homog = tuple(Dirichlet(d.mask, 0.0) for d in ctx.dirichlet)
+        g, _ = poisson_apply(ctx.geom, R, ctx.nu, None, None, homog, alpha=1.0, beta=0.0, c=0.0, wscale=ctx.jac,
+                             out_scale=2.0, want_out=True, want_sums=False)
+        return g * gout, None, None, None, None, None, None
+
+
+def residual_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
+    return _ResidualLoss.apply(u, geom, nu, f, f_gp, tuple(_norm_dirichlet(dirichlet)), float(jac))

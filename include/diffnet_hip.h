@@ -1,0 +1,123 @@
+/*
+ * diffnet_hip.h -- C ABI of libdiffnet_hip.so, the MI355X (gfx950) implementation of the
+ * DiffNet FEM Gauss-quadrature hot path.
+ *
+ * Plain pointers and sizes only: no torch types cross this boundary.  Every pointer is a
+ * DEVICE pointer (HBM resident) unless stated otherwise; tensors are contiguous fp32 in the
+ * reference's layouts: nodal fields (B,1,Ny,Nx) / (B,1,Nz,Ny,Nx), Gauss-point fields
+ * (B,G,nelY,nelX) / (B,G,nelZ,nelY,nelX) with G = ngp_1d^nsd and the Gauss-point id
+ * g = (kg*ngp + jg)*ngp + ig (x fastest), local basis id a = (kb*nbf + jb)*nbf + ib.
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  All entry points are
+ * asynchronous on `stream`, allocate nothing, never synchronise, and are graph-capturable.
+ * Return value: 0 on success, a positive hipError_t from the launch, or a negative DN_E_* code
+ * for an argument the kernels do not support (nothing is launched in that case).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * reference repository root).
+ */
+#ifndef DIFFNET_HIP_H
+#define DIFFNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_ABI_VERSION 1
+
+#define DN_E_BADARG (-1)    /* null pointer / non-positive size / unsupported combination   */
+#define DN_E_UNSUPPORTED (-2) /* (nsd, degree, ngp) outside the compiled instantiations      */
+#define DN_E_WORKSPACE (-3)  /* workspace too small                                           */
+
+/* Geometry + 1-D reference-element tables of one structured mesh.
+ * Mirrors what DiffNetFEM.__init__ derives (DiffNet/DiffNetFEM.py:25-126):
+ *   basis[ig][ib]  = phi_ib(xi_ig)          1-D Lagrange basis at the 1-D Gauss points
+ *   dbasis[ig][ib] = phi'_ib(xi_ig)         derivative in reference coordinates
+ *   gpw[ig]        1-D Gauss weights,  scale[d] = 2/h_d  (d = x,y,z)
+ * The nd tables of the reference (N_gp, dN_x_gp, ...) are the tensor products of these; the
+ * fused kernels apply them axis by axis (sum factorisation) instead of materialising them. */
+typedef struct dn_mesh {
+    int32_t nsd;          /* 2 or 3                                                     */
+    int32_t degree;       /* fem_basis_deg: 1, 2 or 3                                   */
+    int32_t ngp;          /* ngp_1d: 1..4                                               */
+    int32_t batch;        /* B                                                          */
+    int32_t nx, ny, nz;   /* nodes per axis (nz = 1 when nsd == 2)                      */
+    float scale[3];       /* 2/hx, 2/hy, 2/hz                                           */
+    float gpw[4];
+    float basis[4][4];
+    float dbasis[4][4];
+} dn_mesh;
+
+/* One Dirichlet condition: u <- where(mask > 0.5, value, u) with value = field[node] when
+ * `field` is non-null (broadcast over the batch when field_batched == 0) else the constant.
+ * Mirrors the torch.where lines of the loss bodies, e.g. IBN/poisson-2d/parametric/IBN_2D.py:119-121,
+ * examples/poisson/single_instance/e8_2d_poisson_mms.py:120. mask may be fp32 (reference) or u8. */
+typedef struct dn_dirichlet {
+    const void *mask;     /* (B,1,*N) or (1,1,*N); NULL = condition absent              */
+    const float *field;   /* optional Dirichlet values                                  */
+    float value;
+    int32_t mask_is_u8;   /* 0: fp32 mask compared with 0.5, 1: uint8 (non-zero = set)  */
+    int32_t mask_batched; /* 1: (B,...), 0: one mask shared by the whole batch          */
+    int32_t field_batched;
+} dn_dirichlet;
+
+/* Arguments of the fused Poisson operator
+ *     out_a = zero_on_dirichlet( sum_e sum_g W_g ( alpha * nu_g * gradN_a . grad u_g  -  beta * N_a * f_g ) )
+ *     energy = sum_{b,e,g} W_g ( c * nu_g * |grad u_g|^2 - u_g * f_g ),      W_g = gpw_g * wscale
+ * evaluated in ONE pass over the nodal fields with element->node assembly in gather form
+ * (deterministic, no atomics).  It replaces, per call:
+ *   - energy loss + its gradient  (alpha = 2c, beta = 1):  IBN_2D.py:116-134, IBN_3D.py:114-136,
+ *     solve_in_object_3d.py:75-102, 12_klsum.py:53-78, e8_2d_poisson_mms.py:152-180 -- i.e. 5-6
+ *     gauss_pt_eval calls (DiffNet/DiffNetFEM.py:7-18) + ~8 elementwise ops + autograd backward;
+ *   - weak-form residual + Q1_*_vector_assembly + BC mask + sum(R^2) (alpha = beta = 1):
+ *     12_klsum.py:80-132, e8_2d_poisson_mms.py:92-150, e8_3d_poisson_mms.py:89-139, tests/test.py:43-79;
+ *   - the backward of the residual loss: the operator is symmetric, so grad_u = apply(v = 2R, f absent). */
+typedef struct dn_poisson_args {
+    const float *u;        /* (B,1,*N) nodal field                                      */
+    const float *nu;       /* (B,1,*N) or NULL (nu == 1)                                */
+    const float *f;        /* (B,1,*N) nodal forcing or NULL                            */
+    const float *f_gp;     /* (Bf,G,*nel) forcing at Gauss points or NULL (exclusive with f) */
+    int32_t nu_batched;    /* 0: one (1,1,*N) field for the whole batch                 */
+    int32_t f_batched;     /* same for f / f_gp                                         */
+    dn_dirichlet bc[2];    /* applied in order                                          */
+    float alpha, beta, c, wscale;
+    float out_scale;       /* out is multiplied by this (e.g. 1/(B*nel) of torch.mean)  */
+    float *out;            /* (B,1,*N) or NULL                                          */
+    double *energy;        /* device scalar: sum (unscaled) or NULL                     */
+    double *sumsq;         /* device scalar: sum over nodes of (out/out_scale)^2 or NULL */
+    void *workspace;       /* dn_poisson_workspace_bytes() bytes                        */
+    int64_t workspace_bytes;
+} dn_poisson_args;
+
+int dn_abi_version(void);
+/* Human-readable build info ("gfx950 hipcc <ver> ..."), static storage. */
+const char *dn_build_info(void);
+
+int64_t dn_poisson_workspace_bytes(const dn_mesh *mesh);
+int dn_poisson_apply(const dn_mesh *mesh, const dn_poisson_args *args, void *stream);
+
+/* gauss_pt_eval (DiffNet/DiffNetFEM.py:7-18) for an arbitrary table list, and its adjoint.
+ *   out[b,g,e] = sum_a tables[g][a] * in[b, node(e,a)]          (conv_nd with stride `degree`)
+ * in: (B,1,*N); tables: (G, nbf^nsd) device fp32; out: (B,G,*nel). nsd in {1,2,3}, nbf in 2..4.
+ * n[] = nodes per axis in (x,y,z) order (unused axes 1).  The adjoint writes every element of
+ * grad_in exactly once (gather form).  Replaces the 12 gauss_pt_evaluation* wrappers
+ * (DiffNet/DiffNetFEM.py:143-174) and their autograd backward (conv_backward_input). */
+int dn_gauss_pt_eval_fwd(const float *in, const float *tables, float *out, int32_t batch, int32_t nsd,
+                         const int32_t n[3], int32_t nbf, int32_t stride, int32_t G, void *stream);
+int dn_gauss_pt_eval_bwd(const float *grad_out, const float *tables, float *grad_in, int32_t batch, int32_t nsd,
+                         const int32_t n[3], int32_t nbf, int32_t stride, int32_t G, void *stream);
+
+/* Q1_2D_vector_assembly / Q1_3D_vector_assembly (e8_2d_poisson_mms.py:85-90, e8_3d_poisson_mms.py:78-87)
+ * generalised to any degree: out[b, node] (+)= sum over the elements e and local ids a that map to node
+ * of r_split[b,a,e], in the reference's a-ascending order.  accumulate = 0 overwrites `out`.
+ * dn_assemble_bwd is its adjoint: grad_split[b,a,e] = grad_out[b, node(e,a)]. */
+int dn_assemble(const float *r_split, float *out, int32_t batch, int32_t nsd, const int32_t n[3], int32_t nbf,
+                int32_t stride, int32_t accumulate, void *stream);
+int dn_assemble_bwd(const float *grad_out, float *grad_split, int32_t batch, int32_t nsd, const int32_t n[3],
+                    int32_t nbf, int32_t stride, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFNET_HIP_H */

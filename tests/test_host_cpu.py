@@ -1,0 +1,131 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol declared in
+include/diffnet_hip.h, host-built tables are bit-identical to the reference's, the module surface
+(attributes, shapes, state_dict keys, kwargs handling) matches, and the ops refuse CPU tensors."""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from test_oracle_golden import spec_kwargs
+
+FEM_FILES = sorted(glob.glob(os.path.join(GOLDEN, "fem_*.npz")))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "diffnet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_the_whole_abi():
+    from diffnet_amd import _lib, build
+    build.build(verbose=False)
+    h = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 8
+    assert sorted(_lib.SYMBOLS) == syms, "ctypes binding and header disagree"
+    for s in syms:
+        assert hasattr(h, s), s
+    assert h.dn_abi_version() == _lib.ABI_VERSION
+    assert b"gfx950" in h.dn_build_info()
+
+
+def test_launch_planner_rejects_bad_meshes_without_a_gpu():
+    import ctypes as C
+    from diffnet_amd import _lib
+    from diffnet_amd.fem import FemGeometry
+    from diffnet_amd.tables import gauss_rule
+    h = _lib.lib()
+    gx, gw = gauss_rule(2)
+    m = FemGeometry(2, (64, 64), (1 / 63, 1 / 63), 1, 2, gx, gw).mesh_struct(4)
+    assert h.dn_poisson_workspace_bytes(C.byref(m)) > 0
+    m.nx = 1
+    assert h.dn_poisson_workspace_bytes(C.byref(m)) == -1
+    assert h.dn_poisson_apply(C.byref(m), None, None) == -1          # validation happens before any launch
+
+
+@pytest.mark.parametrize("path", FEM_FILES, ids=[os.path.basename(p)[4:-4] for p in FEM_FILES])
+def test_module_surface_matches_reference(path):
+    from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM
+    z = np.load(path)
+    kw = spec_kwargs(z)
+    m = (DiffNet3DFEM if kw["nsd"] == 3 else DiffNet2DFEM)(None, **kw)
+    assert sorted(m.state_dict().keys()) == list(z["state_dict_keys"])
+    for key in z.files:
+        if key.startswith("scalar_"):
+            np.testing.assert_allclose(float(getattr(m, key[7:])), float(z[key]), rtol=1e-6, err_msg=key)
+        elif key.startswith("tab_"):
+            got = np.stack([p.detach().numpy() for p in getattr(m, key[4:])], 0)
+            assert got.shape == z[key].shape, key
+            assert np.array_equal(got, z[key]), key                     # bit identical
+        elif key.startswith("attr_"):
+            got = getattr(m, key[5:]).numpy()
+            assert got.shape == z[key].shape, key
+            if key[5:] in ("xgp", "ygp", "zgp"):
+                np.testing.assert_allclose(got, z[key], rtol=1e-6, atol=1e-6)
+            else:
+                assert np.array_equal(got, z[key]), key
+    np.testing.assert_array_equal(m.gpx_1d, z["gpx_1d"])
+    np.testing.assert_array_equal(m.gpw_1d, z["gpw_1d"])
+    for p in m.parameters():
+        assert not p.requires_grad
+    x = np.array([-0.3, 0.1, 0.9])
+    assert m.bf_1d(x).shape == (m.nbf_1d, 3) and np.allclose(m.bf_1d(x).sum(0), 1.0)
+    assert np.allclose(m.bf_1d_der(x).sum(0), 0.0, atol=1e-12)
+    if m.fem_basis_deg <= 2:
+        tx = torch.tensor(x)
+        np.testing.assert_allclose(m.bf_1d_th(tx).numpy(), m.bf_1d(x), rtol=1e-12)
+        np.testing.assert_allclose(m.bf_1d_der_th(tx).numpy(), m.bf_1d_der(x), rtol=1e-12)
+        np.testing.assert_allclose(m.bf_1d_der2_th(tx).numpy(), m.bf_1d_der2(x), rtol=1e-12)
+
+
+def test_pde_kwargs_and_legacy_constructor():
+    from diffnet_amd import PDE, DiffNet2DFEM, DiffNet3DFEM
+    net = torch.nn.Linear(2, 2)
+    p = PDE(net)
+    assert (p.nsd, p.batch_size, p.n_workers, p.learning_rate, p.domain_size, p.domain_length) == (2, 64, 1, 3e-4, 64, 1.0)
+    p.log("loss", 1.0)
+    opts, sch = p.configure_optimizers()
+    assert isinstance(opts[0], torch.optim.Adam) and sch == []
+    with pytest.raises(NotImplementedError):
+        p.loss(None, None, None)
+    ds = object()
+    m = DiffNet2DFEM(net, ds, domain_size=9)          # legacy 2-positional form (tests/test.py:33 of the reference)
+    assert m.dataset is ds and m.network is net
+    m3 = DiffNet3DFEM(None, nsd=3, domain_sizes=(10, 8, 6), domain_lengths=(2.0, 1.0, 0.5), domain_size=10)
+    assert (m3.nelemX, m3.nelemY, m3.nelemZ) == (9, 7, 5) and m3.xx.shape == (6, 8, 10)
+    assert m3.geom.node_shape == (6, 8, 10) and m3.geom.elem_shape == (5, 7, 9)
+    with pytest.raises(AssertionError):
+        DiffNet2DFEM(None, nsd=3, domain_size=9)
+    with pytest.raises(AssertionError):
+        DiffNet2DFEM(None, domain_size=10, fem_basis_deg=2)
+    assert DiffNet2DFEM(None, domain_size=9, fem_basis_deg=2, ngp_1d=2).ngp_1d == 3     # raised to the degree's minimum
+
+
+def test_ops_refuse_cpu_tensors():
+    from diffnet_amd import DiffNet2DFEM, gauss_pt_eval
+    from diffnet_amd._lib import DiffNetHipError
+    m = DiffNet2DFEM(None, domain_size=9)
+    u = torch.rand(1, 1, 9, 9)
+    with pytest.raises(DiffNetHipError):
+        m.gauss_pt_evaluation(u)
+    with pytest.raises(DiffNetHipError):
+        m.energy_loss(u)
+    with pytest.raises(DiffNetHipError):
+        gauss_pt_eval(u, m.N_gp, nsd=2, stride=1)
+    with pytest.raises(UnboundLocalError):
+        gauss_pt_eval(u, m.N_gp, nsd=4)
+
+
+def test_reference_import_paths():
+    import DiffNet
+    from DiffNet.base import PDE
+    from DiffNet.cuboid_mesh import CuboidMesh
+    from DiffNet.DiffNetFEM import DiffNet2DFEM, DiffNet3DFEM, DiffNetFEM, gauss_pt_eval
+    assert issubclass(DiffNet2DFEM, DiffNetFEM) and issubclass(DiffNetFEM, PDE)
+    x, y, zz = CuboidMesh.meshgrid_3d(np.arange(4.0), np.arange(3.0), np.arange(2.0))
+    assert x.shape == (2, 3, 4) and x[1, 2, 3] == 3 and y[1, 2, 3] == 2 and zz[1, 2, 3] == 1
