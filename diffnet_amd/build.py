@@ -16,8 +16,8 @@ STAMP = os.path.join(HERE, ".libdiffnet_hip.stamp")
 ARCH = "gfx950"
 SOURCES = ["dn_api.hip", "poisson_fused.hip", "gauss_pt_eval.hip"]
 HEADERS = ["dn_common.h", "poisson_elem.h", os.path.join("..", "..", "include", "diffnet_hip.h")]
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-variable",
-         "-Wno-unused-but-set-variable"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-variable",
+         "-Wno-unused-but-set-variable"] + os.environ.get("DN_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

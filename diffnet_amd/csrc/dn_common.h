@@ -45,39 +45,58 @@ struct VecT<2> { using type = float2; };
 template <>
 struct VecT<4> { using type = float4; };
 
-// Load N consecutive floats starting at p[i0]; entries with index >= limit read as `fill`.
-// VEC: the caller guarantees 4*N-byte alignment of &p[i0] (vector load when fully in range).
-template <int N, bool VEC>
-__device__ __forceinline__ void load_run(const float* __restrict__ p, int64_t base, int i0, int limit, float fill,
-                                         float (&dst)[N]) {
-    if constexpr (VEC && (N == 2 || N == 4)) {
-        if (i0 + N <= limit) {
-            using V = typename VecT<N>::type;
-            const V v = *reinterpret_cast<const V*>(p + base + i0);
-            if constexpr (N == 2) { dst[0] = v.x; dst[1] = v.y; }
-            else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
-            return;
-        }
-    }
+// Branch-free row-segment load: NW consecutive nodes starting at x0 plus the node x0+NW shared with the next
+// thread, from a per-sample base pointer (wave-uniform => SGPR) and a 32-bit in-sample offset (=> the
+// `global_load saddr + voffset` form, no 64-bit VALU address arithmetic).  Indices are clamped into [0, nx)
+// so every lane issues the same instructions (no exec-masked regions, no wait between loads); clamped
+// duplicates only ever feed elements that are skipped.
+// VEC: nx % NW == 0 and NW-element aligned rows (checked by the host), so the vector access is aligned.
+template <int NW, bool VEC, typename T>
+__device__ __forceinline__ void load_seg(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[NW + 1]) {
+    if constexpr (VEC && (NW == 2 || NW == 4)) {
+        const unsigned xl = (unsigned)min(x0, nx - NW);
+        if constexpr (sizeof(T) == 4) {
+            using V = typename VecT<NW>::type;
+            const V v = *reinterpret_cast<const V*>(base + (rowoff + xl));
+            const T* vf = reinterpret_cast<const T*>(&v);
 #pragma unroll
-    for (int k = 0; k < N; ++k) dst[k] = (i0 + k < limit) ? p[base + i0 + k] : fill;
+            for (int k = 0; k < NW; ++k) dst[k] = vf[k];
+        } else {
+            static_assert(sizeof(T) == 1, "load_seg: 1- or 4-byte elements");
+            if constexpr (NW == 4) {
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(base + (rowoff + xl));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[k] = (T)((w >> (8 * k)) & 0xffu);
+            } else {
+                const uint16_t w = *reinterpret_cast<const uint16_t*>(base + (rowoff + xl));
+                dst[0] = (T)(w & 0xffu);
+                dst[1] = (T)(w >> 8);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) dst[k] = base[rowoff + (unsigned)min(x0 + k, nx - 1)];
+    }
+    dst[NW] = base[rowoff + (unsigned)min(x0 + NW, nx - 1)];
 }
 
-template <int N, bool VEC>
-__device__ __forceinline__ void store_run(float* __restrict__ p, int64_t base, int i0, int limit, const float (&src)[N]) {
-    if constexpr (VEC && (N == 2 || N == 4)) {
-        if (i0 + N <= limit) {
-            using V = typename VecT<N>::type;
+// Store NW consecutive floats at x0 (entries >= nx dropped).  VEC as above.
+template <int NW, bool VEC>
+__device__ __forceinline__ void store_seg(float* __restrict__ base, unsigned rowoff, int x0, int nx, const float (&src)[NW]) {
+    if constexpr (VEC && (NW == 2 || NW == 4)) {
+        if (x0 < nx) {
+            using V = typename VecT<NW>::type;
             V v;
-            if constexpr (N == 2) { v.x = src[0]; v.y = src[1]; }
-            else { v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3]; }
-            *reinterpret_cast<V*>(p + base + i0) = v;
-            return;
-        }
-    }
+            float* vf = reinterpret_cast<float*>(&v);
 #pragma unroll
-    for (int k = 0; k < N; ++k)
-        if (i0 + k < limit) p[base + i0 + k] = src[k];
+            for (int k = 0; k < NW; ++k) vf[k] = src[k];
+            *reinterpret_cast<V*>(base + (rowoff + (unsigned)x0)) = v;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            if (x0 + k < nx) base[rowoff + (unsigned)(x0 + k)] = src[k];
+    }
 }
 
 }  // namespace dn

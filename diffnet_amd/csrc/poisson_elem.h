@@ -6,8 +6,17 @@
 // here by sum factorisation: the 1-D basis tables are applied axis by axis.  For Q1 the 1-D
 // basis is a lerp, phi(xi) = (1-b, b) with b = (1+xi)/2 and phi' = (-1/2, +1/2), so every 1-D
 // contraction is one subtraction plus one FMA per Gauss point and the derivative is the
-// difference itself; that specialisation is what keeps the kernel under the HBM roofline
+// difference itself; that specialisation is what keeps the kernel near the HBM roofline
 // instead of the VALU roofline.
+//
+// nu and f are always interpolated from nodal values (an absent nu is the constant field 1, an
+// absent f the constant 0: exact under interpolation), so the element code has no runtime flags;
+// FGP selects forcing given directly at the Gauss points (e8_2d_poisson_mms.py:46).
+//
+// Conventions: W_g = w[jg] * wx[ig] (* w[kg]); the returned energy parts are
+//   e1 = sum_g W_g nu_g |grad u|^2_g      (caller multiplies by c)
+//   e2 = sum_g W_g f_g u_g
+// and the nodal contributions are g_a = sum_g W_g ( alpha nu_g gradN_a.grad u_g - beta N_a f_g ).
 #pragma once
 #include "dn_common.h"
 
@@ -19,31 +28,31 @@ struct ElemTab {
     float dx[4][4];      // dbasis[ig][ib] * 2/hx   (generic-degree path)
     float dy[4][4];
     float dz[4][4];
-    float w[4];          // 1-D Gauss weights (wscale folded into w of the x axis: see wx)
-    float wx[4];         // w[ig] * wscale
+    float w[4];          // 1-D Gauss weights
+    float wx[4];         // w[ig] * wscale (the x axis carries the Jacobian / user scale)
+    float w2[4][4];      // w2[jg][ig] = w[jg] * wx[ig]
     float hs[3];         // Q1 path: 0.5 * 2/h_d = 1/h_d
+    float ahs[3];        // alpha * hs[d]
     float alpha, beta, c;
 };
 
-enum { F_NONE = 0, F_NODAL = 1, F_GP = 2 };
-
 // ---------------------------------------------------------------------------------------------
-// 2-D element.  u/nu/f: nodal values [jb][ib]; fg: forcing at Gauss points [jg*NGP+ig] (F_GP).
-// g: contributions to the (P+1)^2 nodes;  returns the element's energy.
+// 2-D element.  u/nu/f: nodal values [jb][ib]; fg: forcing at Gauss points [jg*NGP+ig] (FGP).
 // ---------------------------------------------------------------------------------------------
-template <int P, int NGP>
-__device__ __forceinline__ float elem2d(const ElemTab& T, const bool has_nu, const int fmode,
-                                        const float (&u)[P + 1][P + 1], const float (&nu)[P + 1][P + 1],
-                                        const float (&f)[P + 1][P + 1], const float* fg, float (&g)[P + 1][P + 1]) {
+template <int P, int NGP, bool FGP>
+__device__ __forceinline__ void elem2d(const ElemTab& T, const float (&u)[P + 1][P + 1], const float (&nu)[P + 1][P + 1],
+                                       const float (&f)[P + 1][P + 1], const float* fg, float (&g)[P + 1][P + 1],
+                                       float& e1, float& e2) {
     constexpr int NB = P + 1;
-    float e = 0.f;
+    float a1 = 0.f, a2 = 0.f;
     if constexpr (P == 1) {
         float b1[NGP];
 #pragma unroll
         for (int i = 0; i < NGP; ++i) b1[i] = T.b[i][1];
         const float dx0 = u[0][1] - u[0][0], dx1 = u[1][1] - u[1][0], ddx = dx1 - dx0;
-        float tv0[NGP], dyv[NGP], uy[NGP], uy2[NGP], ux[NGP], ux2[NGP];
-        float tn0[NGP], dyn[NGP], tf0[NGP], dyf[NGP];
+        const float n0 = nu[0][1] - nu[0][0], n1 = nu[1][1] - nu[1][0];
+        const float f0 = f[0][1] - f[0][0], f1 = f[1][1] - f[1][0];
+        float tv0[NGP], dyv[NGP], uy[NGP], uy2[NGP], ux[NGP], ux2[NGP], tn0[NGP], dyn[NGP], tf0[NGP], dyf[NGP];
 #pragma unroll
         for (int i = 0; i < NGP; ++i) {
             tv0[i] = fmaf(b1[i], dx0, u[0][0]);
@@ -52,19 +61,9 @@ __device__ __forceinline__ float elem2d(const ElemTab& T, const bool has_nu, con
             uy2[i] = uy[i] * uy[i];
             ux[i] = T.hs[0] * fmaf(b1[i], ddx, dx0);   // index i is jg here
             ux2[i] = ux[i] * ux[i];
-        }
-        if (has_nu) {
-            const float n0 = nu[0][1] - nu[0][0], n1 = nu[1][1] - nu[1][0];
-#pragma unroll
-            for (int i = 0; i < NGP; ++i) {
-                tn0[i] = fmaf(b1[i], n0, nu[0][0]);
-                dyn[i] = fmaf(b1[i], n1, nu[1][0]) - tn0[i];
-            }
-        }
-        if (fmode == F_NODAL) {
-            const float f0 = f[0][1] - f[0][0], f1 = f[1][1] - f[1][0];
-#pragma unroll
-            for (int i = 0; i < NGP; ++i) {
+            tn0[i] = fmaf(b1[i], n0, nu[0][0]);
+            dyn[i] = fmaf(b1[i], n1, nu[1][0]) - tn0[i];
+            if constexpr (!FGP) {
                 tf0[i] = fmaf(b1[i], f0, f[0][0]);
                 dyf[i] = fmaf(b1[i], f1, f[1][0]) - tf0[i];
             }
@@ -76,38 +75,37 @@ __device__ __forceinline__ float elem2d(const ElemTab& T, const bool has_nu, con
         for (int jg = 0; jg < NGP; ++jg) {
 #pragma unroll
             for (int ig = 0; ig < NGP; ++ig) {
-                const float W = T.w[jg] * T.wx[ig];
                 const float val = fmaf(b1[jg], dyv[ig], tv0[ig]);
-                const float nuv = has_nu ? fmaf(b1[jg], dyn[ig], tn0[ig]) : 1.f;
-                float fv = 0.f;
-                if (fmode == F_NODAL) fv = fmaf(b1[jg], dyf[ig], tf0[ig]);
-                else if (fmode == F_GP) fv = fg[jg * NGP + ig];
-                const float Wn = W * nuv;
-                const float Wf = W * fv;
-                e = fmaf(T.c * Wn, ux2[jg] + uy2[ig], e);
-                e = fmaf(-Wf, val, e);
+                const float nuv = fmaf(b1[jg], dyn[ig], tn0[ig]);
+                float fv;
+                if constexpr (FGP) fv = fg[jg * NGP + ig];
+                else fv = fmaf(b1[jg], dyf[ig], tf0[ig]);
+                const float Wn = T.w2[jg][ig] * nuv;
+                const float Wf = T.w2[jg][ig] * fv;
+                a1 = fmaf(Wn, ux2[jg] + uy2[ig], a1);
+                a2 = fmaf(Wf, val, a2);
                 Qx[jg] += Wn;
                 Qy[ig] += Wn;
-                const float qv = -T.beta * Wf;
-                cs[ig] += qv;
-                c1[ig] = fmaf(b1[jg], qv, c1[ig]);
+                cs[ig] += Wf;
+                c1[ig] = fmaf(b1[jg], Wf, c1[ig]);
             }
         }
-        // transposes
+        // transposes (cs, c1 still lack the factor -beta)
         float cdx1 = 0.f, cdxs = 0.f;
 #pragma unroll
         for (int jg = 0; jg < NGP; ++jg) {
-            const float cx = (T.alpha * T.hs[0]) * (Qx[jg] * ux[jg]);
+            const float cx = T.ahs[0] * (Qx[jg] * ux[jg]);
             cdx1 = fmaf(b1[jg], cx, cdx1);
             cdxs += cx;
         }
         const float cdx0 = cdxs - cdx1;
         float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;   // row sums / b-weighted sums of cot(tv[jb][ig])
+        const float nb = -T.beta;
 #pragma unroll
         for (int ig = 0; ig < NGP; ++ig) {
-            const float cyd = (T.alpha * T.hs[1]) * (Qy[ig] * uy[ig]);
-            const float ct1 = c1[ig] + cyd;      // cot of tv[1][ig]
-            const float ct0 = cs[ig] - ct1;      // cot of tv[0][ig]
+            const float cyd = T.ahs[1] * (Qy[ig] * uy[ig]);
+            const float ct1 = fmaf(nb, c1[ig], cyd);       // cot of tv[1][ig]
+            const float ct0 = fmaf(nb, cs[ig], -ct1);      // cot of tv[0][ig]
             s0 += ct0; s1 += ct1;
             t0 = fmaf(b1[ig], ct0, t0);
             t1 = fmaf(b1[ig], ct1, t1);
@@ -126,8 +124,8 @@ __device__ __forceinline__ float elem2d(const ElemTab& T, const bool has_nu, con
                 for (int ib = 0; ib < NB; ++ib) {
                     a = fmaf(T.b[ig][ib], u[jb][ib], a);
                     d = fmaf(T.dx[ig][ib], u[jb][ib], d);
-                    if (has_nu) n = fmaf(T.b[ig][ib], nu[jb][ib], n);
-                    if (fmode == F_NODAL) q = fmaf(T.b[ig][ib], f[jb][ib], q);
+                    n = fmaf(T.b[ig][ib], nu[jb][ib], n);
+                    if constexpr (!FGP) q = fmaf(T.b[ig][ib], f[jb][ib], q);
                 }
                 tv[jb][ig] = a; td[jb][ig] = d; tn[jb][ig] = n; tf[jb][ig] = q;
             }
@@ -146,15 +144,13 @@ __device__ __forceinline__ float elem2d(const ElemTab& T, const bool has_nu, con
                     val = fmaf(T.b[jg][jb], tv[jb][ig], val);
                     ux = fmaf(T.b[jg][jb], td[jb][ig], ux);
                     uy = fmaf(T.dy[jg][jb], tv[jb][ig], uy);
-                    if (has_nu) nuv = fmaf(T.b[jg][jb], tn[jb][ig], nuv);
-                    if (fmode == F_NODAL) fv = fmaf(T.b[jg][jb], tf[jb][ig], fv);
+                    nuv = fmaf(T.b[jg][jb], tn[jb][ig], nuv);
+                    if constexpr (!FGP) fv = fmaf(T.b[jg][jb], tf[jb][ig], fv);
                 }
-                if (!has_nu) nuv = 1.f;
-                if (fmode == F_GP) fv = fg[jg * NGP + ig];
-                const float W = T.w[jg] * T.wx[ig];
-                const float Wn = W * nuv, Wf = W * fv;
-                e = fmaf(T.c * Wn, ux * ux + uy * uy, e);
-                e = fmaf(-Wf, val, e);
+                if constexpr (FGP) fv = fg[jg * NGP + ig];
+                const float Wn = T.w2[jg][ig] * nuv, Wf = T.w2[jg][ig] * fv;
+                a1 = fmaf(Wn, ux * ux + uy * uy, a1);
+                a2 = fmaf(Wf, val, a2);
                 const float qx = T.alpha * Wn * ux, qy = T.alpha * Wn * uy, qv = -T.beta * Wf;
 #pragma unroll
                 for (int jb = 0; jb < NB; ++jb) {
@@ -177,55 +173,42 @@ __device__ __forceinline__ float elem2d(const ElemTab& T, const bool has_nu, con
                 g[jb][ib] = a;
             }
     }
-    return e;
+    e1 = a1;
+    e2 = a2;
 }
 
 // ---------------------------------------------------------------------------------------------
 // 3-D Q1 element (trilinear hexahedron), lerp form.  u/nu/f: [kb][jb][ib]; fg: [(kg*NGP+jg)*NGP+ig].
 // ---------------------------------------------------------------------------------------------
-template <int NGP>
-__device__ __forceinline__ float elem3d_q1(const ElemTab& T, const bool has_nu, const int fmode,
-                                           const float (&u)[2][2][2], const float (&nu)[2][2][2],
-                                           const float (&f)[2][2][2], const float* fg, float (&g)[2][2][2]) {
+template <int NGP, bool FGP>
+__device__ __forceinline__ void elem3d_q1(const ElemTab& T, const float (&u)[2][2][2], const float (&nu)[2][2][2],
+                                          const float (&f)[2][2][2], const float* fg, float (&g)[2][2][2], float& e1,
+                                          float& e2) {
     float b1[NGP];
 #pragma unroll
     for (int i = 0; i < NGP; ++i) b1[i] = T.b[i][1];
-    float e = 0.f;
+    float a1 = 0.f, a2 = 0.f;
     // ---- forward: x stage, y stage
     float dx[2][2];            // u differences along x            [kb][jb]
     float tv0[2][NGP];         // tv[kb][0][ig]
     float dyv[2][NGP];         // tv[kb][1][ig] - tv[kb][0][ig]
     float vx0[2], ddx[2];      // vx[kb][jg] = fma(b1[jg], ddx[kb], vx0[kb])
+    float tn0[2][NGP], dyn[2][NGP], tf0[2][NGP], dyf[2][NGP];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         dx[kb][0] = u[kb][0][1] - u[kb][0][0];
         dx[kb][1] = u[kb][1][1] - u[kb][1][0];
         vx0[kb] = dx[kb][0];
         ddx[kb] = dx[kb][1] - dx[kb][0];
+        const float n0 = nu[kb][0][1] - nu[kb][0][0], n1 = nu[kb][1][1] - nu[kb][1][0];
+        const float f0 = f[kb][0][1] - f[kb][0][0], f1 = f[kb][1][1] - f[kb][1][0];
 #pragma unroll
         for (int ig = 0; ig < NGP; ++ig) {
             tv0[kb][ig] = fmaf(b1[ig], dx[kb][0], u[kb][0][0]);
             dyv[kb][ig] = fmaf(b1[ig], dx[kb][1], u[kb][1][0]) - tv0[kb][ig];
-        }
-    }
-    float tn0[2][NGP], dyn[2][NGP], tf0[2][NGP], dyf[2][NGP];
-    if (has_nu) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const float n0 = nu[kb][0][1] - nu[kb][0][0], n1 = nu[kb][1][1] - nu[kb][1][0];
-#pragma unroll
-            for (int ig = 0; ig < NGP; ++ig) {
-                tn0[kb][ig] = fmaf(b1[ig], n0, nu[kb][0][0]);
-                dyn[kb][ig] = fmaf(b1[ig], n1, nu[kb][1][0]) - tn0[kb][ig];
-            }
-        }
-    }
-    if (fmode == F_NODAL) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const float f0 = f[kb][0][1] - f[kb][0][0], f1 = f[kb][1][1] - f[kb][1][0];
-#pragma unroll
-            for (int ig = 0; ig < NGP; ++ig) {
+            tn0[kb][ig] = fmaf(b1[ig], n0, nu[kb][0][0]);
+            dyn[kb][ig] = fmaf(b1[ig], n1, nu[kb][1][0]) - tn0[kb][ig];
+            if constexpr (!FGP) {
                 tf0[kb][ig] = fmaf(b1[ig], f0, f[kb][0][0]);
                 dyf[kb][ig] = fmaf(b1[ig], f1, f[kb][1][0]) - tf0[kb][ig];
             }
@@ -235,9 +218,9 @@ __device__ __forceinline__ float elem3d_q1(const ElemTab& T, const bool has_nu, 
     float ux[NGP][NGP], uy[NGP][NGP];   // ux[kg][jg], uy[kg][ig]
 #pragma unroll
     for (int jg = 0; jg < NGP; ++jg) {
-        const float a0 = fmaf(b1[jg], ddx[0], vx0[0]), a1 = fmaf(b1[jg], ddx[1], vx0[1]);
+        const float q0 = fmaf(b1[jg], ddx[0], vx0[0]), q1 = fmaf(b1[jg], ddx[1], vx0[1]);
 #pragma unroll
-        for (int kg = 0; kg < NGP; ++kg) ux[kg][jg] = T.hs[0] * fmaf(b1[kg], a1 - a0, a0);
+        for (int kg = 0; kg < NGP; ++kg) ux[kg][jg] = T.hs[0] * fmaf(b1[kg], q1 - q0, q0);
     }
 #pragma unroll
     for (int ig = 0; ig < NGP; ++ig) {
@@ -250,12 +233,12 @@ __device__ __forceinline__ float elem3d_q1(const ElemTab& T, const bool has_nu, 
     for (int a = 0; a < NGP; ++a)
 #pragma unroll
         for (int b = 0; b < NGP; ++b) Qx[a][b] = Qy[a][b] = 0.f;
-    // cotangents of vv[kb][jg][ig] accumulated as (sum over kg, b1-weighted sum over kg)
-    float cT0[2][NGP], cD[2][NGP];   // after the jg loop: cot of tv[kb][0][ig] partial sums and cot of dyv[kb][ig]
+    float cT0[2][NGP], cD[2][NGP];   // cot of tv[kb][0][ig] (direct path) and of dyv[kb][ig]
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int ig = 0; ig < NGP; ++ig) cT0[kb][ig] = cD[kb][ig] = 0.f;
+    const float nb = -T.beta;
 #pragma unroll
     for (int jg = 0; jg < NGP; ++jg) {
 #pragma unroll
@@ -264,37 +247,34 @@ __device__ __forceinline__ float elem3d_q1(const ElemTab& T, const bool has_nu, 
             const float vv1 = fmaf(b1[jg], dyv[1][ig], tv0[1][ig]);
             const float dz = vv1 - vv0;
             const float uz = T.hs[2] * dz, uz2 = uz * uz;
-            float nn0 = 1.f, dn = 0.f, ff0 = 0.f, df = 0.f;
-            if (has_nu) {
-                nn0 = fmaf(b1[jg], dyn[0][ig], tn0[0][ig]);
-                dn = fmaf(b1[jg], dyn[1][ig], tn0[1][ig]) - nn0;
-            }
-            if (fmode == F_NODAL) {
+            const float nn0 = fmaf(b1[jg], dyn[0][ig], tn0[0][ig]);
+            const float dn = fmaf(b1[jg], dyn[1][ig], tn0[1][ig]) - nn0;
+            float ff0 = 0.f, df = 0.f;
+            if constexpr (!FGP) {
                 ff0 = fmaf(b1[jg], dyf[0][ig], tf0[0][ig]);
                 df = fmaf(b1[jg], dyf[1][ig], tf0[1][ig]) - ff0;
             }
             float Qz = 0.f, cs = 0.f, c1 = 0.f;
 #pragma unroll
             for (int kg = 0; kg < NGP; ++kg) {
-                const float W = T.w[kg] * T.w[jg] * T.wx[ig];
+                const float W = T.w[kg] * T.w2[jg][ig];
                 const float val = fmaf(b1[kg], dz, vv0);
-                const float nuv = has_nu ? fmaf(b1[kg], dn, nn0) : 1.f;
-                float fv = 0.f;
-                if (fmode == F_NODAL) fv = fmaf(b1[kg], df, ff0);
-                else if (fmode == F_GP) fv = fg[(kg * NGP + jg) * NGP + ig];
+                const float nuv = fmaf(b1[kg], dn, nn0);
+                float fv;
+                if constexpr (FGP) fv = fg[(kg * NGP + jg) * NGP + ig];
+                else fv = fmaf(b1[kg], df, ff0);
                 const float Wn = W * nuv, Wf = W * fv;
-                e = fmaf(T.c * Wn, ux[kg][jg] * ux[kg][jg] + uy[kg][ig] * uy[kg][ig] + uz2, e);
-                e = fmaf(-Wf, val, e);
+                a1 = fmaf(Wn, ux[kg][jg] * ux[kg][jg] + uy[kg][ig] * uy[kg][ig] + uz2, a1);
+                a2 = fmaf(Wf, val, a2);
                 Qx[kg][jg] += Wn;
                 Qy[kg][ig] += Wn;
                 Qz += Wn;
-                const float qv = -T.beta * Wf;
-                cs += qv;
-                c1 = fmaf(b1[kg], qv, c1);
+                cs += Wf;
+                c1 = fmaf(b1[kg], Wf, c1);
             }
             // cot of vv1 / vv0 (value path + z-derivative path)
-            const float cz = (T.alpha * T.hs[2]) * (Qz * uz);
-            const float cv1 = c1 + cz, cv0 = cs - cv1;
+            const float cz = T.ahs[2] * (Qz * uz);
+            const float cv1 = fmaf(nb, c1, cz), cv0 = fmaf(nb, cs, -cv1);
             // y-stage transpose: vv[kb] = fma(b1[jg], dyv[kb][ig], tv0[kb][ig])
             cT0[0][ig] += cv0; cD[0][ig] = fmaf(b1[jg], cv0, cD[0][ig]);
             cT0[1][ig] += cv1; cD[1][ig] = fmaf(b1[jg], cv1, cD[1][ig]);
@@ -306,20 +286,20 @@ __device__ __forceinline__ float elem3d_q1(const ElemTab& T, const bool has_nu, 
         float s = 0.f, t = 0.f;
 #pragma unroll
         for (int kg = 0; kg < NGP; ++kg) {
-            const float cy = (T.alpha * T.hs[1]) * (Qy[kg][ig] * uy[kg][ig]);
+            const float cy = T.ahs[1] * (Qy[kg][ig] * uy[kg][ig]);
             s += cy; t = fmaf(b1[kg], cy, t);
         }
         cD[1][ig] += t;
         cD[0][ig] += s - t;
     }
-    // x-derivative path: ux[kg][jg] = hs0 * fma(b1[kg], a1-a0, a0), a_kb = fma(b1[jg], ddx[kb], vx0[kb])
+    // x-derivative path: ux[kg][jg] = hs0 * fma(b1[kg], q1-q0, q0), q_kb = fma(b1[jg], ddx[kb], vx0[kb])
     float cX0[2] = {0.f, 0.f}, cDD[2] = {0.f, 0.f};   // cot of vx0[kb] (= dx[kb][0]) and of ddx[kb]
 #pragma unroll
     for (int jg = 0; jg < NGP; ++jg) {
         float s = 0.f, t = 0.f;
 #pragma unroll
         for (int kg = 0; kg < NGP; ++kg) {
-            const float cx = (T.alpha * T.hs[0]) * (Qx[kg][jg] * ux[kg][jg]);
+            const float cx = T.ahs[0] * (Qx[kg][jg] * ux[kg][jg]);
             s += cx; t = fmaf(b1[kg], cx, t);
         }
         const float ca1 = t, ca0 = s - t;
@@ -329,7 +309,6 @@ __device__ __forceinline__ float elem3d_q1(const ElemTab& T, const bool has_nu, 
     // x-stage transpose
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-        // cot of tv[kb][1][ig] = cD[kb][ig]; cot of tv[kb][0][ig] = cT0[kb][ig] - cD[kb][ig]
         float s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int ig = 0; ig < NGP; ++ig) {
@@ -337,12 +316,12 @@ __device__ __forceinline__ float elem3d_q1(const ElemTab& T, const bool has_nu, 
             s0 += c0_; t0 = fmaf(b1[ig], c0_, t0);
             s1 += c1_; t1 = fmaf(b1[ig], c1_, t1);
         }
-        // cot of dx[kb][1] = cDD[kb]; cot of dx[kb][0] = cX0[kb] - cDD[kb]
         const float cdx1 = cDD[kb], cdx0 = cX0[kb] - cDD[kb];
         g[kb][0][1] = t0 + cdx0; g[kb][0][0] = s0 - g[kb][0][1];
         g[kb][1][1] = t1 + cdx1; g[kb][1][0] = s1 - g[kb][1][1];
     }
-    return e;
+    e1 = a1;
+    e2 = a2;
 }
 
 }  // namespace dn

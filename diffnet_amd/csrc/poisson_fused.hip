@@ -15,6 +15,9 @@
 // tile seams are closed by recomputing one element layer (no atomics => bitwise reproducible).
 // HBM traffic is the algorithmic minimum: each nodal field is read once (+ halo re-reads that hit
 // L2), the output is written once.
+#include <cstdio>
+#include <cstdlib>
+
 #include "dn_common.h"
 #include "poisson_elem.h"
 
@@ -39,36 +42,147 @@ struct PoissonParams {
     float* out;
     double* part_energy;   // per-workgroup partial sums (workspace)
     double* part_sumsq;
+    unsigned* counter;     // arrival counter of the in-kernel final reduction (self-resetting)
+    double* energy;        // final scalars (may be null)
+    double* sumsq;
     int nx, ny, nz;        // nodes
     int nelx, nely, nelz;  // elements
     int rows_per_strip;    // element layers per strip along the marched axis
-    int want_energy, want_sumsq;
+    int want_sums;
 };
 
-// Dirichlet application for one node.  Returns the (possibly replaced) value; sets `fixed`.
-__device__ __forceinline__ float apply_bc(const PoissonParams& p, float v, int b, int64_t node, int64_t nodes_per_sample,
-                                          bool& fixed) {
+// Per-sample base pointers (wave-uniform): all in-kernel indexing is a 32-bit offset from these.
+struct SampleBases {
+    const float* u;
+    const float* nu;
+    const float* f;
+    float* out;
+    const void* mask[2];
+    const float* field[2];
+};
+
+__device__ __forceinline__ SampleBases sample_bases(const PoissonParams& p, int b, int64_t nps) {
+    SampleBases s;
+    s.u = p.u + (int64_t)b * nps;
+    s.nu = p.nu ? p.nu + (p.nu_batched ? (int64_t)b * nps : 0) : nullptr;
+    s.f = p.f ? p.f + (p.f_batched ? (int64_t)b * nps : 0) : nullptr;
+    s.out = p.out ? p.out + (int64_t)b * nps : nullptr;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const DirichletDev& d = p.bc[k];
-        if (d.mask != nullptr) {
-            const int64_t mi = (d.mask_batched ? (int64_t)b * nodes_per_sample : 0) + node;
-            const bool set = d.mask_is_u8 ? (reinterpret_cast<const uint8_t*>(d.mask)[mi] != 0)
-                                          : (reinterpret_cast<const float*>(d.mask)[mi] > 0.5f);
-            if (set) {
-                v = d.field ? d.field[(d.field_batched ? (int64_t)b * nodes_per_sample : 0) + node] : d.value;
-                fixed = true;
-            }
+        const int64_t mo = d.mask_batched ? (int64_t)b * nps : 0;
+        s.mask[k] = d.mask ? (d.mask_is_u8 ? (const void*)(reinterpret_cast<const uint8_t*>(d.mask) + mo)
+                                           : (const void*)(reinterpret_cast<const float*>(d.mask) + mo))
+                           : nullptr;
+        s.field[k] = d.field ? d.field + (d.field_batched ? (int64_t)b * nps : 0) : nullptr;
+    }
+    return s;
+}
+
+// Dirichlet conditions for one row segment (nodes x0..x0+NW): all mask / value loads are issued first, then
+// u <- where(mask > 0.5, value, u) is applied with selects.  Returns the bit set of fixed nodes.
+template <int NW, bool VEC>
+__device__ __forceinline__ unsigned load_apply_bc(const PoissonParams& p, const SampleBases& sb, unsigned rowoff, int x0,
+                                                  float (&u)[NW + 1]) {
+    uint8_t m8[2][NW + 1];
+    float mf[2][NW + 1], fv[2][NW + 1];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (sb.mask[k] != nullptr) {
+            if (p.bc[k].mask_is_u8) load_seg<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, m8[k]);
+            else load_seg<NW, VEC>(reinterpret_cast<const float*>(sb.mask[k]), rowoff, x0, p.nx, mf[k]);
+            if (sb.field[k]) load_seg<NW, VEC>(sb.field[k], rowoff, x0, p.nx, fv[k]);
         }
     }
-    return v;
+    unsigned bits = 0u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (sb.mask[k] != nullptr) {
+            unsigned kb = 0u;
+            if (p.bc[k].mask_is_u8) {
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) kb |= (m8[k][n] != 0) ? (1u << n) : 0u;
+            } else {
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) kb |= (mf[k][n] > 0.5f) ? (1u << n) : 0u;
+            }
+            if (sb.field[k]) {
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) u[n] = (kb & (1u << n)) ? fv[k][n] : u[n];
+            } else {
+                const float val = p.bc[k].value;
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) u[n] = (kb & (1u << n)) ? val : u[n];
+            }
+            bits |= kb;
+        }
+    }
+    return bits;
+}
+
+// Block-level reduction of the two scalars + arrival of this workgroup at the in-kernel final reduction.
+// Two-level arrival (DN_NSHARD shard counters on separate 64-B lines, then one top counter) keeps the
+// same-address atomic fan-in at ~nblocks/64 + 64 instead of nblocks (one address retires only ~88 atomics/us:
+// MI355X_MICROARCH.md "fanin").  The workgroup that arrives last sums all per-workgroup partials in index
+// order (=> deterministic whatever the arrival order); counters are reset by their last arriver, so the
+// workspace is ready for the next launch.  Protocol (cdna_hip_programming.md, Guideline 16): partials are
+// stored write-through (sc1) and drained before the arrival atomic; the last arriver does an agent-scope
+// acquire and reads the partials with sc1 loads.
+#define DN_NSHARD 64
+__device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, float e2, float sq, int tid, int nthreads,
+                                            double* red, int* flag) {
+    const int nblocks = gridDim.x * gridDim.y * gridDim.z;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const double es = block_sum((double)p.T.c * (double)e1 - (double)e2, red, tid, nthreads);
+    const double ss = block_sum((double)sq, red, tid, nthreads);
+    if (tid == 0) {
+        // write-through (sc1) 8-byte stores + drain instead of an agent-scope release fence: a release is a
+        // `buffer_wbl2` of the whole XCD L2, i.e. every workgroup would wait for everybody's freshly written
+        // output lines to be flushed (measured: +5..30 us per workgroup at 8k workgroups).
+        __hip_atomic_store(&p.part_energy[blk], es, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.part_sumsq[blk], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int nshard = nblocks < DN_NSHARD ? nblocks : DN_NSHARD;
+        const int shard = blk % nshard;
+        const unsigned in_shard = (unsigned)((nblocks - shard + nshard - 1) / nshard);
+        unsigned* sc = p.counter + 16 * (1 + shard);              // shard counters: one per 64-B line
+        int last = 0;
+        const unsigned prev = __hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == in_shard - 1) {
+            __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned prev2 = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (prev2 == (unsigned)(nshard - 1)) ? 1 : 0;
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag) {
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        double e = 0.0, s = 0.0;
+        for (int i = tid; i < nblocks; i += nthreads) {
+            e += __hip_atomic_load(&p.part_energy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s += __hip_atomic_load(&p.part_sumsq[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        e = block_sum(e, red, tid, nthreads);
+        s = block_sum(s, red, tid, nthreads);
+        if (tid == 0) {
+            if (p.energy) *p.energy = e;
+            if (p.sumsq) *p.sumsq = s;
+            __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // =============================================================================================
 // 2-D kernel.  grid = (chunks_x, strips_y, B), block = T threads.
-//   P   : element degree, NGP: 1-D Gauss points, E: elements per thread along x, VEC: vector ld/st legal
+//   P: element degree, NGP: 1-D Gauss points, E: elements per thread along x, VEC: vector ld/st legal,
+//   FGP: forcing given at Gauss points
 // =============================================================================================
-template <int P, int NGP, int E, bool VEC>
+template <int P, int NGP, int E, bool VEC, bool FGP>
 __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
     constexpr int NB = P + 1;
     constexpr int NW = E * P;             // nodes owned per thread per node row
@@ -80,17 +194,18 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
     const int x0 = ex0 * P;               // first node
     const bool col_owner = !(chunk > 0 && tid == 0);
     const int64_t nps = (int64_t)p.nx * p.ny;            // nodes per sample
-    const int64_t eps = (int64_t)p.nelx * p.nely;        // elements per sample
+    const unsigned eps = (unsigned)(p.nelx * p.nely);    // elements per sample
+    const SampleBases sb = sample_bases(p, b, nps);
+    const float* fgp = FGP ? p.fgp + (p.f_batched ? (int64_t)b * eps * (NGP * NGP) : 0) : nullptr;
     const int R = p.rows_per_strip;
     const int ey_own = strip * R;
     const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;
     const int ey_end = min(ey_own + R, p.nely);
-    const bool has_nu = p.nu != nullptr;
-    const int fmode = p.f ? F_NODAL : (p.fgp ? F_GP : F_NONE);
-    const bool any_bc = p.bc[0].mask != nullptr || p.bc[1].mask != nullptr;
+    const bool any_bc = sb.mask[0] != nullptr || sb.mask[1] != nullptr;
 
     __shared__ float xch[2][P][256];
     __shared__ double red[8];
+    __shared__ int last_flag;
 
     float cu[NB][NW + 1], cn[NB][NW + 1], cf[NB][NW + 1];
     unsigned fixed[NB];                   // bit n: node (row r, n) is a Dirichlet node
@@ -103,45 +218,14 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
     }
 
     auto load_row = [&](int r, int yr) {
-        const int64_t rowbase = (int64_t)yr * p.nx;
-        {
-            float tmp[NW];
-            load_run<NW, VEC>(p.u, (int64_t)b * nps + rowbase, x0, p.nx, 0.f, tmp);
-#pragma unroll
-            for (int n = 0; n < NW; ++n) cu[r][n] = tmp[n];
-            cu[r][NW] = (x0 + NW < p.nx) ? p.u[(int64_t)b * nps + rowbase + x0 + NW] : 0.f;
-        }
-        if (has_nu) {
-            const int64_t base = (p.nu_batched ? (int64_t)b * nps : 0) + rowbase;
-            float tmp[NW];
-            load_run<NW, VEC>(p.nu, base, x0, p.nx, 0.f, tmp);
-#pragma unroll
-            for (int n = 0; n < NW; ++n) cn[r][n] = tmp[n];
-            cn[r][NW] = (x0 + NW < p.nx) ? p.nu[base + x0 + NW] : 0.f;
-        }
-        if (fmode == F_NODAL) {
-            const int64_t base = (p.f_batched ? (int64_t)b * nps : 0) + rowbase;
-            float tmp[NW];
-            load_run<NW, VEC>(p.f, base, x0, p.nx, 0.f, tmp);
-#pragma unroll
-            for (int n = 0; n < NW; ++n) cf[r][n] = tmp[n];
-            cf[r][NW] = (x0 + NW < p.nx) ? p.f[base + x0 + NW] : 0.f;
-        }
-        unsigned bits = 0u;
-        if (any_bc) {
-#pragma unroll
-            for (int n = 0; n <= NW; ++n) {
-                if (x0 + n < p.nx) {
-                    bool fx = false;
-                    cu[r][n] = apply_bc(p, cu[r][n], b, rowbase + x0 + n, nps, fx);
-                    bits |= fx ? (1u << n) : 0u;
-                }
-            }
-        }
-        fixed[r] = bits;
+        const unsigned rowoff = (unsigned)yr * (unsigned)p.nx;
+        load_seg<NW, VEC>(sb.u, rowoff, x0, p.nx, cu[r]);
+        if (sb.nu) load_seg<NW, VEC>(sb.nu, rowoff, x0, p.nx, cn[r]);
+        if (sb.f) load_seg<NW, VEC>(sb.f, rowoff, x0, p.nx, cf[r]);
+        fixed[r] = any_bc ? load_apply_bc<NW, VEC>(p, sb, rowoff, x0, cu[r]) : 0u;
     };
 
-    float e_acc = 0.f, sq_acc = 0.f;
+    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
     int par = 0;
 
     // Emit node row `yr` from acc[r] (adds the left neighbour's hand-over for n == 0).
@@ -154,11 +238,11 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
                 float v = acc[r][n] + (n == 0 ? left : 0.f);
-                if (fixed[r] & (1u << n)) v = 0.f;
-                if (x0 + n < p.nx) sq_acc = fmaf(v, v, sq_acc);
+                v = (fixed[r] & (1u << n)) ? 0.f : v;
+                sq_acc = (x0 + n < p.nx) ? fmaf(v, v, sq_acc) : sq_acc;
                 o[n] = v * p.out_scale;
             }
-            if (p.out) store_run<NW, VEC>(p.out, (int64_t)b * nps + (int64_t)yr * p.nx, x0, p.nx, o);
+            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)yr * (unsigned)p.nx, x0, p.nx, o);
         }
     };
 
@@ -167,6 +251,7 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
 #pragma unroll
         for (int r = 1; r <= P; ++r) load_row(r, ey * P + r);
         const bool own_layer = ey >= ey_own;
+        const bool count = own_layer && col_owner;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             if (ex0 + e < p.nelx) {
@@ -180,13 +265,15 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
                         lf[jb][ib] = cf[jb][e * P + ib];
                     }
                 float fg[NGP * NGP];
-                if (fmode == F_GP) {
-                    const int64_t base = (p.f_batched ? (int64_t)b * eps * (NGP * NGP) : 0) + (int64_t)ey * p.nelx + ex0 + e;
+                if constexpr (FGP) {
+                    const unsigned eo = (unsigned)ey * (unsigned)p.nelx + (unsigned)(ex0 + e);
 #pragma unroll
-                    for (int gi = 0; gi < NGP * NGP; ++gi) fg[gi] = p.fgp[base + (int64_t)gi * eps];
+                    for (int gi = 0; gi < NGP * NGP; ++gi) fg[gi] = fgp[eo + (unsigned)gi * eps];
                 }
-                const float ee = elem2d<P, NGP>(p.T, has_nu, fmode, lu, ln, lf, fg, g);
-                if (own_layer && col_owner) e_acc += ee;
+                float e1, e2;
+                elem2d<P, NGP, FGP>(p.T, lu, ln, lf, fg, g, e1, e2);
+                e1_acc += count ? e1 : 0.f;
+                e2_acc += count ? e2 : 0.f;
 #pragma unroll
                 for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
@@ -210,20 +297,16 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
     // the last strip also owns the top boundary row of the domain
     if (ey_end == p.nely) emit_row(0, p.ny - 1, true);
 
-    if (p.want_energy || p.want_sumsq) {
-        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        const double es = block_sum((double)e_acc, red, tid, T);
-        const double ss = block_sum((double)sq_acc, red, tid, T);
-        if (tid == 0) { p.part_energy[blk] = es; p.part_sumsq[blk] = ss; }
-    }
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);
 }
 
 // =============================================================================================
 // 3-D Q1 kernel.  grid = (chunks_x * tiles_y, strips_z, B), block = (TX, TY).
 // =============================================================================================
-template <int NGP, int E, bool VEC>
+template <int NGP, int E, bool VEC, bool FGP>
 __global__ void __launch_bounds__(256) poisson3d_q1_kernel(const PoissonParams p, const int chunks_x) {
     constexpr int NW = E;
+    constexpr int G = NGP * NGP * NGP;
     const int TX = blockDim.x, TY = blockDim.y;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * TX + tx;
@@ -232,22 +315,24 @@ __global__ void __launch_bounds__(256) poisson3d_q1_kernel(const PoissonParams p
     const int ex0 = q * E, x0 = ex0;
     const int ey = tile * (TY - 1) + ty;          // element row == lower node row of this thread
     const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);
-    const int64_t npl = (int64_t)p.nx * p.ny;     // nodes per plane
-    const int64_t nps = npl * p.nz;
-    const int64_t eps = (int64_t)p.nelx * p.nely * p.nelz;
+    const unsigned npl = (unsigned)(p.nx * p.ny);     // nodes per plane
+    const int64_t nps = (int64_t)npl * p.nz;
+    const unsigned epl = (unsigned)(p.nelx * p.nely);
+    const unsigned eps = epl * (unsigned)p.nelz;
+    const SampleBases sb = sample_bases(p, b, nps);
+    const float* fgp = FGP ? p.fgp + (p.f_batched ? (int64_t)b * eps * G : 0) : nullptr;
     const int R = p.rows_per_strip;
     const int ez_own = strip * R;
     const int ez_begin = ez_own > 0 ? ez_own - 1 : 0;
     const int ez_end = min(ez_own + R, p.nelz);
-    const bool has_nu = p.nu != nullptr;
-    const int fmode = p.f ? F_NODAL : (p.fgp ? F_GP : F_NONE);
-    const bool any_bc = p.bc[0].mask != nullptr || p.bc[1].mask != nullptr;
+    const bool any_bc = sb.mask[0] != nullptr || sb.mask[1] != nullptr;
     const bool row_ok = ey < p.nely;              // thread has real elements
     const bool noderow_ok = ey < p.ny;            // thread's lower node row exists
 
     // hand-over slots: [parity][slot][thread]; slots: 0 = right (jb0,n=NW), 1..NW = up (jb1,n<NW), NW+1 = up-right
     __shared__ float xch[2][NW + 2][256];
     __shared__ double red[8];
+    __shared__ int last_flag;
 
     float cu[2][2][NW + 1], cn[2][2][NW + 1], cf[2][2][NW + 1];   // [plane kb][row jb][n]
     unsigned fixed[2];                                            // Dirichlet bits of (plane kb, row jb = 0)
@@ -262,51 +347,25 @@ __global__ void __launch_bounds__(256) poisson3d_q1_kernel(const PoissonParams p
     }
 
     auto load_plane = [&](int kb, int z) {
+        unsigned rowoff[2];
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
-            const int y = ey + jb;
-            if (y < p.ny) {
-                const int64_t rowbase = (int64_t)z * npl + (int64_t)y * p.nx;
-                {
-                    float tmp[NW];
-                    load_run<NW, VEC>(p.u, (int64_t)b * nps + rowbase, x0, p.nx, 0.f, tmp);
+            const int y = min(ey + jb, p.ny - 1);       // clamped: rows beyond the domain only feed skipped elements
+            rowoff[jb] = (unsigned)z * npl + (unsigned)y * (unsigned)p.nx;
+            load_seg<NW, VEC>(sb.u, rowoff[jb], x0, p.nx, cu[kb][jb]);
+            if (sb.nu) load_seg<NW, VEC>(sb.nu, rowoff[jb], x0, p.nx, cn[kb][jb]);
+            if (sb.f) load_seg<NW, VEC>(sb.f, rowoff[jb], x0, p.nx, cf[kb][jb]);
+        }
+        if (any_bc) {
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) cu[kb][jb][n] = tmp[n];
-                    cu[kb][jb][NW] = (x0 + NW < p.nx) ? p.u[(int64_t)b * nps + rowbase + x0 + NW] : 0.f;
-                }
-                if (has_nu) {
-                    const int64_t base = (p.nu_batched ? (int64_t)b * nps : 0) + rowbase;
-                    float tmp[NW];
-                    load_run<NW, VEC>(p.nu, base, x0, p.nx, 0.f, tmp);
-#pragma unroll
-                    for (int n = 0; n < NW; ++n) cn[kb][jb][n] = tmp[n];
-                    cn[kb][jb][NW] = (x0 + NW < p.nx) ? p.nu[base + x0 + NW] : 0.f;
-                }
-                if (fmode == F_NODAL) {
-                    const int64_t base = (p.f_batched ? (int64_t)b * nps : 0) + rowbase;
-                    float tmp[NW];
-                    load_run<NW, VEC>(p.f, base, x0, p.nx, 0.f, tmp);
-#pragma unroll
-                    for (int n = 0; n < NW; ++n) cf[kb][jb][n] = tmp[n];
-                    cf[kb][jb][NW] = (x0 + NW < p.nx) ? p.f[base + x0 + NW] : 0.f;
-                }
-                if (any_bc) {
-                    unsigned bits = 0u;
-#pragma unroll
-                    for (int n = 0; n <= NW; ++n) {
-                        if (x0 + n < p.nx) {
-                            bool fx = false;
-                            cu[kb][jb][n] = apply_bc(p, cu[kb][jb][n], b, rowbase + x0 + n, nps, fx);
-                            bits |= fx ? (1u << n) : 0u;
-                        }
-                    }
-                    if (jb == 0) fixed[kb] = bits;
-                }
+            for (int jb = 0; jb < 2; ++jb) {
+                const unsigned bits = load_apply_bc<NW, VEC>(p, sb, rowoff[jb], x0, cu[kb][jb]);
+                if (jb == 0) fixed[kb] = bits;
             }
         }
     };
 
-    float e_acc = 0.f, sq_acc = 0.f;
+    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
     int par = 0;
 
     // Emit node plane z, row ey (jb = 0), nodes x0..x0+NW-1 from acc[0].
@@ -326,11 +385,11 @@ __global__ void __launch_bounds__(256) poisson3d_q1_kernel(const PoissonParams p
                     if (tx > 0) v += xch[par][0][tid - 1];
                     if (tx > 0 && ty > 0) v += xch[par][NW + 1][tid - TX - 1];
                 }
-                if (fixed[0] & (1u << n)) v = 0.f;
-                if (x0 + n < p.nx) sq_acc = fmaf(v, v, sq_acc);
+                v = (fixed[0] & (1u << n)) ? 0.f : v;
+                sq_acc = (x0 + n < p.nx) ? fmaf(v, v, sq_acc) : sq_acc;
                 o[n] = v * p.out_scale;
             }
-            if (p.out) store_run<NW, VEC>(p.out, (int64_t)b * nps + (int64_t)z * npl + (int64_t)ey * p.nx, x0, p.nx, o);
+            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)z * npl + (unsigned)ey * (unsigned)p.nx, x0, p.nx, o);
         }
         par ^= 1;
     };
@@ -339,6 +398,7 @@ __global__ void __launch_bounds__(256) poisson3d_q1_kernel(const PoissonParams p
     for (int ez = ez_begin; ez < ez_end; ++ez) {
         load_plane(1, ez + 1);
         const bool own_layer = ez >= ez_own;
+        const bool count = own_layer && owner;
         if (row_ok) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -354,16 +414,16 @@ __global__ void __launch_bounds__(256) poisson3d_q1_kernel(const PoissonParams p
                                 ln[kb][jb][ib] = cn[kb][jb][e + ib];
                                 lf[kb][jb][ib] = cf[kb][jb][e + ib];
                             }
-                    float fg[NGP * NGP * NGP];
-                    if (fmode == F_GP) {
-                        constexpr int G = NGP * NGP * NGP;
-                        const int64_t base = (p.f_batched ? (int64_t)b * eps * G : 0) +
-                                             ((int64_t)ez * p.nely + ey) * p.nelx + ex0 + e;
+                    float fg[G];
+                    if constexpr (FGP) {
+                        const unsigned eo = (unsigned)ez * epl + (unsigned)ey * (unsigned)p.nelx + (unsigned)(ex0 + e);
 #pragma unroll
-                        for (int gi = 0; gi < G; ++gi) fg[gi] = p.fgp[base + (int64_t)gi * eps];
+                        for (int gi = 0; gi < G; ++gi) fg[gi] = fgp[eo + (unsigned)gi * eps];
                     }
-                    const float ee = elem3d_q1<NGP>(p.T, has_nu, fmode, lu, ln, lf, fg, g);
-                    if (own_layer && owner) e_acc += ee;
+                    float e1, e2;
+                    elem3d_q1<NGP, FGP>(p.T, lu, ln, lf, fg, g, e1, e2);
+                    e1_acc += count ? e1 : 0.f;
+                    e2_acc += count ? e2 : 0.f;
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -386,26 +446,7 @@ __global__ void __launch_bounds__(256) poisson3d_q1_kernel(const PoissonParams p
     }
     if (ez_end == p.nelz) emit_plane(p.nz - 1, true);
 
-    if (p.want_energy || p.want_sumsq) {
-        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        const double es = block_sum((double)e_acc, red, tid, TX * TY);
-        const double ss = block_sum((double)sq_acc, red, tid, TX * TY);
-        if (tid == 0) { p.part_energy[blk] = es; p.part_sumsq[blk] = ss; }
-    }
-}
-
-// Sum the per-workgroup partials in a fixed order (deterministic) into the two output scalars.
-__global__ void __launch_bounds__(256) poisson_finalize_kernel(const double* __restrict__ pe, const double* __restrict__ ps,
-                                                               int n, double* energy, double* sumsq) {
-    __shared__ double red[8];
-    double e = 0.0, s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) { e += pe[i]; s += ps[i]; }
-    e = block_sum(e, red, threadIdx.x, 256);
-    s = block_sum(s, red, threadIdx.x, 256);
-    if (threadIdx.x == 0) {
-        if (energy) *energy = e;
-        if (sumsq) *sumsq = s;
-    }
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, TX * TY, red, &last_flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -415,6 +456,9 @@ struct Geom2D { int T, E, chunks, strips, R; };
 struct Geom3D { int TX, TY, E, chunks, tiles, strips, R; };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// workspace layout: [arrival counters][partial energies: nwg doubles][partial sumsq: nwg doubles]
+static constexpr int64_t DN_WS_HEADER = 64 * (1 + 64);   // top counter + DN_NSHARD shard counters, one 64-B line each
 
 static int chunks_for(int logical_threads, int T) {
     return logical_threads <= T ? 1 : ceil_div(logical_threads - 1, T - 1);
@@ -475,12 +519,40 @@ static Geom3D plan3d(const dn_mesh* m) {
     return g;
 }
 
+// DN_PLAN2D="T,E,R" / DN_PLAN3D="TX,TY,E,R" override the launch geometry (tuning experiments only).
+static Geom2D plan2d_env(const dn_mesh* m, int P) {
+    Geom2D g = plan2d(m, P);
+    const char* e = getenv("DN_PLAN2D");
+    int T, E, R;
+    if (e && sscanf(e, "%d,%d,%d", &T, &E, &R) == 3 && T >= 64 && T <= 256 && (E == 1 || E == 2 || E == 4) && R >= 1) {
+        const int nely = (m->ny - 1) / P;
+        g.T = T; g.E = E; g.R = R > nely ? nely : R;
+        g.chunks = chunks_for((m->nx - 1) / (E * P) + 1, T);
+        g.strips = ceil_div(nely, g.R);
+    }
+    return g;
+}
+
+static Geom3D plan3d_env(const dn_mesh* m) {
+    Geom3D g = plan3d(m);
+    const char* e = getenv("DN_PLAN3D");
+    int TX, TY, E, R;
+    if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY <= 256 && TX * TY >= 64 && (E == 1 || E == 2 || E == 4) && R >= 1) {
+        const int nelz = m->nz - 1;
+        g.TX = TX; g.TY = TY; g.E = E; g.R = R > nelz ? nelz : R;
+        g.chunks = chunks_for((m->nx - 1) / E + 1, TX);
+        g.tiles = chunks_for(m->ny, TY);
+        g.strips = ceil_div(nelz, g.R);
+    }
+    return g;
+}
+
 static long long num_workgroups(const dn_mesh* m) {
     if (m->nsd == 2) {
-        Geom2D g = plan2d(m, m->degree);
+        Geom2D g = plan2d_env(m, m->degree);
         return (long long)g.chunks * g.strips * m->batch;
     }
-    Geom3D g = plan3d(m);
+    Geom3D g = plan3d_env(m);
     return (long long)g.chunks * g.tiles * g.strips * m->batch;
 }
 
@@ -497,8 +569,15 @@ static int validate_mesh(const dn_mesh* m) {
 template <int P, int NGP, int E>
 static void launch2d_vec(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s) {
     dim3 grid(g.chunks, g.strips, batch), block(g.T);
-    if (vec) hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, true>), grid, block, 0, s, pp);
-    else hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, false>), grid, block, 0, s, pp);
+    const bool fgp = pp.fgp != nullptr;
+    constexpr bool CANVEC = (E * P == 2 || E * P == 4);
+    if (vec && CANVEC) {
+        if (fgp) hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, CANVEC, true>), grid, block, 0, s, pp);
+        else hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, CANVEC, false>), grid, block, 0, s, pp);
+    } else {
+        if (fgp) hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, false, true>), grid, block, 0, s, pp);
+        else hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, false, false>), grid, block, 0, s, pp);
+    }
 }
 
 template <int P, int NGP>
@@ -509,7 +588,7 @@ static int launch2d_e(const PoissonParams& pp, const Geom2D& g, int batch, bool 
     if constexpr (P <= 2) {
         if (g.E == 2) { launch2d_vec<P, NGP, 2>(pp, g, batch, vec, s); return 0; }
     }
-    if (g.E == 1) { launch2d_vec<P, NGP, 1>(pp, g, batch, vec && P > 1, s); return 0; }
+    if (g.E == 1) { launch2d_vec<P, NGP, 1>(pp, g, batch, vec, s); return 0; }
     return DN_E_UNSUPPORTED;
 }
 
@@ -529,8 +608,15 @@ static int launch2d(const PoissonParams& pp, const Geom2D& g, int P, int ngp, in
 template <int NGP, int E>
 static void launch3d_vec(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s) {
     dim3 grid(g.chunks * g.tiles, g.strips, batch), block(g.TX, g.TY);
-    if (vec && E > 1) hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, (E > 1)>), grid, block, 0, s, pp, g.chunks);
-    else hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, false>), grid, block, 0, s, pp, g.chunks);
+    const bool fgp = pp.fgp != nullptr;
+    constexpr bool CANVEC = (E == 2 || E == 4);
+    if (vec && CANVEC) {
+        if (fgp) hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, CANVEC, true>), grid, block, 0, s, pp, g.chunks);
+        else hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, CANVEC, false>), grid, block, 0, s, pp, g.chunks);
+    } else {
+        if (fgp) hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, false, true>), grid, block, 0, s, pp, g.chunks);
+        else hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, false, false>), grid, block, 0, s, pp, g.chunks);
+    }
 }
 
 template <int NGP>
@@ -549,7 +635,7 @@ using namespace dn;
 
 extern "C" int64_t dn_poisson_workspace_bytes(const dn_mesh* mesh) {
     if (validate_mesh(mesh) != 0) return DN_E_BADARG;
-    return (int64_t)(2 * sizeof(double)) * num_workgroups(mesh);
+    return DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * num_workgroups(mesh);
 }
 
 extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void* stream) {
@@ -563,7 +649,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     if (m->ngp < (P == 1 ? 2 : 3)) return DN_E_UNSUPPORTED;
     const bool want_red = a->energy || a->sumsq;
     const long long nwg = num_workgroups(m);
-    if (want_red && (!a->workspace || a->workspace_bytes < (int64_t)(2 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
+    if (want_red && (!a->workspace || a->workspace_bytes < DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
+    if ((int64_t)m->nx * m->ny * (m->nsd == 3 ? m->nz : 1) >= (1ll << 30)) return DN_E_UNSUPPORTED;   // 32-bit in-sample offsets
 
     PoissonParams pp;
     for (int i = 0; i < 4; ++i) {
@@ -576,7 +663,12 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         pp.T.w[i] = m->gpw[i];
         pp.T.wx[i] = m->gpw[i] * a->wscale;
     }
-    for (int d = 0; d < 3; ++d) pp.T.hs[d] = 0.5f * m->scale[d];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) pp.T.w2[i][j] = pp.T.w[i] * pp.T.wx[j];
+    for (int d = 0; d < 3; ++d) {
+        pp.T.hs[d] = 0.5f * m->scale[d];
+        pp.T.ahs[d] = a->alpha * pp.T.hs[d];
+    }
     pp.T.alpha = a->alpha; pp.T.beta = a->beta; pp.T.c = a->c;
     pp.u = a->u; pp.nu = a->nu; pp.f = a->f; pp.fgp = a->f_gp;
     pp.nu_batched = a->nu_batched; pp.f_batched = a->f_batched;
@@ -586,27 +678,35 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         pp.bc[k].field_batched = a->bc[k].field_batched;
     }
     pp.out_scale = a->out_scale; pp.out = a->out;
-    pp.part_energy = reinterpret_cast<double*>(a->workspace);
+    pp.counter = reinterpret_cast<unsigned*>(a->workspace);
+    pp.part_energy = a->workspace ? reinterpret_cast<double*>(reinterpret_cast<char*>(a->workspace) + DN_WS_HEADER) : nullptr;
     pp.part_sumsq = pp.part_energy ? pp.part_energy + nwg : nullptr;
+    pp.energy = a->energy; pp.sumsq = a->sumsq;
     pp.nx = m->nx; pp.ny = m->ny; pp.nz = m->nsd == 3 ? m->nz : 1;
     pp.nelx = (m->nx - 1) / P; pp.nely = (m->ny - 1) / P; pp.nelz = m->nsd == 3 ? (m->nz - 1) / P : 1;
-    pp.want_energy = want_red ? 1 : 0; pp.want_sumsq = want_red ? 1 : 0;
+    pp.want_sums = want_red ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
     auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
+    // vector loads/stores of NW nodes are legal when every row segment start is NW-element aligned
+    auto vec_ok = [&](int NW) {
+        bool ok = (NW == 2 || NW == 4) && (m->nx % NW == 0) && aligned(a->u, 4 * NW) && aligned(a->nu, 4 * NW) &&
+                  aligned(a->f, 4 * NW) && aligned(a->out, 4 * NW);
+        for (int k = 0; k < 2; ++k)
+            ok = ok && aligned(a->bc[k].mask, a->bc[k].mask_is_u8 ? NW : 4 * NW) && aligned(a->bc[k].field, 4 * NW);
+        return ok;
+    };
     if (m->nsd == 2) {
-        const Geom2D g = plan2d(m, P);
+        const Geom2D g = plan2d_env(m, P);
         pp.rows_per_strip = g.R;
         const int NW = g.E * P;
-        const bool vec = (NW == 2 || NW == 4) && (m->nx % NW == 0) && aligned(a->u, 4 * NW) && aligned(a->nu, 4 * NW) &&
-                         aligned(a->f, 4 * NW) && aligned(a->out, 4 * NW);
+        const bool vec = vec_ok(NW);
         rc = launch2d(pp, g, P, m->ngp, m->batch, vec, s);
     } else {
-        const Geom3D g = plan3d(m);
+        const Geom3D g = plan3d_env(m);
         pp.rows_per_strip = g.R;
         const int NW = g.E;
-        const bool vec = (NW == 2 || NW == 4) && (m->nx % NW == 0) && aligned(a->u, 4 * NW) && aligned(a->nu, 4 * NW) &&
-                         aligned(a->f, 4 * NW) && aligned(a->out, 4 * NW);
+        const bool vec = vec_ok(NW);
         switch (m->ngp) {
             case 2: rc = launch3d_e<2>(pp, g, m->batch, vec, s); break;
             case 3: rc = launch3d_e<3>(pp, g, m->batch, vec, s); break;
@@ -616,10 +716,5 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     }
     if (rc) return rc;
     DN_LAUNCH_CHECK();
-    if (want_red) {
-        hipLaunchKernelGGL(poisson_finalize_kernel, dim3(1), dim3(256), 0, s, pp.part_energy, pp.part_sumsq, (int)nwg,
-                           a->energy, a->sumsq);
-        DN_LAUNCH_CHECK();
-    }
     return 0;
 }

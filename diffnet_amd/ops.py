@@ -159,10 +159,10 @@ _WS = {}
 
 
 def _workspace(dev, nbytes):
-    key = (dev.index, )
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        ws = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)   # ABI: zero-filled once
         _WS[key] = ws
     return ws
 

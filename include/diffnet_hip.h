@@ -86,7 +86,9 @@ typedef struct dn_poisson_args {
     float *out;            /* (B,1,*N) or NULL                                          */
     double *energy;        /* device scalar: sum (unscaled) or NULL                     */
     double *sumsq;         /* device scalar: sum over nodes of (out/out_scale)^2 or NULL */
-    void *workspace;       /* dn_poisson_workspace_bytes() bytes                        */
+    void *workspace;       /* dn_poisson_workspace_bytes() bytes, needed when energy or sumsq is set. Must be
+                              zero-filled ONCE before its first use; every call leaves it ready for the next
+                              (self-resetting arrival counter). One workspace per concurrently used stream. */
     int64_t workspace_bytes;
 } dn_poisson_args;
 
