@@ -34,6 +34,10 @@ struct ElemTab {
     float hs[3];         // Q1 path: 0.5 * 2/h_d = 1/h_d
     float ahs[3];        // alpha * hs[d]
     float alpha, beta, c;
+    // Q1 marching kernels: moments of the 1-D rule against the lerp weight b = phi_1(xi):
+    //   m[r] = sum_g w[g] * b[g]^r  (r = 0,1,2);  kx[r][ig] = wx[ig] * m[r]
+    float m[3];
+    float kx[3][4];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -319,6 +323,78 @@ __device__ __forceinline__ void elem3d_q1(const ElemTab& T, const float (&u)[2][
         const float cdx1 = cDD[kb], cdx0 = cX0[kb] - cDD[kb];
         g[kb][0][1] = t0 + cdx0; g[kb][0][0] = s0 - g[kb][0][1];
         g[kb][1][1] = t1 + cdx1; g[kb][1][0] = s1 - g[kb][1][1];
+    }
+    e1 = a1;
+    e2 = a2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2-D Q1, marching form.  One element between node rows j (suffix 0) and j+1 (suffix 1), given the
+// x-stage values of both rows at the element's x-Gauss points:
+//   TU[ig] = lerp_x(u)(xi_ig), DX = u[e+1]-u[e];  TN, TF likewise for nu and f.
+// Because nu, f and u are bilinear and the rule is a tensor product, every sum over the y-Gauss points
+// collapses onto the three moments m[0..2] of the 1-D rule (ElemTab), so the work is O(NGP), not O(NGP^2).
+// Outputs: cotangents of the x-stage values of both rows (ct0/ct1 for TU, cdx0/cdx1 for DX) -- the caller
+// adds the carried cotangent of the shared row and applies the x-stage transpose once per row -- and the
+// two energy parts (see the conventions at the top of this file).
+// ---------------------------------------------------------------------------------------------
+template <int NGP, bool FGP>
+__device__ __forceinline__ void q1_layer_2d(const ElemTab& T, const float (&TU0)[NGP], const float (&TU1)[NGP], const float DX0,
+                                            const float DX1, const float (&TN0)[NGP], const float (&TN1)[NGP],
+                                            const float (&TF0)[NGP], const float (&TF1)[NGP], const float* fg,
+                                            float (&ct0)[NGP], float (&ct1)[NGP], float& cdx0, float& cdx1, float& e1,
+                                            float& e2) {
+    float a1 = 0.f, a2 = 0.f;
+    // nu moments along x
+    float S0 = 0.f, S1 = 0.f, dyn[NGP];
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) {
+        dyn[i] = TN1[i] - TN0[i];
+        S0 = fmaf(T.wx[i], TN0[i], S0);
+        S1 = fmaf(T.wx[i], dyn[i], S1);
+    }
+    // x-derivative depends on the y-Gauss index only
+    const float ddx = DX1 - DX0;
+    float c1s = 0.f, css = 0.f;
+#pragma unroll
+    for (int jg = 0; jg < NGP; ++jg) {
+        const float ux = T.hs[0] * fmaf(T.b[jg][1], ddx, DX0);
+        const float Qx = T.w[jg] * fmaf(T.b[jg][1], S1, S0);
+        const float qxu = Qx * ux;
+        a1 = fmaf(qxu, ux, a1);
+        const float cx = T.ahs[0] * qxu;
+        css += cx;
+        c1s = fmaf(T.b[jg][1], cx, c1s);
+    }
+    cdx1 = c1s;
+    cdx0 = css - c1s;
+    const float nb = -T.beta;
+#pragma unroll
+    for (int ig = 0; ig < NGP; ++ig) {
+        const float dyv = TU1[ig] - TU0[ig];
+        const float uy = T.hs[1] * dyv;
+        const float Qy = fmaf(T.kx[1][ig], dyn[ig], T.kx[0][ig] * TN0[ig]);
+        const float qyu = Qy * uy;
+        a1 = fmaf(qyu, uy, a1);
+        const float cyd = T.ahs[1] * qyu;
+        float cs, c1;
+        if constexpr (FGP) {
+            cs = 0.f; c1 = 0.f;
+#pragma unroll
+            for (int jg = 0; jg < NGP; ++jg) {
+                const float wf = T.w2[jg][ig] * fg[jg * NGP + ig];
+                cs += wf;
+                c1 = fmaf(T.b[jg][1], wf, c1);
+            }
+        } else {
+            const float dyf = TF1[ig] - TF0[ig];
+            cs = fmaf(T.kx[1][ig], dyf, T.kx[0][ig] * TF0[ig]);
+            c1 = fmaf(T.kx[2][ig], dyf, T.kx[1][ig] * TF0[ig]);
+        }
+        a2 = fmaf(cs, TU0[ig], a2);
+        a2 = fmaf(c1, dyv, a2);
+        ct1[ig] = fmaf(nb, c1, cyd);
+        ct0[ig] = fmaf(nb, cs, -ct1[ig]);
     }
     e1 = a1;
     e2 = a2;

@@ -301,6 +301,176 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
 }
 
 // =============================================================================================
+// 2-D Q1 kernel, fully sum-factorised marching form.  grid = (chunks_x, strips_y, B), block = T threads.
+// A thread owns E consecutive elements of a row.  Carried across the march, per element: the x-stage values
+// of the lower node row (TU/TN/TF at the x-Gauss points, DX) and the cotangents of that row's x-stage
+// values produced by the element layer below (CT, CDX).  Per layer: x-stage of the new row (1 sub + NGP
+// FMAs per field), the O(NGP) layer arithmetic of q1_layer_2d, then ONE x-stage transpose per completed
+// row, whose result is the finished nodal value (no separate node accumulators).
+// =============================================================================================
+template <int NGP, int E, bool VEC, bool FGP>
+__global__ void __launch_bounds__(256) poisson2d_q1_kernel(const PoissonParams p) {
+    constexpr int NW = E;
+    const int T = blockDim.x;
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+    const int q = chunk * (T - 1) + tid;  // logical thread column (chunks overlap by one thread)
+    const int ex0 = q * E;                // first element == first node of this thread
+    const int x0 = ex0;
+    const bool col_owner = !(chunk > 0 && tid == 0);
+    const int64_t nps = (int64_t)p.nx * p.ny;
+    const unsigned eps = (unsigned)(p.nelx * p.nely);
+    const SampleBases sb = sample_bases(p, b, nps);
+    const float* fgp = FGP ? p.fgp + (p.f_batched ? (int64_t)b * eps * (NGP * NGP) : 0) : nullptr;
+    const int R = p.rows_per_strip;
+    const int ey_own = strip * R;
+    const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;
+    const int ey_end = min(ey_own + R, p.nely);
+    const bool any_bc = sb.mask[0] != nullptr || sb.mask[1] != nullptr;
+
+    __shared__ float xch[2][256];
+    __shared__ double red[8];
+    __shared__ int last_flag;
+
+    float TU0[E][NGP], TN0[E][NGP], TF0[E][NGP], DX0[E];
+    float CT[E][NGP], CDX[E];
+    unsigned fixed0 = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        CDX[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) { CT[e][i] = 0.f; TN0[e][i] = 1.f; TF0[e][i] = 0.f; }
+    }
+
+    // load one node row and apply its x-stage
+    auto row_stage = [&](int yr, float (&TU)[E][NGP], float (&TN)[E][NGP], float (&TF)[E][NGP], float (&DX)[E], unsigned& fixed) {
+        const unsigned rowoff = (unsigned)yr * (unsigned)p.nx;
+        float ru[NW + 1], rn[NW + 1], rf[NW + 1];
+        load_seg<NW, VEC>(sb.u, rowoff, x0, p.nx, ru);
+        if (sb.nu) load_seg<NW, VEC>(sb.nu, rowoff, x0, p.nx, rn);
+        if (!FGP && sb.f) load_seg<NW, VEC>(sb.f, rowoff, x0, p.nx, rf);
+        fixed = any_bc ? load_apply_bc<NW, VEC>(p, sb, rowoff, x0, ru) : 0u;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            DX[e] = ru[e + 1] - ru[e];
+#pragma unroll
+            for (int i = 0; i < NGP; ++i) TU[e][i] = fmaf(p.T.b[i][1], DX[e], ru[e]);
+        }
+        if (sb.nu) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float d = rn[e + 1] - rn[e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) TN[e][i] = fmaf(p.T.b[i][1], d, rn[e]);
+            }
+        }
+        if (!FGP && sb.f) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float d = rf[e + 1] - rf[e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) TF[e][i] = fmaf(p.T.b[i][1], d, rf[e]);
+            }
+        }
+    };
+
+    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
+    int par = 0;
+
+    // Finish node row `yr`: o[n] holds this thread's contributions to nodes x0..x0+E; node x0 also receives
+    // the left neighbour's o[E] through LDS.
+    auto emit_row = [&](const float (&o)[NW + 1], unsigned fixed, int yr, bool owned_row) {
+        xch[par][tid] = o[NW];
+        __syncthreads();
+        const float left = (tid > 0) ? xch[par][tid - 1] : 0.f;
+        par ^= 1;
+        if (owned_row && col_owner) {
+            float v[NW];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                float t = o[n] + (n == 0 ? left : 0.f);
+                t = (fixed & (1u << n)) ? 0.f : t;
+                sq_acc = (x0 + n < p.nx) ? fmaf(t, t, sq_acc) : sq_acc;
+                v[n] = t * p.out_scale;
+            }
+            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)yr * (unsigned)p.nx, x0, p.nx, v);
+        }
+    };
+
+    row_stage(ey_begin, TU0, TN0, TF0, DX0, fixed0);
+    for (int ey = ey_begin; ey < ey_end; ++ey) {
+        float TU1[E][NGP], TN1[E][NGP], TF1[E][NGP], DX1[E];
+        unsigned fixed1;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int i = 0; i < NGP; ++i) { TN1[e][i] = 1.f; TF1[e][i] = 0.f; }
+        row_stage(ey + 1, TU1, TN1, TF1, DX1, fixed1);
+        const bool own_layer = ey >= ey_own;
+        const bool count = own_layer && col_owner;
+        float o[NW + 1];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) o[n] = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (ex0 + e < p.nelx) {
+                float fg[NGP * NGP];
+                if constexpr (FGP) {
+                    const unsigned eo = (unsigned)ey * (unsigned)p.nelx + (unsigned)(ex0 + e);
+#pragma unroll
+                    for (int gi = 0; gi < NGP * NGP; ++gi) fg[gi] = fgp[eo + (unsigned)gi * eps];
+                }
+                float ct0[NGP], ct1[NGP], cdx0, cdx1, e1, e2;
+                q1_layer_2d<NGP, FGP>(p.T, TU0[e], TU1[e], DX0[e], DX1[e], TN0[e], TN1[e], TF0[e], TF1[e], fg, ct0, ct1, cdx0,
+                                      cdx1, e1, e2);
+                e1_acc += count ? e1 : 0.f;
+                e2_acc += count ? e2 : 0.f;
+                // row ey is complete for this element: x-stage transpose of (layer below + this layer)
+                float ssum = 0.f, bsum = cdx0 + CDX[e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) {
+                    const float t = ct0[i] + CT[e][i];
+                    ssum += t;
+                    bsum = fmaf(p.T.b[i][1], t, bsum);
+                    CT[e][i] = ct1[i];
+                }
+                CDX[e] = cdx1;
+                o[e + 1] += bsum;
+                o[e] += ssum - bsum;
+            }
+        }
+        emit_row(o, fixed0, ey, own_layer);
+        // the upper row becomes the lower row of the next layer
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            DX0[e] = DX1[e];
+#pragma unroll
+            for (int i = 0; i < NGP; ++i) { TU0[e][i] = TU1[e][i]; TN0[e][i] = TN1[e][i]; TF0[e][i] = TF1[e][i]; }
+        }
+        fixed0 = fixed1;
+    }
+    // the last strip also owns the top boundary row of the domain: only the layer below contributes
+    if (ey_end == p.nely) {
+        float o[NW + 1];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) o[n] = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (ex0 + e < p.nelx) {
+                float ssum = 0.f, bsum = CDX[e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) { ssum += CT[e][i]; bsum = fmaf(p.T.b[i][1], CT[e][i], bsum); }
+                o[e + 1] += bsum;
+                o[e] += ssum - bsum;
+            }
+        }
+        emit_row(o, fixed0, p.ny - 1, true);
+    }
+
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);
+}
+
+// =============================================================================================
 // 3-D Q1 kernel.  grid = (chunks_x * tiles_y, strips_z, B), block = (TX, TY).
 // =============================================================================================
 template <int NGP, int E, bool VEC, bool FGP>
@@ -571,12 +741,23 @@ static void launch2d_vec(const PoissonParams& pp, const Geom2D& g, int batch, bo
     dim3 grid(g.chunks, g.strips, batch), block(g.T);
     const bool fgp = pp.fgp != nullptr;
     constexpr bool CANVEC = (E * P == 2 || E * P == 4);
-    if (vec && CANVEC) {
-        if (fgp) hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, CANVEC, true>), grid, block, 0, s, pp);
-        else hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, CANVEC, false>), grid, block, 0, s, pp);
+    const bool v = vec && CANVEC;
+    if constexpr (P == 1) {
+        if (v) {
+            if (fgp) hipLaunchKernelGGL((poisson2d_q1_kernel<NGP, E, CANVEC, true>), grid, block, 0, s, pp);
+            else hipLaunchKernelGGL((poisson2d_q1_kernel<NGP, E, CANVEC, false>), grid, block, 0, s, pp);
+        } else {
+            if (fgp) hipLaunchKernelGGL((poisson2d_q1_kernel<NGP, E, false, true>), grid, block, 0, s, pp);
+            else hipLaunchKernelGGL((poisson2d_q1_kernel<NGP, E, false, false>), grid, block, 0, s, pp);
+        }
     } else {
-        if (fgp) hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, false, true>), grid, block, 0, s, pp);
-        else hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, false, false>), grid, block, 0, s, pp);
+        if (v) {
+            if (fgp) hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, CANVEC, true>), grid, block, 0, s, pp);
+            else hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, CANVEC, false>), grid, block, 0, s, pp);
+        } else {
+            if (fgp) hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, false, true>), grid, block, 0, s, pp);
+            else hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, false, false>), grid, block, 0, s, pp);
+        }
     }
 }
 
@@ -668,6 +849,17 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     for (int d = 0; d < 3; ++d) {
         pp.T.hs[d] = 0.5f * m->scale[d];
         pp.T.ahs[d] = a->alpha * pp.T.hs[d];
+    }
+    {   // moments of the 1-D rule against b = phi_1 (Q1 marching kernels), accumulated in double
+        double mm[3] = {0.0, 0.0, 0.0};
+        for (int g = 0; g < m->ngp; ++g) {
+            const double bb = m->basis[g][1];
+            mm[0] += m->gpw[g]; mm[1] += m->gpw[g] * bb; mm[2] += m->gpw[g] * bb * bb;
+        }
+        for (int r = 0; r < 3; ++r) {
+            pp.T.m[r] = (float)mm[r];
+            for (int g = 0; g < 4; ++g) pp.T.kx[r][g] = (float)(mm[r] * (double)m->gpw[g] * (double)a->wscale);
+        }
     }
     pp.T.alpha = a->alpha; pp.T.beta = a->beta; pp.T.c = a->c;
     pp.u = a->u; pp.nu = a->nu; pp.f = a->f; pp.fgp = a->f_gp;
