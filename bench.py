@@ -44,11 +44,30 @@ def make_inputs(shape, dev, seed):
     return [t.to(dev) if dev is not None else t for t in (u, nu, f, bc)]
 
 
+def host_cores():
+    """Cores this process may actually use: the cgroup CPU quota when there is one, else the affinity mask
+    (os.cpu_count() reports the whole host, and oversubscribing torch's intra-op pool makes the CPU leg crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(kw, c, budget_s=20.0):
     """Time the oracle (torch-CPU port of the reference op sequence: per-GP conv + cat + elementwise + autograd
     backward) on a bounded sample: batch 2 of the same mesh, as many iterations as fit the budget."""
     from oracle.fem_oracle import Oracle
-    ncores = os.cpu_count() or 1
+    ncores = min(host_cores(), int(os.environ.get("DN_CPU_THREADS", "32")))
     torch.set_num_threads(ncores)
     o = Oracle(**kw)
     Bs = 2
@@ -73,7 +92,8 @@ def cpu_baseline(kw, c, budget_s=20.0):
         if el > budget_s or it >= 50:
             break
     return {"value": units * it / el, "unit": "elements*gauss_pts/s", "cores": ncores, "kind": "port",
-            "sample": f"oracle/fem_oracle.py energy fwd+bwd, batch {Bs} of the same mesh, {it} iters in {el:.1f}s, torch {torch.__version__} CPU"}
+            "sample": f"oracle/fem_oracle.py energy fwd+bwd, batch {Bs} of the same mesh, {it} iters in {el:.1f}s, "
+                      f"torch {torch.__version__} CPU, {ncores} threads (os.cpu_count()={os.cpu_count()})"}
 
 
 def main():
@@ -154,6 +174,15 @@ def main():
     alg_bytes = ALG_BYTES_PER_NODE * B * m.geom.nnode_total
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
 
+    traffic, traffic_src = None, None
+    try:   # HBM bytes per launch from the committed rocprofv3 PMC summary of this exact workload (profiles/)
+        prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        key = f"{args.nsd}d_n{args.size}_g{args.ngp}_b{B}"
+        if key in prof:
+            traffic, traffic_src = prof[key]["hbm_bytes_per_launch"], prof[key]["source"]
+    except Exception:
+        pass
+
     if rank == 0:
         value = units_per_step * world * args.steps / dt
         out = {
@@ -165,8 +194,8 @@ def main():
                                    "fused single pass (BASELINE.json configs[1] mesh)",
                        "batch_per_gpu": B, "nodes": list(m.geom.node_shape), "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "dn_poisson_apply (poisson kernel + finalize)", "kernel_avg_ms": kern_avg_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "poisson fused kernel (one launch per dn_poisson_apply)", "kernel_avg_ms": kern_avg_ms,
                          "kernel_min_ms": kern_ms[0], "algorithmic_bytes": alg_bytes},
         }
         if not args.no_cpu and world == 1:

@@ -405,3 +405,33 @@ def test_edge_cases_and_errors():
     lb, gb = m2.energy_loss_and_grad(uu.transpose(2, 3).contiguous().transpose(2, 3), nu1.expand(3, -1, -1, -1).contiguous(), None,
                                      dirichlet=[(bc1.expand(3, -1, -1, -1).contiguous(), 0.0)])
     assert torch.equal(la, lb) and torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("nsd,sizes,lengths,world", [(3, (33, 20, 26), (1.0, 0.6, 0.8), 3), (2, (64, 50, 1), (1.0, 1.0, 1.0), 2)])
+def test_slab_decomposition_on_gpu_matches_global(nsd, sizes, lengths, world):
+    """Every rank's slab computed with the HIP kernels on this one GPU, exchange steps emulated in-process:
+    the assembled result must equal the global HIP evaluation (diffnet_amd/slab.py; the N>1 transport itself is
+    covered by tests/test_slab_gloo.py)."""
+    from diffnet_amd import ops
+    from diffnet_amd.slab import SlabDecomposition
+    from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM
+    cls = DiffNet3DFEM if nsd == 3 else DiffNet2DFEM
+    B = 2
+    shape = (B, 1, *sizes[:nsd][::-1])
+    u, nu, f = seeded(shape, 31).to(dev()), seeded(shape, 32, 0.5).to(dev()), seeded(shape, 33).to(dev())
+    bc = boundary_mask(shape).to(dev())
+    pad = (1,) * (3 - nsd)
+    gm = cls(None, nsd=nsd, domain_sizes=sizes[:nsd] + pad, domain_lengths=lengths[:nsd] + pad, domain_size=sizes[0],
+             domain_length=lengths[0]).to(dev())
+    lref, gref = gm.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=0.5)
+    esum = 0.0
+    gfull = torch.zeros_like(u)
+    for r in range(world):
+        dec = SlabDecomposition(nsd, sizes, lengths, r, world)
+        fem = cls(None, **dec.local_kwargs()).to(dev())
+        g, sums = ops.poisson_apply(fem.geom, dec.take(u), dec.take(nu), dec.take(f), None, [(dec.take(bc), 0.0)], alpha=1.0, beta=1.0,
+                                    c=0.5, wscale=1.0, out_scale=1.0 / (B * dec.nel_global))
+        esum += float(sums[0])
+        gfull[:, :, dec.n0:dec.n1 + 1] += g               # interface layers: sum of both neighbours' parts
+    np.testing.assert_allclose(esum / (B * gm.geom.nelem_total), float(lref), rtol=1e-6)
+    close(gfull, gref.cpu().numpy(), rtol=1e-5, arel=1e-6)
