@@ -1,0 +1,3 @@
+// 2-D Q1 fused Poisson kernels for ngp_1d = 4 (see poisson2d_q1.inl).
+#define DN_NGP 4
+#include "poisson2d_q1.inl"

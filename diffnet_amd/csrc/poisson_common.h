@@ -1,0 +1,220 @@
+// Shared device-side pieces of the fused Poisson kernels: kernel parameter block, per-sample base pointers,
+// Dirichlet handling and the in-kernel deterministic final reduction.
+#pragma once
+#include "dn_common.h"
+#include "poisson_elem.h"
+
+namespace dn {
+
+struct DirichletDev {
+    const void* mask;
+    const float* field;
+    float value;
+    int mask_is_u8, mask_batched, field_batched;
+};
+
+struct PoissonParams {
+    ElemTab T;
+    const float* u;
+    const float* nu;
+    const float* f;
+    const float* fgp;
+    int nu_batched, f_batched;
+    DirichletDev bc[2];
+    float out_scale;
+    float* out;
+    double* part_energy;   // per-workgroup partial sums (workspace)
+    double* part_sumsq;
+    unsigned* counter;     // arrival counter of the in-kernel final reduction (self-resetting)
+    double* energy;        // final scalars (may be null)
+    double* sumsq;
+    int nx, ny, nz;        // nodes
+    int nelx, nely, nelz;  // elements
+    int rows_per_strip;    // element layers per strip along the marched axis
+    int want_sums;
+};
+
+// Per-sample base pointers (wave-uniform): all in-kernel indexing is a 32-bit offset from these.
+struct SampleBases {
+    const float* u;
+    const float* nu;
+    const float* f;
+    float* out;
+    const void* mask[2];
+    const float* field[2];
+};
+
+__device__ __forceinline__ SampleBases sample_bases(const PoissonParams& p, int b, int64_t nps) {
+    SampleBases s;
+    s.u = p.u + (int64_t)b * nps;
+    s.nu = p.nu ? p.nu + (p.nu_batched ? (int64_t)b * nps : 0) : nullptr;
+    s.f = p.f ? p.f + (p.f_batched ? (int64_t)b * nps : 0) : nullptr;
+    s.out = p.out ? p.out + (int64_t)b * nps : nullptr;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const DirichletDev& d = p.bc[k];
+        const int64_t mo = d.mask_batched ? (int64_t)b * nps : 0;
+        s.mask[k] = d.mask ? (d.mask_is_u8 ? (const void*)(reinterpret_cast<const uint8_t*>(d.mask) + mo)
+                                           : (const void*)(reinterpret_cast<const float*>(d.mask) + mo))
+                           : nullptr;
+        s.field[k] = d.field ? d.field + (d.field_batched ? (int64_t)b * nps : 0) : nullptr;
+    }
+    return s;
+}
+
+// Dirichlet conditions for one row segment (nodes x0..x0+NW): all mask / value loads are issued first, then
+// u <- where(mask > 0.5, value, u) is applied with selects.  Returns the bit set of fixed nodes.
+template <int NW, bool VEC>
+__device__ __forceinline__ unsigned load_apply_bc(const PoissonParams& p, const SampleBases& sb, unsigned rowoff, int x0,
+                                                  float (&u)[NW + 1]) {
+    uint8_t m8[2][NW + 1];
+    float mf[2][NW + 1], fv[2][NW + 1];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (sb.mask[k] != nullptr) {
+            if (p.bc[k].mask_is_u8) load_seg<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, m8[k]);
+            else load_seg<NW, VEC>(reinterpret_cast<const float*>(sb.mask[k]), rowoff, x0, p.nx, mf[k]);
+            if (sb.field[k]) load_seg<NW, VEC>(sb.field[k], rowoff, x0, p.nx, fv[k]);
+        }
+    }
+    unsigned bits = 0u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (sb.mask[k] != nullptr) {
+            unsigned kb = 0u;
+            if (p.bc[k].mask_is_u8) {
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) kb |= (m8[k][n] != 0) ? (1u << n) : 0u;
+            } else {
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) kb |= (mf[k][n] > 0.5f) ? (1u << n) : 0u;
+            }
+            if (sb.field[k]) {
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) u[n] = (kb & (1u << n)) ? fv[k][n] : u[n];
+            } else {
+                const float val = p.bc[k].value;
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) u[n] = (kb & (1u << n)) ? val : u[n];
+            }
+            bits |= kb;
+        }
+    }
+    return bits;
+}
+
+// Block-level reduction of the two scalars + arrival of this workgroup at the in-kernel final reduction.
+// Two-level arrival (DN_NSHARD shard counters on separate 64-B lines, then one top counter) keeps the
+// same-address atomic fan-in at ~nblocks/64 + 64 instead of nblocks (one address retires only ~88 atomics/us:
+// MI355X_MICROARCH.md "fanin").  The workgroup that arrives last sums all per-workgroup partials in index
+// order (=> deterministic whatever the arrival order); counters are reset by their last arriver, so the
+// workspace is ready for the next launch.  Protocol (cdna_hip_programming.md, Guideline 16): partials are
+// stored write-through (sc1) and drained before the arrival atomic; the last arriver does an agent-scope
+// acquire and reads the partials with sc1 loads.
+#define DN_NSHARD 64
+__device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, float e2, float sq, int tid, int nthreads,
+                                            double* red, int* flag) {
+    const int nblocks = gridDim.x * gridDim.y * gridDim.z;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const double es = block_sum((double)p.T.c * (double)e1 - (double)e2, red, tid, nthreads);
+    const double ss = block_sum((double)sq, red, tid, nthreads);
+    if (tid == 0) {
+        // write-through (sc1) 8-byte stores + drain instead of an agent-scope release fence: a release is a
+        // `buffer_wbl2` of the whole XCD L2, i.e. every workgroup would wait for everybody's freshly written
+        // output lines to be flushed (measured: +5..30 us per workgroup at 8k workgroups).
+        __hip_atomic_store(&p.part_energy[blk], es, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.part_sumsq[blk], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int nshard = nblocks < DN_NSHARD ? nblocks : DN_NSHARD;
+        const int shard = blk % nshard;
+        const unsigned in_shard = (unsigned)((nblocks - shard + nshard - 1) / nshard);
+        unsigned* sc = p.counter + 16 * (1 + shard);              // shard counters: one per 64-B line
+        int last = 0;
+        const unsigned prev = __hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == in_shard - 1) {
+            __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned prev2 = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (prev2 == (unsigned)(nshard - 1)) ? 1 : 0;
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag) {
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        double e = 0.0, s = 0.0;
+        for (int i = tid; i < nblocks; i += nthreads) {
+            e += __hip_atomic_load(&p.part_energy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s += __hip_atomic_load(&p.part_sumsq[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        e = block_sum(e, red, tid, nthreads);
+        s = block_sum(s, red, tid, nthreads);
+        if (tid == 0) {
+            if (p.energy) *p.energy = e;
+            if (p.sumsq) *p.sumsq = s;
+            __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// Raw (not yet interpreted) Dirichlet data of one row segment: issued early, applied later, so that the
+// loads of the next row are in flight while the current layer is computed.
+template <int NW>
+struct BcRaw {
+    uint32_t m[2][NW + 1];   // mask values: zero-extended byte (u8 masks) or float bit pattern
+    float fv[2][NW + 1];     // Dirichlet value fields
+};
+
+template <int NW, bool VEC>
+__device__ __forceinline__ void bc_issue(const PoissonParams& p, const SampleBases& sb, unsigned rowoff, int x0, BcRaw<NW>& r) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (sb.mask[k] != nullptr) {
+            if (p.bc[k].mask_is_u8) {
+                uint8_t t[NW + 1];
+                load_seg<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, t);
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) r.m[k][n] = t[n];
+            } else {
+                load_seg<NW, VEC>(reinterpret_cast<const uint32_t*>(sb.mask[k]), rowoff, x0, p.nx, r.m[k]);
+            }
+            if (sb.field[k]) load_seg<NW, VEC>(sb.field[k], rowoff, x0, p.nx, r.fv[k]);
+        }
+    }
+}
+
+// u <- where(mask > 0.5, value, u) for both conditions in order; keep[n] = 0 on Dirichlet nodes, 1 elsewhere.
+template <int NW>
+__device__ __forceinline__ void bc_apply(const PoissonParams& p, const SampleBases& sb, const BcRaw<NW>& r, float (&u)[NW + 1],
+                                         float (&keep)[NW]) {
+#pragma unroll
+    for (int n = 0; n < NW; ++n) keep[n] = 1.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (sb.mask[k] != nullptr) {
+            const bool u8 = p.bc[k].mask_is_u8 != 0;
+            const bool hasf = sb.field[k] != nullptr;
+            const float val = p.bc[k].value;
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) {
+                const bool set = u8 ? (r.m[k][n] != 0u) : (__uint_as_float(r.m[k][n]) > 0.5f);
+                u[n] = set ? (hasf ? r.fv[k][n] : val) : u[n];
+                if (n < NW) keep[n] = set ? 0.f : keep[n];
+            }
+        }
+    }
+}
+
+
+struct Geom2D { int T, E, chunks, strips, R; };
+struct Geom3D { int TX, TY, E, chunks, tiles, strips, R; };
+
+// 2-D Q1 marching kernels are compiled one translation unit per NGP (poisson2d_q1_g{2,3,4}.hip)
+int launch_poisson2d_q1_g2(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
+int launch_poisson2d_q1_g3(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
+int launch_poisson2d_q1_g4(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
+
+}  // namespace dn

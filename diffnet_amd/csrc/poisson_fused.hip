@@ -15,167 +15,13 @@
 // tile seams are closed by recomputing one element layer (no atomics => bitwise reproducible).
 // HBM traffic is the algorithmic minimum: each nodal field is read once (+ halo re-reads that hit
 // L2), the output is written once.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
-#include "dn_common.h"
-#include "poisson_elem.h"
+#include "poisson_common.h"
 
 namespace dn {
-
-struct DirichletDev {
-    const void* mask;
-    const float* field;
-    float value;
-    int mask_is_u8, mask_batched, field_batched;
-};
-
-struct PoissonParams {
-    ElemTab T;
-    const float* u;
-    const float* nu;
-    const float* f;
-    const float* fgp;
-    int nu_batched, f_batched;
-    DirichletDev bc[2];
-    float out_scale;
-    float* out;
-    double* part_energy;   // per-workgroup partial sums (workspace)
-    double* part_sumsq;
-    unsigned* counter;     // arrival counter of the in-kernel final reduction (self-resetting)
-    double* energy;        // final scalars (may be null)
-    double* sumsq;
-    int nx, ny, nz;        // nodes
-    int nelx, nely, nelz;  // elements
-    int rows_per_strip;    // element layers per strip along the marched axis
-    int want_sums;
-};
-
-// Per-sample base pointers (wave-uniform): all in-kernel indexing is a 32-bit offset from these.
-struct SampleBases {
-    const float* u;
-    const float* nu;
-    const float* f;
-    float* out;
-    const void* mask[2];
-    const float* field[2];
-};
-
-__device__ __forceinline__ SampleBases sample_bases(const PoissonParams& p, int b, int64_t nps) {
-    SampleBases s;
-    s.u = p.u + (int64_t)b * nps;
-    s.nu = p.nu ? p.nu + (p.nu_batched ? (int64_t)b * nps : 0) : nullptr;
-    s.f = p.f ? p.f + (p.f_batched ? (int64_t)b * nps : 0) : nullptr;
-    s.out = p.out ? p.out + (int64_t)b * nps : nullptr;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const DirichletDev& d = p.bc[k];
-        const int64_t mo = d.mask_batched ? (int64_t)b * nps : 0;
-        s.mask[k] = d.mask ? (d.mask_is_u8 ? (const void*)(reinterpret_cast<const uint8_t*>(d.mask) + mo)
-                                           : (const void*)(reinterpret_cast<const float*>(d.mask) + mo))
-                           : nullptr;
-        s.field[k] = d.field ? d.field + (d.field_batched ? (int64_t)b * nps : 0) : nullptr;
-    }
-    return s;
-}
-
-// Dirichlet conditions for one row segment (nodes x0..x0+NW): all mask / value loads are issued first, then
-// u <- where(mask > 0.5, value, u) is applied with selects.  Returns the bit set of fixed nodes.
-template <int NW, bool VEC>
-__device__ __forceinline__ unsigned load_apply_bc(const PoissonParams& p, const SampleBases& sb, unsigned rowoff, int x0,
-                                                  float (&u)[NW + 1]) {
-    uint8_t m8[2][NW + 1];
-    float mf[2][NW + 1], fv[2][NW + 1];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (sb.mask[k] != nullptr) {
-            if (p.bc[k].mask_is_u8) load_seg<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, m8[k]);
-            else load_seg<NW, VEC>(reinterpret_cast<const float*>(sb.mask[k]), rowoff, x0, p.nx, mf[k]);
-            if (sb.field[k]) load_seg<NW, VEC>(sb.field[k], rowoff, x0, p.nx, fv[k]);
-        }
-    }
-    unsigned bits = 0u;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (sb.mask[k] != nullptr) {
-            unsigned kb = 0u;
-            if (p.bc[k].mask_is_u8) {
-#pragma unroll
-                for (int n = 0; n <= NW; ++n) kb |= (m8[k][n] != 0) ? (1u << n) : 0u;
-            } else {
-#pragma unroll
-                for (int n = 0; n <= NW; ++n) kb |= (mf[k][n] > 0.5f) ? (1u << n) : 0u;
-            }
-            if (sb.field[k]) {
-#pragma unroll
-                for (int n = 0; n <= NW; ++n) u[n] = (kb & (1u << n)) ? fv[k][n] : u[n];
-            } else {
-                const float val = p.bc[k].value;
-#pragma unroll
-                for (int n = 0; n <= NW; ++n) u[n] = (kb & (1u << n)) ? val : u[n];
-            }
-            bits |= kb;
-        }
-    }
-    return bits;
-}
-
-// Block-level reduction of the two scalars + arrival of this workgroup at the in-kernel final reduction.
-// Two-level arrival (DN_NSHARD shard counters on separate 64-B lines, then one top counter) keeps the
-// same-address atomic fan-in at ~nblocks/64 + 64 instead of nblocks (one address retires only ~88 atomics/us:
-// MI355X_MICROARCH.md "fanin").  The workgroup that arrives last sums all per-workgroup partials in index
-// order (=> deterministic whatever the arrival order); counters are reset by their last arriver, so the
-// workspace is ready for the next launch.  Protocol (cdna_hip_programming.md, Guideline 16): partials are
-// stored write-through (sc1) and drained before the arrival atomic; the last arriver does an agent-scope
-// acquire and reads the partials with sc1 loads.
-#define DN_NSHARD 64
-__device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, float e2, float sq, int tid, int nthreads,
-                                            double* red, int* flag) {
-    const int nblocks = gridDim.x * gridDim.y * gridDim.z;
-    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const double es = block_sum((double)p.T.c * (double)e1 - (double)e2, red, tid, nthreads);
-    const double ss = block_sum((double)sq, red, tid, nthreads);
-    if (tid == 0) {
-        // write-through (sc1) 8-byte stores + drain instead of an agent-scope release fence: a release is a
-        // `buffer_wbl2` of the whole XCD L2, i.e. every workgroup would wait for everybody's freshly written
-        // output lines to be flushed (measured: +5..30 us per workgroup at 8k workgroups).
-        __hip_atomic_store(&p.part_energy[blk], es, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&p.part_sumsq[blk], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int nshard = nblocks < DN_NSHARD ? nblocks : DN_NSHARD;
-        const int shard = blk % nshard;
-        const unsigned in_shard = (unsigned)((nblocks - shard + nshard - 1) / nshard);
-        unsigned* sc = p.counter + 16 * (1 + shard);              // shard counters: one per 64-B line
-        int last = 0;
-        const unsigned prev = __hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == in_shard - 1) {
-            __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned prev2 = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (prev2 == (unsigned)(nshard - 1)) ? 1 : 0;
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    if (*flag) {
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        double e = 0.0, s = 0.0;
-        for (int i = tid; i < nblocks; i += nthreads) {
-            e += __hip_atomic_load(&p.part_energy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s += __hip_atomic_load(&p.part_sumsq[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        e = block_sum(e, red, tid, nthreads);
-        s = block_sum(s, red, tid, nthreads);
-        if (tid == 0) {
-            if (p.energy) *p.energy = e;
-            if (p.sumsq) *p.sumsq = s;
-            __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
 
 // =============================================================================================
 // 2-D kernel.  grid = (chunks_x, strips_y, B), block = T threads.
@@ -296,176 +142,6 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
     }
     // the last strip also owns the top boundary row of the domain
     if (ey_end == p.nely) emit_row(0, p.ny - 1, true);
-
-    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);
-}
-
-// =============================================================================================
-// 2-D Q1 kernel, fully sum-factorised marching form.  grid = (chunks_x, strips_y, B), block = T threads.
-// A thread owns E consecutive elements of a row.  Carried across the march, per element: the x-stage values
-// of the lower node row (TU/TN/TF at the x-Gauss points, DX) and the cotangents of that row's x-stage
-// values produced by the element layer below (CT, CDX).  Per layer: x-stage of the new row (1 sub + NGP
-// FMAs per field), the O(NGP) layer arithmetic of q1_layer_2d, then ONE x-stage transpose per completed
-// row, whose result is the finished nodal value (no separate node accumulators).
-// =============================================================================================
-template <int NGP, int E, bool VEC, bool FGP>
-__global__ void __launch_bounds__(256) poisson2d_q1_kernel(const PoissonParams p) {
-    constexpr int NW = E;
-    const int T = blockDim.x;
-    const int tid = threadIdx.x;
-    const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
-    const int q = chunk * (T - 1) + tid;  // logical thread column (chunks overlap by one thread)
-    const int ex0 = q * E;                // first element == first node of this thread
-    const int x0 = ex0;
-    const bool col_owner = !(chunk > 0 && tid == 0);
-    const int64_t nps = (int64_t)p.nx * p.ny;
-    const unsigned eps = (unsigned)(p.nelx * p.nely);
-    const SampleBases sb = sample_bases(p, b, nps);
-    const float* fgp = FGP ? p.fgp + (p.f_batched ? (int64_t)b * eps * (NGP * NGP) : 0) : nullptr;
-    const int R = p.rows_per_strip;
-    const int ey_own = strip * R;
-    const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;
-    const int ey_end = min(ey_own + R, p.nely);
-    const bool any_bc = sb.mask[0] != nullptr || sb.mask[1] != nullptr;
-
-    __shared__ float xch[2][256];
-    __shared__ double red[8];
-    __shared__ int last_flag;
-
-    float TU0[E][NGP], TN0[E][NGP], TF0[E][NGP], DX0[E];
-    float CT[E][NGP], CDX[E];
-    unsigned fixed0 = 0u;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        CDX[e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NGP; ++i) { CT[e][i] = 0.f; TN0[e][i] = 1.f; TF0[e][i] = 0.f; }
-    }
-
-    // load one node row and apply its x-stage
-    auto row_stage = [&](int yr, float (&TU)[E][NGP], float (&TN)[E][NGP], float (&TF)[E][NGP], float (&DX)[E], unsigned& fixed) {
-        const unsigned rowoff = (unsigned)yr * (unsigned)p.nx;
-        float ru[NW + 1], rn[NW + 1], rf[NW + 1];
-        load_seg<NW, VEC>(sb.u, rowoff, x0, p.nx, ru);
-        if (sb.nu) load_seg<NW, VEC>(sb.nu, rowoff, x0, p.nx, rn);
-        if (!FGP && sb.f) load_seg<NW, VEC>(sb.f, rowoff, x0, p.nx, rf);
-        fixed = any_bc ? load_apply_bc<NW, VEC>(p, sb, rowoff, x0, ru) : 0u;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            DX[e] = ru[e + 1] - ru[e];
-#pragma unroll
-            for (int i = 0; i < NGP; ++i) TU[e][i] = fmaf(p.T.b[i][1], DX[e], ru[e]);
-        }
-        if (sb.nu) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const float d = rn[e + 1] - rn[e];
-#pragma unroll
-                for (int i = 0; i < NGP; ++i) TN[e][i] = fmaf(p.T.b[i][1], d, rn[e]);
-            }
-        }
-        if (!FGP && sb.f) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const float d = rf[e + 1] - rf[e];
-#pragma unroll
-                for (int i = 0; i < NGP; ++i) TF[e][i] = fmaf(p.T.b[i][1], d, rf[e]);
-            }
-        }
-    };
-
-    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
-    int par = 0;
-
-    // Finish node row `yr`: o[n] holds this thread's contributions to nodes x0..x0+E; node x0 also receives
-    // the left neighbour's o[E] through LDS.
-    auto emit_row = [&](const float (&o)[NW + 1], unsigned fixed, int yr, bool owned_row) {
-        xch[par][tid] = o[NW];
-        __syncthreads();
-        const float left = (tid > 0) ? xch[par][tid - 1] : 0.f;
-        par ^= 1;
-        if (owned_row && col_owner) {
-            float v[NW];
-#pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                float t = o[n] + (n == 0 ? left : 0.f);
-                t = (fixed & (1u << n)) ? 0.f : t;
-                sq_acc = (x0 + n < p.nx) ? fmaf(t, t, sq_acc) : sq_acc;
-                v[n] = t * p.out_scale;
-            }
-            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)yr * (unsigned)p.nx, x0, p.nx, v);
-        }
-    };
-
-    row_stage(ey_begin, TU0, TN0, TF0, DX0, fixed0);
-    for (int ey = ey_begin; ey < ey_end; ++ey) {
-        float TU1[E][NGP], TN1[E][NGP], TF1[E][NGP], DX1[E];
-        unsigned fixed1;
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-#pragma unroll
-            for (int i = 0; i < NGP; ++i) { TN1[e][i] = 1.f; TF1[e][i] = 0.f; }
-        row_stage(ey + 1, TU1, TN1, TF1, DX1, fixed1);
-        const bool own_layer = ey >= ey_own;
-        const bool count = own_layer && col_owner;
-        float o[NW + 1];
-#pragma unroll
-        for (int n = 0; n <= NW; ++n) o[n] = 0.f;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (ex0 + e < p.nelx) {
-                float fg[NGP * NGP];
-                if constexpr (FGP) {
-                    const unsigned eo = (unsigned)ey * (unsigned)p.nelx + (unsigned)(ex0 + e);
-#pragma unroll
-                    for (int gi = 0; gi < NGP * NGP; ++gi) fg[gi] = fgp[eo + (unsigned)gi * eps];
-                }
-                float ct0[NGP], ct1[NGP], cdx0, cdx1, e1, e2;
-                q1_layer_2d<NGP, FGP>(p.T, TU0[e], TU1[e], DX0[e], DX1[e], TN0[e], TN1[e], TF0[e], TF1[e], fg, ct0, ct1, cdx0,
-                                      cdx1, e1, e2);
-                e1_acc += count ? e1 : 0.f;
-                e2_acc += count ? e2 : 0.f;
-                // row ey is complete for this element: x-stage transpose of (layer below + this layer)
-                float ssum = 0.f, bsum = cdx0 + CDX[e];
-#pragma unroll
-                for (int i = 0; i < NGP; ++i) {
-                    const float t = ct0[i] + CT[e][i];
-                    ssum += t;
-                    bsum = fmaf(p.T.b[i][1], t, bsum);
-                    CT[e][i] = ct1[i];
-                }
-                CDX[e] = cdx1;
-                o[e + 1] += bsum;
-                o[e] += ssum - bsum;
-            }
-        }
-        emit_row(o, fixed0, ey, own_layer);
-        // the upper row becomes the lower row of the next layer
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            DX0[e] = DX1[e];
-#pragma unroll
-            for (int i = 0; i < NGP; ++i) { TU0[e][i] = TU1[e][i]; TN0[e][i] = TN1[e][i]; TF0[e][i] = TF1[e][i]; }
-        }
-        fixed0 = fixed1;
-    }
-    // the last strip also owns the top boundary row of the domain: only the layer below contributes
-    if (ey_end == p.nely) {
-        float o[NW + 1];
-#pragma unroll
-        for (int n = 0; n <= NW; ++n) o[n] = 0.f;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (ex0 + e < p.nelx) {
-                float ssum = 0.f, bsum = CDX[e];
-#pragma unroll
-                for (int i = 0; i < NGP; ++i) { ssum += CT[e][i]; bsum = fmaf(p.T.b[i][1], CT[e][i], bsum); }
-                o[e + 1] += bsum;
-                o[e] += ssum - bsum;
-            }
-        }
-        emit_row(o, fixed0, p.ny - 1, true);
-    }
 
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);
 }
@@ -622,8 +298,6 @@ __global__ void __launch_bounds__(256) poisson3d_q1_kernel(const PoissonParams p
 // ---------------------------------------------------------------------------------------------
 // host side: launch geometry
 // ---------------------------------------------------------------------------------------------
-struct Geom2D { int T, E, chunks, strips, R; };
-struct Geom3D { int TX, TY, E, chunks, tiles, strips, R; };
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -637,14 +311,16 @@ static int chunks_for(int logical_threads, int T) {
 // Pick elements-per-thread, block width and strip height so that (a) the x extent wastes few lanes,
 // (b) the launch has >= ~4 workgroups per CU when the problem allows it, (c) the marched strips are
 // long enough that the one recomputed layer per strip stays a small fraction.
-static Geom2D plan2d(const dn_mesh* m, int P) {
+static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
     Geom2D g;
     const int nx = m->nx, nely = (m->ny - 1) / P;
     const int maxE = (P == 1) ? 4 : (P == 2 ? 2 : 1);
+    const int minE = (P == 1) ? 2 : 1;                  // the Q1 marching kernel is built for E = 2 and 4
     double best = -1.0;
-    g.T = 64; g.E = 1;
-    for (int E = 1; E <= maxE; E *= 2) {
+    g.T = 64; g.E = minE; g.chunks = 1;
+    for (int E = minE; E <= maxE; E *= 2) {
         const int NW = E * P;
+        if (P == 1 && E == 4 && (nx % 4 != 0 || !allow_e4)) continue;   // E = 4 exists only with aligned vector rows
         const int Q = (nx - 1) / NW + 1;                 // logical thread columns
         for (int T = 64; T <= 256; T *= 2) {
             const int chunks = chunks_for(Q, T);
@@ -654,10 +330,10 @@ static Geom2D plan2d(const dn_mesh* m, int P) {
             if (score > best) { best = score; g.T = T; g.E = E; g.chunks = chunks; }
         }
     }
-    // strips: aim for >= 1024 workgroups in total, R in [4, 64]
+    // strips: aim for >= 8 workgroups per CU in total, R in [4, 32]
     const long long wg_per_strip = (long long)g.chunks * m->batch;
     int R = 32;
-    while (R > 4 && wg_per_strip * ceil_div(nely, R) < 1024) R /= 2;
+    while (R > 4 && wg_per_strip * ceil_div(nely, R) < 2048) R /= 2;
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = ceil_div(nely, g.R);
@@ -690,11 +366,12 @@ static Geom3D plan3d(const dn_mesh* m) {
 }
 
 // DN_PLAN2D="T,E,R" / DN_PLAN3D="TX,TY,E,R" override the launch geometry (tuning experiments only).
-static Geom2D plan2d_env(const dn_mesh* m, int P) {
-    Geom2D g = plan2d(m, P);
+static Geom2D plan2d_env(const dn_mesh* m, int P, bool allow_e4 = true) {
+    Geom2D g = plan2d(m, P, allow_e4);
     const char* e = getenv("DN_PLAN2D");
     int T, E, R;
-    if (e && sscanf(e, "%d,%d,%d", &T, &E, &R) == 3 && T >= 64 && T <= 256 && (E == 1 || E == 2 || E == 4) && R >= 1) {
+    if (e && sscanf(e, "%d,%d,%d", &T, &E, &R) == 3 && T >= 64 && T <= 256 && (E == 1 || E == 2 || E == 4) && R >= 1 &&
+        !(P == 1 && (E == 1 || (E == 4 && (m->nx % 4 != 0 || !allow_e4))))) {
         const int nely = (m->ny - 1) / P;
         g.T = T; g.E = E; g.R = R > nely ? nely : R;
         g.chunks = chunks_for((m->nx - 1) / (E * P) + 1, T);
@@ -717,9 +394,9 @@ static Geom3D plan3d_env(const dn_mesh* m) {
     return g;
 }
 
-static long long num_workgroups(const dn_mesh* m) {
+static long long num_workgroups(const dn_mesh* m, bool allow_e4 = true) {
     if (m->nsd == 2) {
-        Geom2D g = plan2d_env(m, m->degree);
+        Geom2D g = plan2d_env(m, m->degree, allow_e4);
         return (long long)g.chunks * g.strips * m->batch;
     }
     Geom3D g = plan3d_env(m);
@@ -743,13 +420,7 @@ static void launch2d_vec(const PoissonParams& pp, const Geom2D& g, int batch, bo
     constexpr bool CANVEC = (E * P == 2 || E * P == 4);
     const bool v = vec && CANVEC;
     if constexpr (P == 1) {
-        if (v) {
-            if (fgp) hipLaunchKernelGGL((poisson2d_q1_kernel<NGP, E, CANVEC, true>), grid, block, 0, s, pp);
-            else hipLaunchKernelGGL((poisson2d_q1_kernel<NGP, E, CANVEC, false>), grid, block, 0, s, pp);
-        } else {
-            if (fgp) hipLaunchKernelGGL((poisson2d_q1_kernel<NGP, E, false, true>), grid, block, 0, s, pp);
-            else hipLaunchKernelGGL((poisson2d_q1_kernel<NGP, E, false, false>), grid, block, 0, s, pp);
-        }
+        (void)v;   // Q1 goes through launch_poisson2d_q1_g* (see launch2d)
     } else {
         if (v) {
             if (fgp) hipLaunchKernelGGL((poisson2d_kernel<P, NGP, E, CANVEC, true>), grid, block, 0, s, pp);
@@ -775,9 +446,9 @@ static int launch2d_e(const PoissonParams& pp, const Geom2D& g, int batch, bool 
 
 static int launch2d(const PoissonParams& pp, const Geom2D& g, int P, int ngp, int batch, bool vec, hipStream_t s) {
     switch (P * 10 + ngp) {
-        case 12: return launch2d_e<1, 2>(pp, g, batch, vec, s);
-        case 13: return launch2d_e<1, 3>(pp, g, batch, vec, s);
-        case 14: return launch2d_e<1, 4>(pp, g, batch, vec, s);
+        case 12: return launch_poisson2d_q1_g2(pp, g, batch, vec, s);
+        case 13: return launch_poisson2d_q1_g3(pp, g, batch, vec, s);
+        case 14: return launch_poisson2d_q1_g4(pp, g, batch, vec, s);
         case 23: return launch2d_e<2, 3>(pp, g, batch, vec, s);
         case 24: return launch2d_e<2, 4>(pp, g, batch, vec, s);
         case 33: return launch2d_e<3, 3>(pp, g, batch, vec, s);
@@ -816,7 +487,8 @@ using namespace dn;
 
 extern "C" int64_t dn_poisson_workspace_bytes(const dn_mesh* mesh) {
     if (validate_mesh(mesh) != 0) return DN_E_BADARG;
-    return DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * num_workgroups(mesh);
+    const long long n = std::max(num_workgroups(mesh, true), num_workgroups(mesh, false));   // either launch plan fits
+    return DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * n;
 }
 
 extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void* stream) {
@@ -829,7 +501,17 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     const int P = m->degree;
     if (m->ngp < (P == 1 ? 2 : 3)) return DN_E_UNSUPPORTED;
     const bool want_red = a->energy || a->sumsq;
-    const long long nwg = num_workgroups(m);
+    auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
+    // vector loads/stores of NW nodes are legal when every row segment start is NW-element aligned
+    auto vec_ok = [&](int NW) {
+        bool ok = (NW == 2 || NW == 4) && (m->nx % NW == 0) && aligned(a->u, 4 * NW) && aligned(a->nu, 4 * NW) &&
+                  aligned(a->f, 4 * NW) && aligned(a->out, 4 * NW);
+        for (int k = 0; k < 2; ++k)
+            ok = ok && aligned(a->bc[k].mask, a->bc[k].mask_is_u8 ? NW : 4 * NW) && aligned(a->bc[k].field, 4 * NW);
+        return ok;
+    };
+    const bool allow_e4 = vec_ok(4);
+    const long long nwg = num_workgroups(m, allow_e4);
     if (want_red && (!a->workspace || a->workspace_bytes < DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
     if ((int64_t)m->nx * m->ny * (m->nsd == 3 ? m->nz : 1) >= (1ll << 30)) return DN_E_UNSUPPORTED;   // 32-bit in-sample offsets
 
@@ -879,17 +561,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.want_sums = want_red ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-    auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
-    // vector loads/stores of NW nodes are legal when every row segment start is NW-element aligned
-    auto vec_ok = [&](int NW) {
-        bool ok = (NW == 2 || NW == 4) && (m->nx % NW == 0) && aligned(a->u, 4 * NW) && aligned(a->nu, 4 * NW) &&
-                  aligned(a->f, 4 * NW) && aligned(a->out, 4 * NW);
-        for (int k = 0; k < 2; ++k)
-            ok = ok && aligned(a->bc[k].mask, a->bc[k].mask_is_u8 ? NW : 4 * NW) && aligned(a->bc[k].field, 4 * NW);
-        return ok;
-    };
     if (m->nsd == 2) {
-        const Geom2D g = plan2d_env(m, P);
+        const Geom2D g = plan2d_env(m, P, allow_e4);
         pp.rows_per_strip = g.R;
         const int NW = g.E * P;
         const bool vec = vec_ok(NW);
