@@ -13,6 +13,8 @@
 // register allocation (measured: 226 vs 111 VGPRs), and every element is kept in its own basic block (the
 // `if (valid)` below is also a scheduling fence: in one block the scheduler interleaves the E element streams and
 // the live temporaries double).
+#include <cstdlib>
+
 #include "poisson_common.h"
 
 namespace dn {
@@ -138,10 +140,15 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
     // Finish node row `yr`: o[n] holds this thread's contributions to nodes x0..x0+E; node x0 also receives
     // the left neighbour's o[E] through LDS.
     auto emit_row = [&](const float (&o)[NW + 1], const float (&keep)[NW], int yr, bool owned_row) {
+#ifndef DN_ABLATE_XCH                      // timing experiment only: drop the neighbour hand-over
         xch[par][tid] = o[NW];
-        __syncthreads();
+        // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the prefetched next row
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const float left = (tid > 0) ? xch[par][tid - 1] : 0.f;
         par ^= 1;
+#else
+        const float left = 0.f;
+#endif
         if (owned_row && col_owner) {
             float v[NW];
 #pragma unroll
@@ -150,7 +157,11 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
                 sq_acc = fmaf(t, t, sq_acc);                 // nodes beyond the domain receive no contribution: t == 0
                 v[n] = t * p.out_scale;
             }
+#ifndef DN_ABLATE_STORE
             if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)yr * (unsigned)p.nx, x0, p.nx, v);
+#else
+            if (sb.out && v[0] == 12345.678f) store_seg<NW, VEC>(sb.out, (unsigned)yr * (unsigned)p.nx, x0, p.nx, v);
+#endif
         }
     };
 
@@ -171,8 +182,14 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
                     for (int gi = 0; gi < NGP * NGP; ++gi) fg[gi] = fgp[eo + (unsigned)gi * eps];
                 }
                 float ct0[NGP], ct1[NGP], cdx0, cdx1, e1, e2;
+#ifndef DN_ABLATE_COMPUTE
                 q1_layer_2d<NGP, FGP>(p.T, L.TU[e], U.TU[e], L.DX[e], U.DX[e], L.TN[e], U.TN[e], L.TF[e], U.TF[e], fg, ct0, ct1,
                                       cdx0, cdx1, e1, e2);
+#else                                      // timing experiment only: keep every load alive with trivial arithmetic
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) { ct0[i] = L.TU[e][i] + U.TN[e][i]; ct1[i] = U.TU[e][i] + U.TF[e][i]; }
+                cdx0 = L.DX[e]; cdx1 = U.DX[e]; e1 = cdx0; e2 = cdx1;
+#endif
                 le1 += e1;
                 le2 += e2;
                 // row ey is complete for this element: x-stage transpose of (layer below + this layer)
@@ -208,7 +225,9 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
     }
 #else
     for (; ey < ey_end; ++ey) {
+#ifndef DN_ABLATE_MEM                      // timing experiment only: reuse the first row's data
         row_issue(ey + 1, raw);
+#endif
         row_stage(raw, SB);
         layer(ey, SA, SB);
         SA = SB;                           // the upper row becomes the lower row of the next layer
@@ -235,6 +254,241 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);
 }
 
+// =============================================================================================
+// LDS-DMA variant (E = 4, aligned rows, Dirichlet masks absent or uint8 + constant values).
+// Same arithmetic as poisson2d_q1_kernel; the difference is how node rows reach the registers: every wave streams
+// its 256-node row segments with `global_load_lds` (LDS-DMA: no VGPR destination) into a private two-slot ring,
+// two rows ahead of the layer being computed, and reads them back with ds_read_b128.  This (a) keeps ~2 rows per
+// wave in flight without prefetch registers, (b) removes the three extra per-row loads of the node shared with the
+// next lane (it is the next lane's first float in LDS), (c) leaves the loaded-latency (~4 us under load) two full
+// layer rounds to hide in.  Waits are counted (`s_waitcnt vmcnt(NG)` leaves the younger row in flight) and the
+// hand-over barrier is LDS-only, as a `__syncthreads()` would drain the DMA (cdna_hip_programming.md section 5,
+// "Pipelining across barriers").  All LDS is one dynamic array (same section, trap 4a).
+// =============================================================================================
+template <int NGP, int FL>
+__global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_dma_kernel(const PoissonParams p) {
+    constexpr int E = 4, NW = 4;
+    constexpr bool HAS_NU = (FL & FL_NU) != 0, HAS_F = (FL & FL_F) != 0;
+    constexpr bool BC_U8C = (FL & FL_BC_U8C) != 0;
+    constexpr int NF = 1 + (HAS_NU ? 1 : 0) + (HAS_F ? 1 : 0);
+    constexpr int NM = BC_U8C ? 2 : 0;
+    constexpr int FSLOT = 1024 + 256, MSLOT = 256 + 256;         // bytes per field / mask per row
+    constexpr int SLOT = NF * FSLOT + NM * MSLOT;
+    constexpr int NG = 2 * (NF + NM);                             // LDS-DMA instructions per row
+    static_assert((FL & (FL_FGP | FL_BC)) == 0, "LDS-DMA kernel: nodal forcing and uint8/constant Dirichlet only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int T = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = T >> 6;
+    const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+    const int q = chunk * (T - 1) + tid;
+    const int ex0 = q * E, x0 = ex0;
+    const int xw = (chunk * (T - 1) + wave * 64) * E;             // first node of this wave
+    const bool col_owner = !(chunk > 0 && tid == 0);
+    const int64_t nps = (int64_t)p.nx * p.ny;
+    const SampleBases sb = sample_bases(p, b, nps);
+    const int R = p.rows_per_strip;
+    const int ey_own = strip * R;
+    const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;
+    const int ey_end = min(ey_own + R, p.nely);
+    // LDS carve-up: [per-wave rings][xch 2 x T floats][red 8 doubles][flag]
+    unsigned char* ring = lds + wave * 2 * SLOT;
+    float* xch = reinterpret_cast<float*>(lds + nwave * 2 * SLOT);
+    double* red = reinterpret_cast<double*>(lds + nwave * 2 * SLOT + 2 * 256 * 4);
+    int* last_flag = reinterpret_cast<int*>(lds + nwave * 2 * SLOT + 2 * 256 * 4 + 64);
+
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    const float* fbase[3] = {sb.u, HAS_NU ? sb.nu : sb.f, sb.f};
+    const uint8_t* mbase[2] = {reinterpret_cast<const uint8_t*>(sb.mask[0]),
+                               reinterpret_cast<const uint8_t*>(sb.mask[1] ? sb.mask[1] : sb.mask[0])};
+    const float mval[2] = {p.bc[0].value, sb.mask[1] ? p.bc[1].value : p.bc[0].value};   // absent 2nd condition: repeat the 1st
+
+    const unsigned xl = (unsigned)min(x0, p.nx - NW);                       // this lane's 4 nodes (clamped, aligned)
+    const unsigned xe = (unsigned)min(xw + 256 + lane, p.nx - 1);           // the node after the wave's segment (+ spare lanes)
+    const unsigned xe4 = (unsigned)min(xw + 256 + 4 * lane, p.nx - NW);     // same for byte masks: LDS-DMA moves whole aligned dwords
+    auto issue_row = [&](int yr) {
+        const unsigned rowoff = (unsigned)min(yr, p.ny - 1) * (unsigned)p.nx;
+        unsigned char* slot = ring + (yr & 1) * SLOT;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            __builtin_amdgcn_global_load_lds((gptr)(fbase[k] + (rowoff + xl)), (lptr)(slot + k * FSLOT), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(fbase[k] + (rowoff + xe)), (lptr)(slot + k * FSLOT + 1024), 4, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+            __builtin_amdgcn_global_load_lds((gptr)(mbase[k] + (rowoff + xl)), (lptr)(slot + NF * FSLOT + k * MSLOT), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(mbase[k] + (rowoff + xe4)), (lptr)(slot + NF * FSLOT + k * MSLOT + 256), 4, 0, 0);
+        }
+    };
+
+    RowState2D<NGP, E> SA, SB;
+    float CT[E][NGP], CDX[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        CDX[e] = 0.f;
+        SA.keep[e] = SB.keep[e] = 1.f;
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) { CT[e][i] = 0.f; SA.TN[e][i] = SB.TN[e][i] = 1.f; SA.TF[e][i] = SB.TF[e][i] = 0.f; }
+    }
+
+    // read a landed row out of the ring, apply Dirichlet conditions and the x-stage.
+    // The ring is read with inline-asm ds_read: for a compiler-visible LDS read hipcc (ROCm 7.2) conservatively drains
+    // every LDS-DMA in flight (`s_waitcnt vmcnt(0)`), which would serialise the two-row prefetch; the asm reads are
+    // ordered by the counted vmcnt wait above them and retired by the explicit lgkmcnt(0) below.
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ring;
+    auto read_stage = [&](int yr, RowState2D<NGP, E>& S) {
+        const unsigned a16 = ring_lds + (unsigned)(yr & 1) * SLOT + (unsigned)lane * 16u;
+        const unsigned a4 = ring_lds + (unsigned)(yr & 1) * SLOT + (unsigned)lane * 4u;
+        f4 v[3];
+        float nx1[3];
+        unsigned mw[2] = {0u, 0u}, mn[2] = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[k]) : "v"(a16), "n"(k * FSLOT));
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(nx1[k]) : "v"(a16), "n"(k * FSLOT + 16));
+        }
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(mw[k]) : "v"(a4), "n"(NF * FSLOT + k * MSLOT));
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(mn[k]) : "v"(a4), "n"(NF * FSLOT + k * MSLOT + 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float r[3][NW + 1];
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            asm volatile("" : "+v"(v[k]), "+v"(nx1[k]));                  // consumers stay behind the wait
+            r[k][0] = v[k].x; r[k][1] = v[k].y; r[k][2] = v[k].z; r[k][3] = v[k].w;
+            r[k][4] = nx1[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NM; ++k) asm volatile("" : "+v"(mw[k]), "+v"(mn[k]));
+        if constexpr (BC_U8C) {
+#pragma unroll
+            for (int n = 0; n < NW; ++n) S.keep[n] = 1.f;
+#pragma unroll
+            for (int k = 0; k < NM; ++k) {
+                const uint32_t w = mw[k], wn = mn[k];
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) {
+                    const bool set = n < NW ? ((w >> (8 * n)) & 0xffu) != 0u : wn != 0u;
+                    r[0][n] = set ? mval[k] : r[0][n];
+                    if (n < NW) S.keep[n] = set ? 0.f : S.keep[n];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            S.DX[e] = r[0][e + 1] - r[0][e];
+#pragma unroll
+            for (int i = 0; i < NGP; ++i) S.TU[e][i] = fmaf(p.T.b[i][1], S.DX[e], r[0][e]);
+            if constexpr (HAS_NU) {
+                const float d = r[1][e + 1] - r[1][e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) S.TN[e][i] = fmaf(p.T.b[i][1], d, r[1][e]);
+            }
+            if constexpr (HAS_F) {
+                constexpr int kf = HAS_NU ? 2 : 1;
+                const float d = r[kf][e + 1] - r[kf][e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) S.TF[e][i] = fmaf(p.T.b[i][1], d, r[kf][e]);
+            }
+        }
+    };
+
+    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
+    int par = 0;
+
+    auto emit_row = [&](const float (&o)[NW + 1], const float (&keep)[NW], int yr, bool owned_row) {
+        xch[par * 256 + tid] = o[NW];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS-only: the DMA stays in flight
+        const float left = (tid > 0) ? xch[par * 256 + tid - 1] : 0.f;
+        par ^= 1;
+        if (owned_row && col_owner) {
+            float v[NW];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const float t = (o[n] + (n == 0 ? left : 0.f)) * keep[n];
+                sq_acc = fmaf(t, t, sq_acc);
+                v[n] = t * p.out_scale;
+            }
+            if (sb.out) store_seg<NW, true>(sb.out, (unsigned)yr * (unsigned)p.nx, x0, p.nx, v);
+        }
+    };
+
+    auto layer = [&](int ey, const RowState2D<NGP, E>& L, const RowState2D<NGP, E>& U) {
+        const bool own_layer = ey >= ey_own;
+        const float cnt = (own_layer && col_owner) ? 1.f : 0.f;
+        float o[NW + 1], le1 = 0.f, le2 = 0.f;
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) o[n] = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (ex0 + e < p.nelx) {
+                float ct0[NGP], ct1[NGP], cdx0, cdx1, e1, e2;
+                q1_layer_2d<NGP, false>(p.T, L.TU[e], U.TU[e], L.DX[e], U.DX[e], L.TN[e], U.TN[e], L.TF[e], U.TF[e], nullptr, ct0,
+                                        ct1, cdx0, cdx1, e1, e2);
+                le1 += e1;
+                le2 += e2;
+                float ssum = 0.f, bsum = cdx0 + CDX[e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) {
+                    const float t = ct0[i] + CT[e][i];
+                    ssum += t;
+                    bsum = fmaf(p.T.b[i][1], t, bsum);
+                    CT[e][i] = ct1[i];
+                }
+                CDX[e] = cdx1;
+                o[e + 1] += bsum;
+                o[e] += ssum - bsum;
+            }
+        }
+        e1_acc = fmaf(cnt, le1, e1_acc);
+        e2_acc = fmaf(cnt, le2, e2_acc);
+        emit_row(o, L.keep, ey, own_layer);
+    };
+
+    issue_row(ey_begin);
+    issue_row(ey_begin + 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");           // row ey_begin landed, ey_begin+1 in flight
+    read_stage(ey_begin, SA);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // ring reads done before the slot is refilled
+    issue_row(ey_begin + 2);
+    for (int ey = ey_begin; ey < ey_end; ++ey) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");       // row ey+1 landed; row ey+2 may still fly
+        read_stage(ey + 1, SB);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_row(ey + 3);
+        layer(ey, SA, SB);
+        SA = SB;
+    }
+    if (ey_end == p.nely) {
+        float o[NW + 1];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) o[n] = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (ex0 + e < p.nelx) {
+                float ssum = 0.f, bsum = CDX[e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) { ssum += CT[e][i]; bsum = fmaf(p.T.b[i][1], CT[e][i], bsum); }
+                o[e + 1] += bsum;
+                o[e] += ssum - bsum;
+            }
+        }
+        emit_row(o, SA.keep, p.ny - 1, true);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // no DMA may outlive the workgroup's LDS
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, last_flag);
+}
+
+template <int NGP, int FL>
+static void launch_dma(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
+    constexpr int NF = 1 + ((FL & FL_NU) ? 1 : 0) + ((FL & FL_F) ? 1 : 0), NM = (FL & FL_BC_U8C) ? 2 : 0;
+    const size_t lds = (size_t)(g.T / 64) * 2 * (NF * 1280 + NM * 512) + 2 * 256 * 4 + 64 + 16;
+    hipLaunchKernelGGL((poisson2d_q1_dma_kernel<NGP, FL>), dim3(g.chunks, g.strips, batch), dim3(g.T), lds, s, pp);
+}
+
 // ---- dispatch over the compile-time flag set --------------------------------------------------------------
 template <int NGP, int E, bool VEC, int FL>
 static void launch_one(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
@@ -244,9 +498,20 @@ static void launch_one(const PoissonParams& pp, const Geom2D& g, int batch, hipS
 template <int NGP, int E, bool VEC, int FLF>   // FLF: nu / f flags already fixed
 static void launch_bc(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
     const bool any = pp.bc[0].mask || pp.bc[1].mask;
-    bool u8c = any;
+    bool u8c = any && pp.bc[0].mask != nullptr;
     for (int k = 0; k < 2; ++k)
         if (pp.bc[k].mask && (!pp.bc[k].mask_is_u8 || pp.bc[k].field)) u8c = false;
+    // The LDS-DMA variant is functionally complete and parity-tested (DN_USE_DMA=1), but measured 5-15 % SLOWER than the
+    // register path on MI355X at the bench shape (profiles/README.md): the kernel is not load-latency bound, so the
+    // two-row-deep ring buys nothing and costs LDS round trips.  It stays opt-in.
+    static const bool use_dma = getenv("DN_USE_DMA") != nullptr;
+    if constexpr (E == 4 && VEC && (FLF & FL_FGP) == 0) {
+        if (use_dma && (!any || u8c)) {
+            if (!any) launch_dma<NGP, FLF>(pp, g, batch, s);
+            else launch_dma<NGP, FLF | FL_BC_U8C>(pp, g, batch, s);
+            return;
+        }
+    }
     if (!any) launch_one<NGP, E, VEC, FLF>(pp, g, batch, s);
     else if (u8c) launch_one<NGP, E, VEC, FLF | FL_BC_U8C>(pp, g, batch, s);
     else launch_one<NGP, E, VEC, FLF | FL_BC>(pp, g, batch, s);
