@@ -1,0 +1,53 @@
+"""First-order shear-deformation (FSDT / Mindlin) plate residuals on the HIP operators -- SURVEY.md 8(a) row a14,
+reference `examples/elasticity/single_instance/e1_plate_bending_fsdt.py:128-232`.
+
+Three nodal fields (w, phi_x, phi_y); 9 Gauss-point evaluations, the constitutive combinations (eq. 4 of the
+script), three weak-form residuals and their element->node assembly, Dirichlet rows replaced by the boundary
+values.  Round-1 status: composed from the single-launch HIP operators (`gauss_pt_evaluation*`,
+`assemble`) -- any degree the operators support (the reference script is Q1; BASELINE configs[4] asks for Q2, whose
+assembly the reference does not have: it is `dn_assemble` with nbf = 3).  A fused three-field kernel in the style of
+`dn_poisson_apply` is listed in DESIGN.md section 6."""
+import torch
+
+
+def fsdt_residuals(fem, w, phi_x, phi_y, bc, w_bc=0.0, phi_x_bc=0.0, phi_y_bc=0.0, E=1.0, v=0.25, h=0.1, K_s=1.0, q=1.0,
+                   hx=None, hy=None):
+    """Assembled residuals (R1, R2, R3) of the three FSDT equations; `bc >= 0.5` marks Dirichlet nodes."""
+    hx = fem.h if hx is None else hx
+    hy = fem.h if hy is None else hy
+
+    def fix(t, val):
+        return torch.where(bc >= 0.5, val if isinstance(val, torch.Tensor) else torch.full_like(t, val), t)
+
+    w, phi_x, phi_y = fix(w, w_bc), fix(phi_x, phi_x_bc), fix(phi_y, phi_y_bc)
+    D_11 = (E * h ** 3) / (12 * (1 - v ** 2))
+    D_22 = D_11
+    D_12 = (E * v * h ** 3) / (12 * (1 - v ** 2))
+    D_66 = (E * h ** 3) / (12 * (1 + v))
+    A_44 = A_55 = (E * h) / (2 * (1 + v))
+    ev, dx, dy = fem.gauss_pt_evaluation, fem.gauss_pt_evaluation_der_x, fem.gauss_pt_evaluation_der_y
+    Q_x = K_s * A_55 * (ev(phi_x) + dx(w))
+    Q_y = K_s * A_44 * (ev(phi_y) + dy(w))
+    pxx, pxy, pyx, pyy = dx(phi_x), dy(phi_x), dx(phi_y), dy(phi_y)
+    M_xx = D_11 * pxx + D_12 * pyy
+    M_yy = D_12 * pxx + D_22 * pyy
+    M_xy = D_66 * (pxy + pyx)
+    dev = w.device
+    N, Nx, Ny = (t.to(dev) for t in (fem.Nvalues, fem.dN_x_values, fem.dN_y_values))       # (1, nbf, ngp, 1, 1)
+    jxw = (fem.gpw.to(dev) * (0.5 * hx) * (0.5 * hy)).reshape(1, 1, -1, 1, 1)
+
+    def weak(a_x, a_y, a_0):
+        """sum_g JxW ( dN_x a_x + dN_y a_y + N a_0 ), per local basis function -> (B, nbf, nelY, nelX)"""
+        t = Nx * a_x.unsqueeze(1) + Ny * a_y.unsqueeze(1) + N * a_0.unsqueeze(1)
+        return torch.sum(t * jxw, 2)
+
+    qg = torch.full_like(Q_x, q)
+    R1 = fem.assemble(weak(Q_x, Q_y, -qg))
+    R2 = fem.assemble(weak(M_xx, M_xy, Q_x))
+    R3 = fem.assemble(weak(M_xy, M_yy, Q_y))
+    return fix(R1, w_bc), fix(R2, phi_x_bc), fix(R3, phi_y_bc)
+
+
+def fsdt_loss(fem, w, phi_x, phi_y, bc, **kw):
+    """Frobenius norms of the three residuals (e1_plate_bending_fsdt.py:230-232)."""
+    return tuple(torch.norm(R, 'fro') for R in fsdt_residuals(fem, w, phi_x, phi_y, bc, **kw))

@@ -1,0 +1,47 @@
+"""Convolutional auto-encoder used by IBN_2D.py:186 (`AE(1, 1, n_downsample=2)`); reference:
+DiffNet/networks/autoencoders.py:7-95.  Encoder: ReflPad3 -> Conv7x7(in -> 2*dim) -> InstanceNorm -> LeakyReLU, then
+n_downsample x [Conv4x4 s2 -> InstanceNorm -> ReLU] with widths 2*dim*(i+1) -> 2*dim*(i+2), Tanh.  Decoder mirrors it
+with transposed convolutions + LeakyReLU, then ReflPad4 -> Conv3x3 -> Conv7x7.  The reference leaves the final
+activation commented out (:81) and so does this one."""
+from torch import nn
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels=3, dim=64, n_downsample=3, encoder_type='convolutional'):
+        super().__init__()
+        # the reference's first InstanceNorm is declared with `dim` features after a 2*dim-channel conv: harmless
+        # (affine=False) and kept so construction consumes the RNG identically
+        layers = [nn.ReflectionPad2d(3), nn.Conv2d(in_channels, dim * 2, 7), nn.InstanceNorm2d(dim), nn.LeakyReLU(0.2, inplace=True)]
+        for i in range(n_downsample):
+            cin, cout = (dim * 2 * (i + 1), dim * (i + 2) * 2) if i <= 3 else (dim * 10, dim * 10)
+            layers += [nn.Conv2d(cin, cout, 4, stride=2, padding=1), nn.InstanceNorm2d(cout), nn.ReLU(inplace=True)]
+        self.model_blocks = nn.Sequential(*layers, nn.Tanh())
+
+    def forward(self, x):
+        return self.model_blocks(x)
+
+
+class Decoder(nn.Module):
+    def __init__(self, out_channels=3, dim=64, n_upsample=3, encoder_type='convolutional', activation='relu'):
+        super().__init__()
+        layers = []
+        i = 0
+        for i in reversed(range(n_upsample)):
+            cin, cout = (dim * 10, dim * 10) if i > 3 else (dim * (i + 2) * 2, dim * (i + 1) * 2)
+            layers += [nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1), nn.InstanceNorm2d(cout), nn.LeakyReLU(0.2, inplace=True)]
+        layers += [nn.ReflectionPad2d(4), nn.Conv2d(dim * (i + 1) * 2, out_channels, 3), nn.Conv2d(out_channels, out_channels, 7)]
+        self.model_blocks = nn.Sequential(*layers)
+        self.activation = nn.Sigmoid() if activation == 'sigmoid' else nn.ReLU()   # declared, not applied (as the reference)
+
+    def forward(self, x):
+        return self.model_blocks(x)
+
+
+class AE(nn.Module):
+    def __init__(self, in_channels, out_channels, dims=64, n_downsample=4):
+        super().__init__()
+        self.encoder = Encoder(in_channels, dim=dims, n_downsample=n_downsample, encoder_type='regular')
+        self.decoder = Decoder(out_channels, dim=dims, n_upsample=n_downsample, activation='relu')
+
+    def forward(self, x):
+        return self.decoder(self.encoder(x))

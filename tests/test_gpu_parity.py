@@ -435,3 +435,43 @@ def test_slab_decomposition_on_gpu_matches_global(nsd, sizes, lengths, world):
         gfull[:, :, dec.n0:dec.n1 + 1] += g               # interface layers: sum of both neighbours' parts
     np.testing.assert_allclose(esum / (B * gm.geom.nelem_total), float(lref), rtol=1e-6)
     close(gfull, gref.cpu().numpy(), rtol=1e-5, arel=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["n17", "n33"])
+def test_fsdt_plate_vs_reference_golden(tag):
+    from diffnet_amd.elasticity import fsdt_loss, fsdt_residuals
+    z = load(f"loss_fsdt_{tag}.npz")
+    m = module(eval(str(z["kwargs"])))
+    bc = cu(z["inputs"])[:, 3:4].contiguous()
+    fields = [cu(z[n]).requires_grad_(True) for n in ("w", "phi_x", "phi_y")]
+    Rs = fsdt_residuals(m, *fields, bc)
+    for i, R in enumerate(Rs):
+        close(R, z[f"R{i + 1}"], rtol=1e-4, arel=1e-5)
+    norms = fsdt_loss(m, *fields, bc)
+    for i, nv in enumerate(norms):
+        np.testing.assert_allclose(float(nv), float(z["norms"][i]), rtol=1e-5)
+        gs = torch.autograd.grad(nv, fields, retain_graph=True)
+        ref = z[f"grad_norm{i + 1}"]
+        for gq, rq in zip(gs, ref):
+            close(gq, rq, rtol=1e-4, arel=1e-4 * float(np.abs(ref).max()) / max(float(np.abs(rq).max()), 1e-30))
+
+
+def test_fsdt_q2_assembly_is_the_adjoint_of_evaluation():
+    """Q2 element->node assembly (absent from the reference): <assemble(r), v> == <r, gather(v)> and the FSDT residual
+    on a Q2 mesh is finite and vanishes on Dirichlet nodes (configs[4] shape class, small instance)."""
+    from diffnet_amd.elasticity import fsdt_residuals
+    m = module(dict(domain_size=33, fem_basis_deg=2))
+    r = seeded((2, 9, 16, 16), 41).to(dev()).requires_grad_(True)
+    v = seeded((2, 1, 33, 33), 42).to(dev())
+    a = m.assemble(r)
+    (gr,) = torch.autograd.grad(a, r, v)
+    lhs = float((a.detach().double() * v.double()).sum())
+    rhs = float((r.detach().double() * gr.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * abs(lhs)
+    # gather(v)[b,a,e] is v at local node a of element e
+    assert torch.equal(gr[:, 4], v[:, 0, 1::2, 1::2])        # centre node of each Q2 element
+    bc = boundary_mask((2, 1, 33, 33)).to(dev())
+    f3 = [seeded((2, 1, 33, 33), 43 + i).to(dev()) for i in range(3)]
+    Rs = fsdt_residuals(m, *f3, bc)
+    for R in Rs:
+        assert torch.isfinite(R).all() and float((R * bc).abs().max()) == 0.0
