@@ -63,7 +63,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(kw, c, budget_s=20.0):
+def cpu_baseline(kw, c, budget_s=15.0):
     """Time the oracle (torch-CPU port of the reference op sequence: per-GP conv + cat + elementwise + autograd
     backward) on a bounded sample: batch 2 of the same mesh, as many iterations as fit the budget."""
     from oracle.fem_oracle import Oracle
@@ -89,7 +89,7 @@ def cpu_baseline(kw, c, budget_s=20.0):
         step()
         it += 1
         el = time.perf_counter() - t0
-        if el > budget_s or it >= 50:
+        if el > budget_s or it >= 400:
             break
     return {"value": units * it / el, "unit": "elements*gauss_pts/s", "cores": ncores, "kind": "port",
             "sample": f"oracle/fem_oracle.py energy fwd+bwd, batch {Bs} of the same mesh, {it} iters in {el:.1f}s, "
