@@ -80,6 +80,34 @@ __device__ __forceinline__ void load_seg(const T* __restrict__ base, unsigned ro
     dst[NW] = base[rowoff + (unsigned)min(x0 + NW, nx - 1)];
 }
 
+// Exactly NW consecutive nodes starting at x0 (clamped like load_seg, no shared +1 node).
+template <int NW, bool VEC, typename T>
+__device__ __forceinline__ void load_own(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[NW]) {
+    if constexpr (VEC && (NW == 2 || NW == 4)) {
+        const unsigned xl = (unsigned)min(x0, nx - NW);
+        if constexpr (sizeof(T) == 4) {
+            using V = typename VecT<NW>::type;
+            const V v = *reinterpret_cast<const V*>(base + (rowoff + xl));
+            const T* vf = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int k = 0; k < NW; ++k) dst[k] = vf[k];
+        } else {
+            if constexpr (NW == 4) {
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(base + (rowoff + xl));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[k] = (T)((w >> (8 * k)) & 0xffu);
+            } else {
+                const uint16_t w = *reinterpret_cast<const uint16_t*>(base + (rowoff + xl));
+                dst[0] = (T)(w & 0xffu);
+                dst[1] = (T)(w >> 8);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) dst[k] = base[rowoff + (unsigned)min(x0 + k, nx - 1)];
+    }
+}
+
 // Store NW consecutive floats at x0 (entries >= nx dropped).  VEC as above.
 template <int NW, bool VEC>
 __device__ __forceinline__ void store_seg(float* __restrict__ base, unsigned rowoff, int x0, int nx, const float (&src)[NW]) {

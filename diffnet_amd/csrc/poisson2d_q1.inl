@@ -211,6 +211,11 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
         emit_row(o, L.keep, ey, own_layer);
     };
 
+#ifdef DN_STAGGER
+    // de-phase the workgroups: identical workgroups started together tend to run in lockstep (everybody loads, then
+    // everybody computes), so the load and compute phases of different workgroups do not overlap
+    for (int i = (int)((blockIdx.y + blockIdx.z) & 3u); i > 0; --i) __builtin_amdgcn_s_sleep(DN_STAGGER);
+#endif
     RowRaw2D<E> raw;
     row_issue(ey_begin, raw);
     row_stage(raw, SA);
@@ -426,8 +431,14 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_dma_kernel(c
         for (int e = 0; e < E; ++e) {
             if (ex0 + e < p.nelx) {
                 float ct0[NGP], ct1[NGP], cdx0, cdx1, e1, e2;
+#ifndef DN_ABLATE_COMPUTE
                 q1_layer_2d<NGP, false>(p.T, L.TU[e], U.TU[e], L.DX[e], U.DX[e], L.TN[e], U.TN[e], L.TF[e], U.TF[e], nullptr, ct0,
                                         ct1, cdx0, cdx1, e1, e2);
+#else
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) { ct0[i] = L.TU[e][i] + U.TN[e][i]; ct1[i] = U.TU[e][i] + U.TF[e][i]; }
+                cdx0 = L.DX[e]; cdx1 = U.DX[e]; e1 = cdx0; e2 = cdx1;
+#endif
                 le1 += e1;
                 le2 += e2;
                 float ssum = 0.f, bsum = cdx0 + CDX[e];

@@ -1,0 +1,426 @@
+// 3-D Q1 fused Poisson kernel, fully sum-factorised marching form.  Included by
+// poisson3d_q1_g{2,3,4}.hip with DN_NGP defined.
+//
+// grid = (chunks_x * tiles_y, strips_z, B), block = (TX, TY).  Thread (tx, ty) owns E consecutive elements of
+// element row ey and marches over element planes.  Carried per element: the in-plane stage of the lower node plane
+// (VU/VX/VY/VN/VF at the in-plane Gauss points) and the cotangents of that plane's stage values from the layer
+// below.  Per layer: load the two node rows of the new plane, x- and y-stage them, the O(NGP^2) layer arithmetic
+// (q1_layer_3d), then ONE in-plane transpose (y then x) per finished plane; contributions to nodes shared with the
+// neighbouring threads (right, up, up-right) go through a double-buffered LDS slot, one LDS-only barrier per layer.
+#include <cstdlib>
+
+#include "poisson_common.h"
+
+namespace dn {
+
+enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8 };
+
+template <int NGP, int E>
+struct PlaneState3D {
+    float VU[E][NGP][NGP], VX[E][NGP], VY[E][NGP], VN[E][NGP][NGP], VF[E][NGP][NGP];
+    float keep[E];
+};
+
+#ifndef DN_Q1_3D_WAVES
+#define DN_Q1_3D_WAVES 2
+#endif
+
+template <int NGP, int E, bool VEC, int FL>
+__global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(const PoissonParams p, const int chunks_x) {
+    constexpr int NW = E;
+    constexpr int G = NGP * NGP * NGP;
+    constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, FGP = (FL & FL3_FGP) != 0, BC_ANY = (FL & FL3_BC) != 0;
+    const int TX = blockDim.x, TY = blockDim.y;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * TX + tx;
+    const int chunk = blockIdx.x % chunks_x, tile = blockIdx.x / chunks_x, strip = blockIdx.y, b = blockIdx.z;
+    const int q = chunk * (TX - 1) + tx;
+    const int ex0 = q * E, x0 = ex0;
+    const int ey = tile * (TY - 1) + ty;          // element row == lower node row of this thread
+    const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);
+    const unsigned npl = (unsigned)(p.nx * p.ny);
+    const int64_t nps = (int64_t)npl * p.nz;
+    const unsigned epl = (unsigned)(p.nelx * p.nely);
+    const unsigned eps = epl * (unsigned)p.nelz;
+    const SampleBases sb = sample_bases(p, b, nps);
+    const float* fgp = FGP ? p.fgp + (p.f_batched ? (int64_t)b * eps * G : 0) : nullptr;
+    const int R = p.rows_per_strip;
+    const int ez_own = strip * R;
+    const int ez_begin = ez_own > 0 ? ez_own - 1 : 0;
+    const int ez_end = min(ez_own + R, p.nelz);
+    const bool row_ok = ey < p.nely;              // thread has real elements
+    const bool noderow_ok = ey < p.ny;            // thread's lower node row exists
+
+    // hand-over slots: [parity][slot][thread]; 0 = right (row 0, n = E), 1..E = up (row 1, n < E), E+1 = up-right
+    __shared__ float xch[2][NW + 2][256];
+    __shared__ double red[8];
+    __shared__ int last_flag;
+
+    PlaneState3D<NGP, E> SA, SB;
+    float cU[E][NGP][NGP], cX[E][NGP], cY[E][NGP];      // carried cotangents of the lower plane's stage values
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        SA.keep[e] = SB.keep[e] = 1.f;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) {
+            cX[e][j] = cY[e][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NGP; ++i) { cU[e][j][i] = 0.f; SA.VN[e][j][i] = SB.VN[e][j][i] = 1.f; SA.VF[e][j][i] = SB.VF[e][j][i] = 0.f; }
+        }
+    }
+
+#ifdef DN_3D_TILE
+    // In-plane node tile staged through LDS so that every node is loaded from memory once per workgroup: a thread
+    // loads only ITS row segment (E nodes, one vector load per field), applies the Dirichlet conditions, publishes it;
+    // the +1 node and the next row come from the neighbours.  The last thread column / row of the tile additionally
+    // load the column / row beyond the tile.  Row stride rs keeps 8-byte alignment of the E = 2 segments.
+    constexpr int NFLD = 1 + (HAS_NU ? 1 : 0) + (HAS_F ? 1 : 0);
+    __shared__ float ntile[NFLD][832];
+    const int rs = TX * E + 2;
+    struct OwnRow {
+        float u[NW], n[NW], f[NW], keep[NW];
+        uint32_t m[2][NW];     // raw Dirichlet masks (byte value or float bits) and value fields, applied at publish time
+        float fv[2][NW];
+    };
+    struct Plus1 { float u, n, f; uint32_t m[2]; float fv[2]; };
+    struct Pending { OwnRow own, nxt; Plus1 p0, p1; };     // loads of one node plane in flight (software prefetch)
+
+    auto row_off = [&](int z, int y) { return (unsigned)min(z, p.nz - 1) * npl + (unsigned)min(y, p.ny - 1) * (unsigned)p.nx; };
+    // issue the loads of this thread's E nodes of global row y (no use of the results: they stay in flight)
+    auto issue_row_nodes = [&](int z, int y, OwnRow& r) {
+        const unsigned rowoff = row_off(z, y);
+        load_own<NW, VEC>(sb.u, rowoff, x0, p.nx, r.u);
+        if constexpr (HAS_NU) load_own<NW, VEC>(sb.nu, rowoff, x0, p.nx, r.n);
+        if constexpr (HAS_F) load_own<NW, VEC>(sb.f, rowoff, x0, p.nx, r.f);
+        if constexpr (BC_ANY) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (sb.mask[k] != nullptr) {
+                    if (p.bc[k].mask_is_u8) {
+                        uint8_t t[NW];
+                        load_own<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, t);
+#pragma unroll
+                        for (int n = 0; n < NW; ++n) r.m[k][n] = t[n];
+                    } else {
+                        load_own<NW, VEC>(reinterpret_cast<const uint32_t*>(sb.mask[k]), rowoff, x0, p.nx, r.m[k]);
+                    }
+                    if (sb.field[k]) load_own<NW, VEC>(sb.field[k], rowoff, x0, p.nx, r.fv[k]);
+                }
+            }
+        }
+    };
+    auto issue_plus1 = [&](int z, int y, Plus1& q1) {
+        const unsigned o = row_off(z, y) + (unsigned)min(x0 + NW, p.nx - 1);
+        q1.u = sb.u[o];
+        if constexpr (HAS_NU) q1.n = sb.nu[o];
+        if constexpr (HAS_F) q1.f = sb.f[o];
+        if constexpr (BC_ANY) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (sb.mask[k] != nullptr) {
+                    q1.m[k] = p.bc[k].mask_is_u8 ? (uint32_t) reinterpret_cast<const uint8_t*>(sb.mask[k])[o]
+                                                 : reinterpret_cast<const uint32_t*>(sb.mask[k])[o];
+                    if (sb.field[k]) q1.fv[k] = sb.field[k][o];
+                }
+            }
+        }
+    };
+    auto issue_plane = [&](int z, Pending& pd) {
+        issue_row_nodes(z, ey, pd.own);
+        if (tx == TX - 1) issue_plus1(z, ey, pd.p0);
+        if (ty == TY - 1) {                      // the row beyond the tile
+            issue_row_nodes(z, ey + 1, pd.nxt);
+            if (tx == TX - 1) issue_plus1(z, ey + 1, pd.p1);
+        }
+    };
+    // u <- where(mask > 0.5, value, u) on one node; returns the keep factor
+    auto dirichlet1 = [&](float& u, const uint32_t (&m)[2], const float (&fv)[2]) {
+        float keep = 1.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (sb.mask[k] != nullptr) {
+                const bool set = p.bc[k].mask_is_u8 ? (m[k] != 0u) : (__uint_as_float(m[k]) > 0.5f);
+                u = set ? (sb.field[k] ? fv[k] : p.bc[k].value) : u;
+                keep = set ? 0.f : keep;
+            }
+        }
+        return keep;
+    };
+    auto apply_bc_row = [&](OwnRow& r) {
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            if constexpr (BC_ANY) {
+                const uint32_t mm[2] = {r.m[0][n], r.m[1][n]};
+                const float ff[2] = {r.fv[0][n], r.fv[1][n]};
+                r.keep[n] = dirichlet1(r.u[n], mm, ff);
+            } else {
+                r.keep[n] = 1.f;
+            }
+        }
+    };
+    auto publish = [&](int lrow, int lcol, const OwnRow& r) {
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            ntile[0][lrow * rs + lcol + n] = r.u[n];
+            if constexpr (HAS_NU) ntile[1][lrow * rs + lcol + n] = r.n[n];
+            if constexpr (HAS_F) ntile[HAS_NU ? 2 : 1][lrow * rs + lcol + n] = r.f[n];
+        }
+    };
+    auto publish_plus1 = [&](int lrow, Plus1& q1) {
+        if constexpr (BC_ANY) (void)dirichlet1(q1.u, q1.m, q1.fv);
+        ntile[0][lrow * rs + TX * E] = q1.u;
+        if constexpr (HAS_NU) ntile[1][lrow * rs + TX * E] = q1.n;
+        if constexpr (HAS_F) ntile[HAS_NU ? 2 : 1][lrow * rs + TX * E] = q1.f;
+    };
+
+    // Dirichlet + publish the landed plane, then read rows ey, ey+1 of the tile and do the in-plane x- and y-stage
+    auto plane_stage = [&](Pending& pd, PlaneState3D<NGP, E>& S) {
+        float ru[2][NW + 1], rn[2][NW + 1], rf[2][NW + 1];
+        OwnRow& own = pd.own;
+        apply_bc_row(own);
+#pragma unroll
+        for (int n = 0; n < NW; ++n) S.keep[n] = own.keep[n];
+        publish(ty, tx * E, own);
+        if (tx == TX - 1) publish_plus1(ty, pd.p0);
+        if (ty == TY - 1) {
+            apply_bc_row(pd.nxt);
+            publish(TY, tx * E, pd.nxt);
+            if (tx == TX - 1) publish_plus1(TY, pd.p1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) {
+                const int li = (ty + jb) * rs + tx * E + n;
+                ru[jb][n] = (jb == 0 && n < NW) ? own.u[n] : ntile[0][li];
+                if constexpr (HAS_NU) rn[jb][n] = (jb == 0 && n < NW) ? own.n[n] : ntile[1][li];
+                if constexpr (HAS_F) rf[jb][n] = (jb == 0 && n < NW) ? own.f[n] : ntile[HAS_NU ? 2 : 1][li];
+            }
+        }
+#else
+    // Direct form (default): every thread loads its two node rows itself (row ey+1 is also loaded by the next thread row;
+    // the duplicate is served by L1/L2).  Measured 8-15 % faster than the LDS-tile form above at 128^3 / 256^3
+    // (profiles/README.md): the tile adds a second barrier per plane and the kernel is not load-instruction bound.
+    struct Pending { int z; };
+    auto issue_plane = [&](int z, Pending& pd) { pd.z = z; };
+    auto plane_stage = [&](Pending& pd, PlaneState3D<NGP, E>& S) {
+        const int z = min(pd.z, p.nz - 1);
+        float ru[2][NW + 1], rn[2][NW + 1], rf[2][NW + 1];
+        BcRaw<NW> braw[2];
+        unsigned rowoff[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int y = min(ey + jb, p.ny - 1);       // clamped: rows beyond the domain only feed skipped elements
+            rowoff[jb] = (unsigned)z * npl + (unsigned)y * (unsigned)p.nx;
+            load_seg<NW, VEC>(sb.u, rowoff[jb], x0, p.nx, ru[jb]);
+            if constexpr (HAS_NU) load_seg<NW, VEC>(sb.nu, rowoff[jb], x0, p.nx, rn[jb]);
+            if constexpr (HAS_F) load_seg<NW, VEC>(sb.f, rowoff[jb], x0, p.nx, rf[jb]);
+            if constexpr (BC_ANY) bc_issue<NW, VEC>(p, sb, rowoff[jb], x0, braw[jb]);
+        }
+        if constexpr (BC_ANY) {
+            float k1[NW];
+            bc_apply<NW>(p, sb, braw[0], ru[0], S.keep);
+            bc_apply<NW>(p, sb, braw[1], ru[1], k1);
+        }
+#endif
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float dx0 = ru[0][e + 1] - ru[0][e], dx1 = ru[1][e + 1] - ru[1][e];
+#pragma unroll
+            for (int i = 0; i < NGP; ++i) {
+                const float t0 = fmaf(p.T.b[i][1], dx0, ru[0][e]);
+                S.VY[e][i] = fmaf(p.T.b[i][1], dx1, ru[1][e]) - t0;
+#pragma unroll
+                for (int j = 0; j < NGP; ++j) S.VU[e][j][i] = fmaf(p.T.b[j][1], S.VY[e][i], t0);
+            }
+#pragma unroll
+            for (int j = 0; j < NGP; ++j) S.VX[e][j] = fmaf(p.T.b[j][1], dx1 - dx0, dx0);
+            if constexpr (HAS_NU) {
+                const float d0 = rn[0][e + 1] - rn[0][e], d1 = rn[1][e + 1] - rn[1][e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) {
+                    const float t0 = fmaf(p.T.b[i][1], d0, rn[0][e]);
+                    const float dy = fmaf(p.T.b[i][1], d1, rn[1][e]) - t0;
+#pragma unroll
+                    for (int j = 0; j < NGP; ++j) S.VN[e][j][i] = fmaf(p.T.b[j][1], dy, t0);
+                }
+            }
+            if constexpr (HAS_F) {
+                const float d0 = rf[0][e + 1] - rf[0][e], d1 = rf[1][e + 1] - rf[1][e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) {
+                    const float t0 = fmaf(p.T.b[i][1], d0, rf[0][e]);
+                    const float dy = fmaf(p.T.b[i][1], d1, rf[1][e]) - t0;
+#pragma unroll
+                    for (int j = 0; j < NGP; ++j) S.VF[e][j][i] = fmaf(p.T.b[j][1], dy, t0);
+                }
+            }
+        }
+    };
+
+    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
+    int par = 0;
+
+    // in-plane transpose (y then x) of the cotangents of one plane's stage values -> contributions to the 2 x (E+1) nodes
+    auto plane_transpose = [&](int e, const float (&tU)[NGP][NGP], const float (&tX)[NGP], const float (&tY)[NGP], float (&o)[2][NW + 1]) {
+        float s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) {
+            float s = 0.f, t = 0.f;
+#pragma unroll
+            for (int j = 0; j < NGP; ++j) { s += tU[j][i]; t = fmaf(p.T.b[j][1], tU[j][i], t); }
+            const float c1 = t + tY[i], c0 = s - c1;            // cot of the x-lerped rows tv1[i], tv0[i]
+            s0 += c0; t0 = fmaf(p.T.b[i][1], c0, t0);
+            s1 += c1; t1 = fmaf(p.T.b[i][1], c1, t1);
+        }
+        float sX = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) { sX += tX[j]; d1 = fmaf(p.T.b[j][1], tX[j], d1); }
+        const float g01 = t0 + (sX - d1), g11 = t1 + d1;
+        o[0][e + 1] += g01; o[0][e] += s0 - g01;
+        o[1][e + 1] += g11; o[1][e] += s1 - g11;
+    };
+
+    // Emit node plane z, row ey, nodes x0..x0+E-1 from o (+ the neighbours' hand-overs).
+    auto emit_plane = [&](const float (&o)[2][NW + 1], const float (&keep)[NW], int z, bool owned_plane) {
+        xch[par][0][tid] = o[0][NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) xch[par][1 + n][tid] = o[1][n];
+        xch[par][NW + 1][tid] = o[1][NW];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (owned_plane && owner && noderow_ok) {
+            float v[NW];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                float t = o[0][n];
+                if (ty > 0) t += xch[par][1 + n][tid - TX];
+                if (n == 0) {
+                    if (tx > 0) t += xch[par][0][tid - 1];
+                    if (tx > 0 && ty > 0) t += xch[par][NW + 1][tid - TX - 1];
+                }
+                t *= keep[n];
+                sq_acc = fmaf(t, t, sq_acc);
+                v[n] = t * p.out_scale;
+            }
+            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)z * npl + (unsigned)ey * (unsigned)p.nx, x0, p.nx, v);
+        }
+        par ^= 1;
+    };
+
+    auto layer = [&](int ez, const PlaneState3D<NGP, E>& L, const PlaneState3D<NGP, E>& U) {
+        const bool own_layer = ez >= ez_own;
+        const float cnt = (own_layer && owner) ? 1.f : 0.f;
+        float o[2][NW + 1], le1 = 0.f, le2 = 0.f;
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) o[0][n] = o[1][n] = 0.f;
+        if (row_ok) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (ex0 + e < p.nelx) {       // also a scheduling fence between the element streams (see the 2-D kernel)
+                    float fg[G];
+                    if constexpr (FGP) {
+                        const unsigned eo = (unsigned)ez * epl + (unsigned)ey * (unsigned)p.nelx + (unsigned)(ex0 + e);
+#pragma unroll
+                        for (int gi = 0; gi < G; ++gi) fg[gi] = fgp[eo + (unsigned)gi * eps];
+                    }
+                    float lU[NGP][NGP], uU[NGP][NGP], lX[NGP], uX[NGP], lY[NGP], uY[NGP], e1, e2;
+#ifndef DN_ABLATE_COMPUTE
+                    q1_layer_3d<NGP, FGP>(p.T, L.VU[e], U.VU[e], L.VX[e], U.VX[e], L.VY[e], U.VY[e], L.VN[e], U.VN[e], L.VF[e], U.VF[e],
+                                          fg, lU, uU, lX, uX, lY, uY, e1, e2);
+#else                                      // timing experiment only
+#pragma unroll
+                    for (int j = 0; j < NGP; ++j) {
+                        lX[j] = L.VX[e][j]; uX[j] = U.VX[e][j]; lY[j] = L.VY[e][j]; uY[j] = U.VY[e][j];
+#pragma unroll
+                        for (int i = 0; i < NGP; ++i) { lU[j][i] = L.VU[e][j][i] + U.VN[e][j][i]; uU[j][i] = U.VU[e][j][i] + U.VF[e][j][i]; }
+                    }
+                    e1 = lX[0]; e2 = uX[0];
+#endif
+                    le1 += e1;
+                    le2 += e2;
+#pragma unroll
+                    for (int j = 0; j < NGP; ++j) {
+                        lX[j] += cX[e][j]; lY[j] += cY[e][j];
+                        cX[e][j] = uX[j]; cY[e][j] = uY[j];
+#pragma unroll
+                        for (int i = 0; i < NGP; ++i) { lU[j][i] += cU[e][j][i]; cU[e][j][i] = uU[j][i]; }
+                    }
+                    plane_transpose(e, lU, lX, lY, o);
+                }
+            }
+        }
+        e1_acc = fmaf(cnt, le1, e1_acc);
+        e2_acc = fmaf(cnt, le2, e2_acc);
+        emit_plane(o, L.keep, ez, own_layer);
+    };
+
+    Pending pd;
+    issue_plane(ez_begin, pd);
+    plane_stage(pd, SA);
+    issue_plane(ez_begin + 1, pd);         // in flight; consumed at the top of the first iteration
+#ifdef DN_3D_TILE
+    __syncthreads();                       // every thread has read the first tile before it is overwritten
+#endif
+    for (int ez = ez_begin; ez < ez_end; ++ez) {
+        plane_stage(pd, SB);               // plane ez+1 (loads issued one layer ago)
+#ifndef DN_NO_PREFETCH3D
+        issue_plane(ez + 2, pd);           // prefetch: lands while this layer is computed (the emit barrier is LDS-only)
+#endif
+        layer(ez, SA, SB);
+        SA = SB;
+#ifdef DN_NO_PREFETCH3D
+        issue_plane(ez + 2, pd);
+#endif
+    }
+    if (ez_end == p.nelz) {       // the last strip owns the top boundary plane: only the layer below contributes
+        float o[2][NW + 1];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) o[0][n] = o[1][n] = 0.f;
+        if (row_ok) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (ex0 + e < p.nelx) plane_transpose(e, cU[e], cX[e], cY[e], o);
+        }
+        emit_plane(o, SA.keep, p.nz - 1, true);
+    }
+
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, TX * TY, red, &last_flag);
+}
+
+// ---- dispatch ---------------------------------------------------------------------------------------------
+template <int NGP, int E, bool VEC, int FL>
+static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
+    hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL>), dim3(g.chunks * g.tiles, g.strips, batch), dim3(g.TX, g.TY), 0, s, pp,
+                       g.chunks);
+}
+
+template <int NGP, int E, bool VEC>
+static void launch3_flags(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
+    const int f = pp.fgp ? 2 : (pp.f ? 1 : 0);
+    const bool bc = pp.bc[0].mask || pp.bc[1].mask;
+#define DN_L3(FLAGS) (bc ? launch3_one<NGP, E, VEC, (FLAGS) | FL3_BC>(pp, g, batch, s) : launch3_one<NGP, E, VEC, (FLAGS)>(pp, g, batch, s))
+    if (pp.nu) {
+        if (f == 0) DN_L3(FL3_NU);
+        else if (f == 1) DN_L3(FL3_NU | FL3_F);
+        else DN_L3(FL3_NU | FL3_FGP);
+    } else {
+        if (f == 0) DN_L3(0);
+        else if (f == 1) DN_L3(FL3_F);
+        else DN_L3(FL3_FGP);
+    }
+#undef DN_L3
+}
+
+#define DN_CAT2(a, b) a##b
+#define DN_CAT(a, b) DN_CAT2(a, b)
+int DN_CAT(launch_poisson3d_q1_g, DN_NGP)(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s) {
+#if DN_NGP == 2
+    if (g.E == 2 && vec) { launch3_flags<DN_NGP, 2, true>(pp, g, batch, s); return 0; }
+    if (g.E == 2) { launch3_flags<DN_NGP, 2, false>(pp, g, batch, s); return 0; }
+#endif
+    if (g.E == 1) { launch3_flags<DN_NGP, 1, false>(pp, g, batch, s); return 0; }
+    return DN_E_UNSUPPORTED;
+}
+
+}  // namespace dn

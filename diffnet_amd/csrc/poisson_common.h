@@ -209,6 +209,45 @@ __device__ __forceinline__ void bc_apply(const PoissonParams& p, const SampleBas
 }
 
 
+// Dirichlet conditions on exactly N nodes starting at x0 of one row (loads issued first, then selects).
+// u <- where(mask > 0.5, value, u) for both conditions in order; keep[n] = 0 on Dirichlet nodes, 1 elsewhere.
+template <int N, bool VEC>
+__device__ __forceinline__ void bc_nodes(const PoissonParams& p, const SampleBases& sb, unsigned rowoff, int x0, float (&u)[N],
+                                         float (&keep)[N]) {
+    uint32_t m[2][N];
+    float fv[2][N];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (sb.mask[k] != nullptr) {
+            if (p.bc[k].mask_is_u8) {
+                uint8_t t[N];
+                load_own<N, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, t);
+#pragma unroll
+                for (int n = 0; n < N; ++n) m[k][n] = t[n];
+            } else {
+                load_own<N, VEC>(reinterpret_cast<const uint32_t*>(sb.mask[k]), rowoff, x0, p.nx, m[k]);
+            }
+            if (sb.field[k]) load_own<N, VEC>(sb.field[k], rowoff, x0, p.nx, fv[k]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) keep[n] = 1.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (sb.mask[k] != nullptr) {
+            const bool u8 = p.bc[k].mask_is_u8 != 0;
+            const bool hasf = sb.field[k] != nullptr;
+            const float val = p.bc[k].value;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const bool set = u8 ? (m[k][n] != 0u) : (__uint_as_float(m[k][n]) > 0.5f);
+                u[n] = set ? (hasf ? fv[k][n] : val) : u[n];
+                keep[n] = set ? 0.f : keep[n];
+            }
+        }
+    }
+}
+
 struct Geom2D { int T, E, chunks, strips, R; };
 struct Geom3D { int TX, TY, E, chunks, tiles, strips, R; };
 
@@ -216,5 +255,9 @@ struct Geom3D { int TX, TY, E, chunks, tiles, strips, R; };
 int launch_poisson2d_q1_g2(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
 int launch_poisson2d_q1_g3(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
 int launch_poisson2d_q1_g4(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
+// 3-D Q1 marching kernels likewise (poisson3d_q1_g{2,3,4}.hip)
+int launch_poisson3d_q1_g2(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);
+int launch_poisson3d_q1_g3(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);
+int launch_poisson3d_q1_g4(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);
 
 }  // namespace dn

@@ -400,4 +400,98 @@ __device__ __forceinline__ void q1_layer_2d(const ElemTab& T, const float (&TU0)
     e2 = a2;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3-D Q1, marching form.  One element between node planes k (L) and k+1 (U), given each plane's in-plane stage at
+// the element's in-plane Gauss points m = (jg, ig):
+//   VU[jg][ig] value of u, VX[jg] = lerp_y of the x-differences, VY[ig] = y-difference of the x-lerped rows,
+//   VN / VF values of nu / f.
+// As in 2-D every sum over the z-Gauss points collapses onto the moments m[0..2] of the 1-D rule, and the sums over
+// one in-plane index onto the small vectors A0/A1 (per jg) and B0/B1 (per ig): O(NGP^2) work per element.
+// Outputs: cotangents of both planes' stage values (…L / …U) and the two energy parts.
+// ---------------------------------------------------------------------------------------------
+template <int NGP, bool FGP>
+__device__ __forceinline__ void q1_layer_3d(const ElemTab& T, const float (&LU)[NGP][NGP], const float (&UU)[NGP][NGP],
+                                            const float (&LX)[NGP], const float (&UX)[NGP], const float (&LY)[NGP],
+                                            const float (&UY)[NGP], const float (&LN)[NGP][NGP], const float (&UN)[NGP][NGP],
+                                            const float (&LF)[NGP][NGP], const float (&UF)[NGP][NGP], const float* fg,
+                                            float (&cUL)[NGP][NGP], float (&cUU)[NGP][NGP], float (&cXL)[NGP], float (&cXU)[NGP],
+                                            float (&cYL)[NGP], float (&cYU)[NGP], float& e1, float& e2) {
+    float a1 = 0.f, a2 = 0.f;
+    float A0[NGP], A1[NGP], B0[NGP], B1[NGP];
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) A0[i] = A1[i] = B0[i] = B1[i] = 0.f;
+    const float nb = -T.beta;
+#pragma unroll
+    for (int jg = 0; jg < NGP; ++jg) {
+#pragma unroll
+        for (int ig = 0; ig < NGP; ++ig) {
+            const float w2 = T.w2[jg][ig];
+            const float dzu = UU[jg][ig] - LU[jg][ig];
+            const float uz = T.hs[2] * dzu;
+            const float dzn = UN[jg][ig] - LN[jg][ig];
+            const float wn0 = w2 * LN[jg][ig], wn1 = w2 * dzn;
+            A0[jg] += wn0; A1[jg] += wn1; B0[ig] += wn0; B1[ig] += wn1;
+            const float Qz = fmaf(T.m[1], wn1, T.m[0] * wn0);
+            const float qzu = Qz * uz;
+            a1 = fmaf(qzu, uz, a1);
+            const float cz = T.ahs[2] * qzu;
+            float cs, c1;
+            if constexpr (FGP) {
+                cs = 0.f; c1 = 0.f;
+#pragma unroll
+                for (int kg = 0; kg < NGP; ++kg) {
+                    const float wf = T.w[kg] * w2 * fg[(kg * NGP + jg) * NGP + ig];
+                    cs += wf;
+                    c1 = fmaf(T.b[kg][1], wf, c1);
+                }
+            } else {
+                const float dzf = UF[jg][ig] - LF[jg][ig];
+                const float wf0 = w2 * LF[jg][ig], wf1 = w2 * dzf;
+                cs = fmaf(T.m[1], wf1, T.m[0] * wf0);
+                c1 = fmaf(T.m[2], wf1, T.m[1] * wf0);
+            }
+            a2 = fmaf(cs, LU[jg][ig], a2);
+            a2 = fmaf(c1, dzu, a2);
+            cUU[jg][ig] = fmaf(nb, c1, cz);
+            cUL[jg][ig] = fmaf(nb, cs, -cUU[jg][ig]);
+        }
+    }
+#pragma unroll
+    for (int jg = 0; jg < NGP; ++jg) {
+        const float dv = UX[jg] - LX[jg];
+        float sx = 0.f, tx = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < NGP; ++kg) {
+            const float ux = T.hs[0] * fmaf(T.b[kg][1], dv, LX[jg]);
+            const float Qx = T.w[kg] * fmaf(T.b[kg][1], A1[jg], A0[jg]);
+            const float qxu = Qx * ux;
+            a1 = fmaf(qxu, ux, a1);
+            const float cx = T.ahs[0] * qxu;
+            sx += cx;
+            tx = fmaf(T.b[kg][1], cx, tx);
+        }
+        cXU[jg] = tx;
+        cXL[jg] = sx - tx;
+    }
+#pragma unroll
+    for (int ig = 0; ig < NGP; ++ig) {
+        const float dv = UY[ig] - LY[ig];
+        float sy = 0.f, ty = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < NGP; ++kg) {
+            const float uy = T.hs[1] * fmaf(T.b[kg][1], dv, LY[ig]);
+            const float Qy = T.w[kg] * fmaf(T.b[kg][1], B1[ig], B0[ig]);
+            const float qyu = Qy * uy;
+            a1 = fmaf(qyu, uy, a1);
+            const float cy = T.ahs[1] * qyu;
+            sy += cy;
+            ty = fmaf(T.b[kg][1], cy, ty);
+        }
+        cYU[ig] = ty;
+        cYL[ig] = sy - ty;
+    }
+    e1 = a1;
+    e2 = a2;
+}
+
 }  // namespace dn

@@ -146,154 +146,9 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);
 }
 
-// =============================================================================================
-// 3-D Q1 kernel.  grid = (chunks_x * tiles_y, strips_z, B), block = (TX, TY).
-// =============================================================================================
-template <int NGP, int E, bool VEC, bool FGP>
-__global__ void __launch_bounds__(256) poisson3d_q1_kernel(const PoissonParams p, const int chunks_x) {
-    constexpr int NW = E;
-    constexpr int G = NGP * NGP * NGP;
-    const int TX = blockDim.x, TY = blockDim.y;
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int tid = ty * TX + tx;
-    const int chunk = blockIdx.x % chunks_x, tile = blockIdx.x / chunks_x, strip = blockIdx.y, b = blockIdx.z;
-    const int q = chunk * (TX - 1) + tx;
-    const int ex0 = q * E, x0 = ex0;
-    const int ey = tile * (TY - 1) + ty;          // element row == lower node row of this thread
-    const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);
-    const unsigned npl = (unsigned)(p.nx * p.ny);     // nodes per plane
-    const int64_t nps = (int64_t)npl * p.nz;
-    const unsigned epl = (unsigned)(p.nelx * p.nely);
-    const unsigned eps = epl * (unsigned)p.nelz;
-    const SampleBases sb = sample_bases(p, b, nps);
-    const float* fgp = FGP ? p.fgp + (p.f_batched ? (int64_t)b * eps * G : 0) : nullptr;
-    const int R = p.rows_per_strip;
-    const int ez_own = strip * R;
-    const int ez_begin = ez_own > 0 ? ez_own - 1 : 0;
-    const int ez_end = min(ez_own + R, p.nelz);
-    const bool any_bc = sb.mask[0] != nullptr || sb.mask[1] != nullptr;
-    const bool row_ok = ey < p.nely;              // thread has real elements
-    const bool noderow_ok = ey < p.ny;            // thread's lower node row exists
+}  // namespace dn
 
-    // hand-over slots: [parity][slot][thread]; slots: 0 = right (jb0,n=NW), 1..NW = up (jb1,n<NW), NW+1 = up-right
-    __shared__ float xch[2][NW + 2][256];
-    __shared__ double red[8];
-    __shared__ int last_flag;
-
-    float cu[2][2][NW + 1], cn[2][2][NW + 1], cf[2][2][NW + 1];   // [plane kb][row jb][n]
-    unsigned fixed[2];                                            // Dirichlet bits of (plane kb, row jb = 0)
-    float acc[2][2][NW + 1];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        fixed[kb] = 0u;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int n = 0; n <= NW; ++n) { acc[kb][jb][n] = 0.f; cn[kb][jb][n] = 1.f; cf[kb][jb][n] = 0.f; cu[kb][jb][n] = 0.f; }
-    }
-
-    auto load_plane = [&](int kb, int z) {
-        unsigned rowoff[2];
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-            const int y = min(ey + jb, p.ny - 1);       // clamped: rows beyond the domain only feed skipped elements
-            rowoff[jb] = (unsigned)z * npl + (unsigned)y * (unsigned)p.nx;
-            load_seg<NW, VEC>(sb.u, rowoff[jb], x0, p.nx, cu[kb][jb]);
-            if (sb.nu) load_seg<NW, VEC>(sb.nu, rowoff[jb], x0, p.nx, cn[kb][jb]);
-            if (sb.f) load_seg<NW, VEC>(sb.f, rowoff[jb], x0, p.nx, cf[kb][jb]);
-        }
-        if (any_bc) {
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {
-                const unsigned bits = load_apply_bc<NW, VEC>(p, sb, rowoff[jb], x0, cu[kb][jb]);
-                if (jb == 0) fixed[kb] = bits;
-            }
-        }
-    };
-
-    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
-    int par = 0;
-
-    // Emit node plane z, row ey (jb = 0), nodes x0..x0+NW-1 from acc[0].
-    auto emit_plane = [&](int z, bool owned_plane) {
-        xch[par][0][tid] = acc[0][0][NW];
-#pragma unroll
-        for (int n = 0; n < NW; ++n) xch[par][1 + n][tid] = acc[0][1][n];
-        xch[par][NW + 1][tid] = acc[0][1][NW];
-        __syncthreads();
-        if (owned_plane && owner && noderow_ok) {
-            float o[NW];
-#pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                float v = acc[0][0][n];
-                if (ty > 0) v += xch[par][1 + n][tid - TX];
-                if (n == 0) {
-                    if (tx > 0) v += xch[par][0][tid - 1];
-                    if (tx > 0 && ty > 0) v += xch[par][NW + 1][tid - TX - 1];
-                }
-                v = (fixed[0] & (1u << n)) ? 0.f : v;
-                sq_acc = (x0 + n < p.nx) ? fmaf(v, v, sq_acc) : sq_acc;
-                o[n] = v * p.out_scale;
-            }
-            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)z * npl + (unsigned)ey * (unsigned)p.nx, x0, p.nx, o);
-        }
-        par ^= 1;
-    };
-
-    load_plane(0, ez_begin);
-    for (int ez = ez_begin; ez < ez_end; ++ez) {
-        load_plane(1, ez + 1);
-        const bool own_layer = ez >= ez_own;
-        const bool count = own_layer && owner;
-        if (row_ok) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                if (ex0 + e < p.nelx) {
-                    float lu[2][2][2], ln[2][2][2], lf[2][2][2], g[2][2][2];
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                            for (int ib = 0; ib < 2; ++ib) {
-                                lu[kb][jb][ib] = cu[kb][jb][e + ib];
-                                ln[kb][jb][ib] = cn[kb][jb][e + ib];
-                                lf[kb][jb][ib] = cf[kb][jb][e + ib];
-                            }
-                    float fg[G];
-                    if constexpr (FGP) {
-                        const unsigned eo = (unsigned)ez * epl + (unsigned)ey * (unsigned)p.nelx + (unsigned)(ex0 + e);
-#pragma unroll
-                        for (int gi = 0; gi < G; ++gi) fg[gi] = fgp[eo + (unsigned)gi * eps];
-                    }
-                    float e1, e2;
-                    elem3d_q1<NGP, FGP>(p.T, lu, ln, lf, fg, g, e1, e2);
-                    e1_acc += count ? e1 : 0.f;
-                    e2_acc += count ? e2 : 0.f;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                            for (int ib = 0; ib < 2; ++ib) acc[kb][jb][e + ib] += g[kb][jb][ib];
-                }
-            }
-        }
-        emit_plane(ez, own_layer);
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int n = 0; n <= NW; ++n) {
-                cu[0][jb][n] = cu[1][jb][n]; cn[0][jb][n] = cn[1][jb][n]; cf[0][jb][n] = cf[1][jb][n];
-                acc[0][jb][n] = acc[1][jb][n];
-                acc[1][jb][n] = 0.f;
-            }
-        fixed[0] = fixed[1];
-    }
-    if (ez_end == p.nelz) emit_plane(p.nz - 1, true);
-
-    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, TX * TY, red, &last_flag);
-}
+namespace dn {
 
 // ---------------------------------------------------------------------------------------------
 // host side: launch geometry
@@ -343,22 +198,23 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
 static Geom3D plan3d(const dn_mesh* m) {
     Geom3D g;
     const int nx = m->nx, ny = m->ny, nelz = m->nz - 1;
+    const int maxE = m->ngp == 2 ? 2 : 1;              // register budget of the marching kernel: E = 2 only at 2x2x2 points
     double best = -1.0;
     g.TX = 16; g.TY = 16; g.E = 1; g.chunks = 1; g.tiles = 1;
-    for (int E = 1; E <= 4; E *= 2) {
+    for (int E = 1; E <= maxE; E *= 2) {
         const int Q = (nx - 1) / E + 1;
-        for (int TX = 8; TX <= 64; TX *= 2) {
+        for (int TX = 8; TX <= 128; TX *= 2) {
             const int TY = 256 / TX;
             const int chunks = chunks_for(Q, TX);
             const int tiles = chunks_for(ny, TY);
             const double util = ((double)Q / ((double)chunks * TX)) * ((double)ny / ((double)tiles * TY));
-            const double score = util + 0.01 * E;
+            const double score = util + 0.05 * E + 0.0005 * TX;      // prefer wide rows (coalescing) at equal utilisation
             if (score > best) { best = score; g.TX = TX; g.TY = TY; g.E = E; g.chunks = chunks; g.tiles = tiles; }
         }
     }
     const long long wg_per_strip = (long long)g.chunks * g.tiles * m->batch;
     int R = 32;
-    while (R > 4 && wg_per_strip * ceil_div(nelz, R) < 1024) R /= 2;
+    while (R > 4 && wg_per_strip * ceil_div(nelz, R) < 2048) R /= 2;
     if (R > nelz) R = nelz;
     g.R = R < 1 ? 1 : R;
     g.strips = ceil_div(nelz, g.R);
@@ -384,7 +240,7 @@ static Geom3D plan3d_env(const dn_mesh* m) {
     Geom3D g = plan3d(m);
     const char* e = getenv("DN_PLAN3D");
     int TX, TY, E, R;
-    if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY <= 256 && TX * TY >= 64 && (E == 1 || E == 2 || E == 4) && R >= 1) {
+    if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY <= 256 && TX * TY >= 64 && (E == 1 || (E == 2 && m->ngp == 2)) && R >= 1) {
         const int nelz = m->nz - 1;
         g.TX = TX; g.TY = TY; g.E = E; g.R = R > nelz ? nelz : R;
         g.chunks = chunks_for((m->nx - 1) / E + 1, TX);
@@ -453,30 +309,6 @@ static int launch2d(const PoissonParams& pp, const Geom2D& g, int P, int ngp, in
         case 24: return launch2d_e<2, 4>(pp, g, batch, vec, s);
         case 33: return launch2d_e<3, 3>(pp, g, batch, vec, s);
         case 34: return launch2d_e<3, 4>(pp, g, batch, vec, s);
-        default: return DN_E_UNSUPPORTED;
-    }
-}
-
-template <int NGP, int E>
-static void launch3d_vec(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s) {
-    dim3 grid(g.chunks * g.tiles, g.strips, batch), block(g.TX, g.TY);
-    const bool fgp = pp.fgp != nullptr;
-    constexpr bool CANVEC = (E == 2 || E == 4);
-    if (vec && CANVEC) {
-        if (fgp) hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, CANVEC, true>), grid, block, 0, s, pp, g.chunks);
-        else hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, CANVEC, false>), grid, block, 0, s, pp, g.chunks);
-    } else {
-        if (fgp) hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, false, true>), grid, block, 0, s, pp, g.chunks);
-        else hipLaunchKernelGGL((poisson3d_q1_kernel<NGP, E, false, false>), grid, block, 0, s, pp, g.chunks);
-    }
-}
-
-template <int NGP>
-static int launch3d_e(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s) {
-    switch (g.E) {
-        case 1: launch3d_vec<NGP, 1>(pp, g, batch, vec, s); return 0;
-        case 2: launch3d_vec<NGP, 2>(pp, g, batch, vec, s); return 0;
-        case 4: launch3d_vec<NGP, 4>(pp, g, batch, vec, s); return 0;
         default: return DN_E_UNSUPPORTED;
     }
 }
@@ -573,9 +405,9 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         const int NW = g.E;
         const bool vec = vec_ok(NW);
         switch (m->ngp) {
-            case 2: rc = launch3d_e<2>(pp, g, m->batch, vec, s); break;
-            case 3: rc = launch3d_e<3>(pp, g, m->batch, vec, s); break;
-            case 4: rc = launch3d_e<4>(pp, g, m->batch, vec, s); break;
+            case 2: rc = launch_poisson3d_q1_g2(pp, g, m->batch, vec, s); break;
+            case 3: rc = launch_poisson3d_q1_g3(pp, g, m->batch, vec, s); break;
+            case 4: rc = launch_poisson3d_q1_g4(pp, g, m->batch, vec, s); break;
             default: rc = DN_E_UNSUPPORTED;
         }
     }
