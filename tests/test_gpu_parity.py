@@ -475,3 +475,19 @@ def test_fsdt_q2_assembly_is_the_adjoint_of_evaluation():
     Rs = fsdt_residuals(m, *f3, bc)
     for R in Rs:
         assert torch.isfinite(R).all() and float((R * bc).abs().max()) == 0.0
+
+
+def test_end_to_end_energy_minimisation_converges_to_manufactured_solution():
+    """Field-as-parameter Poisson solve (the shape of e8_2d_poisson_mms.py) through the built-in fit loop: the fused loss
+    and the reference loss body on the drop-in operators reach the same discrete solution, which converges to
+    sin(pi x) sin(pi y) at the Q1 rate."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ex_poisson2d", os.path.join(os.path.dirname(GOLDEN), "..", "examples", "poisson_2d_energy.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    err33, hist = ex.run(size=33, epochs=40, verbose=False)
+    err65, _ = ex.run(size=65, epochs=60, verbose=False)
+    errd, histd = ex.run(size=33, epochs=40, dropin=True, verbose=False)
+    assert hist[-1] < hist[0] and err33 < 5e-3 and err65 < 1.5e-3
+    assert err65 < 0.4 * err33                      # ~h^2 convergence
+    assert abs(errd - err33) < 0.2 * err33 and abs(histd[-1] - hist[-1]) < 1e-5 * abs(hist[-1])
