@@ -332,3 +332,18 @@ class _ResidualLoss(torch.autograd.Function):
 
 def residual_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
     return _ResidualLoss.apply(u, geom, nu, f, f_gp, tuple(_norm_dirichlet(dirichlet)), float(jac))
+
+
+def compute_winding_nodes(points, normals, area, q):
+    """Drop-in for `compute_winding_nodes` of IBN/poisson-2d/parametric/IBN_2D.py:89-104 (same argument shapes:
+    points / normals (B,1,Npts,2), area (B,1,Npts,1) -- unused by the reference too --, q = stack((xx, yy)) (2,Ny,Nx));
+    returns (B,1,Nx,Ny).  One HIP launch instead of a Python loop over grid columns."""
+    pts = _require(points.reshape(points.size(0), -1, 2), "points")
+    nrm = _require(normals.reshape(normals.size(0), -1, 2), "normals")
+    nodes = _require(q if q.is_cuda else q.to(pts.device), "nodes", 3)
+    B, npts = pts.shape[0], pts.shape[1]
+    ny, nx = nodes.shape[1], nodes.shape[2]
+    out = torch.empty((B, 1, nx, ny), dtype=torch.float32, device=pts.device)
+    rc = _lib.lib().dn_winding_nodes(_p(pts), _p(nrm), _p(nodes), _p(out), B, npts, ny, nx, _stream(pts))
+    _lib.check(rc, "dn_winding_nodes")
+    return out

@@ -119,6 +119,12 @@ int dn_assemble(const float *r_split, float *out, int32_t batch, int32_t nsd, co
 int dn_assemble_bwd(const float *grad_out, float *grad_split, int32_t batch, int32_t nsd, const int32_t n[3],
                     int32_t nbf, int32_t stride, void *stream);
 
+/* Winding-number inside/outside field: compute_winding_nodes of IBN/poisson-2d/parametric/IBN_2D.py:89-104.
+ * points, normals: (B, Npts, 2); nodes: (2, Ny, Nx) node coordinates (xx, yy); out: (B, 1, Nx, Ny) in the reference's
+ * (Nx, Ny) order: out[b,0,ix,iy] = sum_p ((p - q).n_p) / (4 pi |p - q|_1)^3 with q = nodes[:, iy, ix]. */
+int dn_winding_nodes(const float *points, const float *normals, const float *nodes, float *out, int32_t batch,
+                     int32_t npts, int32_t ny, int32_t nx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,3 +349,14 @@ class Oracle:
             R = self.assemble_q1(torch.sum(tt * jxw, 2), torch.zeros_like(w))
             Rs.append(torch.where(bc >= 0.5, zero, R))
         return Rs
+
+
+def winding_nodes(points, normals, nodes):
+    """Vectorised restatement of compute_winding_nodes (IBN/poisson-2d/parametric/IBN_2D.py:89-104):
+    points/normals (B,Npts,2), nodes (2,Ny,Nx) -> (B,1,Nx,Ny); L1 distance in the denominator as in the reference."""
+    import math
+    q = nodes.permute(2, 1, 0)[None, :, :, None, :]                 # (1, Nx, Ny, 1, 2)
+    d = points[:, None, None, :, :] - q                             # (B, Nx, Ny, Npts, 2)
+    num = (d * normals[:, None, None, :, :]).sum(-1)
+    den = (4 * math.pi * d.abs().sum(-1)) ** 3
+    return (num / den).sum(-1)[:, None]

@@ -491,3 +491,27 @@ def test_end_to_end_energy_minimisation_converges_to_manufactured_solution():
     assert hist[-1] < hist[0] and err33 < 5e-3 and err65 < 1.5e-3
     assert err65 < 0.4 * err33                      # ~h^2 convergence
     assert abs(errd - err33) < 0.2 * err33 and abs(histd[-1] - hist[-1]) < 1e-5 * abs(hist[-1])
+
+
+@pytest.mark.parametrize("tag", ["n17_p40", "n33_p100"])
+def test_winding_number_vs_reference_golden(tag):
+    from diffnet_amd.ops import compute_winding_nodes
+    z = load(f"winding_{tag}.npz")
+    w = compute_winding_nodes(cu(z["points"]).unsqueeze(1), cu(z["normals"]).unsqueeze(1), cu(z["area"]).unsqueeze(1), cu(z["nodes"]))
+    assert tuple(w.shape) == z["winding"].shape
+    close(w, z["winding"], rtol=2e-4, arel=1e-5)
+
+
+def test_winding_number_vs_oracle_large():
+    from diffnet_amd.ops import compute_winding_nodes
+    from oracle.fem_oracle import winding_nodes
+    g = torch.Generator().manual_seed(3)
+    B, npts, ny, nx = 2, 700, 40, 70
+    th = torch.sort(torch.rand((B, npts), generator=g) * 6.283185, dim=1).values
+    pts = torch.stack([0.5 + 0.27 * torch.cos(th), 0.45 + 0.21 * torch.sin(th)], -1)
+    nrm = torch.stack([torch.cos(th), torch.sin(th)], -1)
+    xx, yy = torch.meshgrid(torch.linspace(0, 1, nx), torch.linspace(0, 1, ny), indexing="xy")
+    nodes = torch.stack((xx, yy), 0)
+    ref = winding_nodes(pts, nrm, nodes)
+    w = compute_winding_nodes(pts.to(dev()).unsqueeze(1), nrm.to(dev()).unsqueeze(1), None if False else torch.zeros(B, 1, npts, 1, device=dev()), nodes.to(dev()))
+    close(w, ref.numpy(), rtol=5e-4, arel=1e-5)

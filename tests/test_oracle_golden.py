@@ -224,3 +224,11 @@ def test_fsdt_plate(tag):
         refg = z[f"grad_norm{i + 1}"]
         for gq, rq in zip(gs, refg):
             np.testing.assert_allclose(gq.numpy(), rq, rtol=1e-4, atol=1e-4 * np.abs(refg).max())
+
+
+@pytest.mark.parametrize("tag", ["n17_p40", "n33_p100"])
+def test_winding_number_oracle(tag):
+    from oracle.fem_oracle import winding_nodes
+    z = load(f"winding_{tag}.npz")
+    w = winding_nodes(tt(z["points"]), tt(z["normals"]), tt(z["nodes"]))
+    np.testing.assert_allclose(w.numpy(), z["winding"], rtol=2e-4, atol=1e-5 * np.abs(z["winding"]).max())

@@ -465,5 +465,30 @@ def main():
                  f"torch {torch.__version__} (CPU path), numpy {np.__version__}\n")
 
 
+# --------------------------------------------------------------------------------------
+# 4. "next" rows: winding-number inside/outside field of IBN_2D.py:89-104
+# --------------------------------------------------------------------------------------
+def gen_winding(outdir):
+    ibn2d = sys.modules.get("ref_ibn2d") or load_script("IBN/poisson-2d/parametric/IBN_2D.py", "ref_ibn2d")
+    from DiffNet.DiffNetFEM import DiffNet2DFEM
+    for tag, n, npts, B in [("n17_p40", 17, 40, 2), ("n33_p100", 33, 100, 1)]:
+        g = rng(37)
+        m = DiffNet2DFEM(None, domain_size=n)
+        th = torch.sort(torch.rand((B, npts), generator=g) * 2 * math.pi, dim=1).values
+        r = 0.2 + 0.1 * torch.rand((B, 1), generator=g)
+        pts = torch.stack([0.5 + r * torch.cos(th), 0.5 + r * torch.sin(th)], -1)          # (B, npts, 2) closed curve
+        nrm = torch.stack([torch.cos(th), torch.sin(th)], -1)
+        area = torch.rand((B, npts, 1), generator=g)
+        nodes = torch.stack((m.xx, m.yy), 0)
+        w = ibn2d.compute_winding_nodes(pts.unsqueeze(1), nrm.unsqueeze(1), area.unsqueeze(1), nodes)
+        np.savez_compressed(os.path.join(outdir, f"winding_{tag}.npz"), n=n, points=T(pts), normals=T(nrm), area=T(area),
+                            nodes=T(nodes), winding=T(w))
+        print("winding", tag, tuple(w.shape), float(w.abs().max()))
+
+
 if __name__ == "__main__":
-    main()
+    if "--winding" in sys.argv:
+        install_shims()
+        gen_winding(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))
+    else:
+        main()
