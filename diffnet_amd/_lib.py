@@ -52,6 +52,10 @@ SYMBOLS = {
                               C.c_void_p]),
     "dn_assemble_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32, C.c_int32,
                                   C.c_void_p]),
+    "dn_fdm_stencil_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32,
+                                     C.c_float, C.c_float, C.c_void_p]),
+    "dn_fdm_stencil_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32,
+                                     C.c_float, C.c_float, C.c_void_p]),
     "dn_winding_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p]),
 }

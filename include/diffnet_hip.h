@@ -125,6 +125,16 @@ int dn_assemble_bwd(const float *grad_out, float *grad_split, int32_t batch, int
 int dn_winding_nodes(const float *points, const float *normals, const float *nodes, float *out, int32_t batch,
                      int32_t npts, int32_t ny, int32_t nx, void *stream);
 
+/* DiffNetFDM stencil derivatives (DiffNet/DiffNetFDM.py:158-199): out = Corr( conv2d(g_padded, kernel9) ) with
+ * g_padded (B,1,ny+2,nx+2) replicate-padded by the caller as in the reference, out (B,1,ny,nx), kernel9 a HOST pointer to
+ * the 3x3 correlation kernel (row-major), and the reference's dense correction matmul (:63-119) reduced to what it does:
+ * along `axis` (0 = x: columns, 1 = y: rows) the two boundary lines become a*d[edge] + b*d[edge+-1].
+ * dn_fdm_stencil_bwd is the adjoint (gradient wrt g_padded). */
+int dn_fdm_stencil_fwd(const float *g_padded, float *out, int32_t batch, int32_t ny, int32_t nx, const float *kernel9,
+                       int32_t axis, float a, float b, void *stream);
+int dn_fdm_stencil_bwd(const float *grad_out, float *grad_g_padded, int32_t batch, int32_t ny, int32_t nx,
+                       const float *kernel9, int32_t axis, float a, float b, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

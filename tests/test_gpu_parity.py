@@ -515,3 +515,17 @@ def test_winding_number_vs_oracle_large():
     ref = winding_nodes(pts, nrm, nodes)
     w = compute_winding_nodes(pts.to(dev()).unsqueeze(1), nrm.to(dev()).unsqueeze(1), None if False else torch.zeros(B, 1, npts, 1, device=dev()), nodes.to(dev()))
     close(w, ref.numpy(), rtol=5e-4, arel=1e-5)
+
+
+@pytest.mark.parametrize("n", [16, 33])
+def test_fdm_derivatives_vs_reference_golden(n):
+    from DiffNet.DiffNetFDM import DiffNetFDM
+    z = load(f"fdm_n{n}.npz")
+    m = DiffNetFDM(None, domain_size=n).to(dev())
+    u = cu(z["u"])
+    for name, pad in (("x", m.pad), ("y", m.pad), ("xx", m.pad_d2), ("yy", m.pad_d2)):
+        ur = u.clone().requires_grad_(True)
+        d = getattr(m, "derivative_" + name)(pad(ur))
+        close(d, z["d_" + name], rtol=1e-5, arel=2e-6, msg=name)
+        (g,) = torch.autograd.grad(d, ur, cu(z["cot_" + name]))
+        close(g, z["vjp_" + name], rtol=1e-5, arel=2e-6, msg="vjp " + name)

@@ -129,3 +129,16 @@ def test_reference_import_paths():
     assert issubclass(DiffNet2DFEM, DiffNetFEM) and issubclass(DiffNetFEM, PDE)
     x, y, zz = CuboidMesh.meshgrid_3d(np.arange(4.0), np.arange(3.0), np.arange(2.0))
     assert x.shape == (2, 3, 4) and x[1, 2, 3] == 3 and y[1, 2, 3] == 2 and zz[1, 2, 3] == 1
+
+
+@pytest.mark.parametrize("n", [16, 33])
+def test_fdm_module_surface_matches_reference(n):
+    from DiffNet.DiffNetFDM import DiffNetFDM
+    z = np.load(os.path.join(GOLDEN, f"fdm_n{n}.npz"))
+    m = DiffNetFDM(None, domain_size=n)
+    assert sorted(m.state_dict().keys()) == list(z["keys"])
+    for k in ("sobelx", "sobely", "sobelxx", "sobelyy", "h_corr", "v_corr", "h_corr_d2", "v_corr_d2"):
+        assert np.array_equal(getattr(m, k).numpy(), z["par_" + k]), k
+    assert isinstance(m.pad, torch.nn.ReplicationPad2d) and m.nsd == 2 and m.stencil_len == 3
+    with pytest.raises(AttributeError):
+        m.calc_laplacian(None)

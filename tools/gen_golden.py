@@ -487,8 +487,37 @@ def gen_winding(outdir):
 
 
 if __name__ == "__main__":
-    if "--winding" in sys.argv:
+    if "--fdm" in sys.argv:
+        pass
+    elif "--winding" in sys.argv:
         install_shims()
         gen_winding(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))
     else:
         main()
+
+
+def gen_fdm(outdir):
+    import contextlib
+    import io
+    from DiffNet.DiffNetFDM import DiffNetFDM
+    for n, B in [(16, 2), (33, 1)]:
+        with contextlib.redirect_stdout(io.StringIO()):        # the reference prints its correction matrices
+            m = DiffNetFDM(None, domain_size=n)
+        g = rng(41)
+        u = torch.rand((B, 1, n, n), generator=g)
+        out = {"u": T(u), "keys": np.array(sorted(m.state_dict().keys()))}
+        for name, pad in (("x", m.pad), ("y", m.pad), ("xx", m.pad_d2), ("yy", m.pad_d2)):
+            ur = u.clone().requires_grad_(True)
+            d = getattr(m, "derivative_" + name)(pad(ur))
+            cot = torch.rand(d.shape, generator=g)
+            (gu,) = torch.autograd.grad(d, ur, cot)
+            out["d_" + name], out["cot_" + name], out["vjp_" + name] = T(d), T(cot), T(gu)
+        for k in ("sobelx", "sobely", "sobelxx", "sobelyy", "h_corr", "v_corr", "h_corr_d2", "v_corr_d2"):
+            out["par_" + k] = T(getattr(m, k))
+        np.savez_compressed(os.path.join(outdir, f"fdm_n{n}.npz"), **out)
+        print("fdm", n, float(np.abs(out["d_xx"]).max()))
+
+
+if __name__ == "__main__" and "--fdm" in sys.argv:
+    install_shims()
+    gen_fdm(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))
