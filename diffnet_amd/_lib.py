@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdiffnet_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE"}
 
@@ -33,7 +33,8 @@ class DnPoissonArgs(C.Structure):
                 ("alpha", C.c_float), ("beta", C.c_float), ("c", C.c_float), ("wscale", C.c_float),
                 ("out_scale", C.c_float),
                 ("out", C.c_void_p), ("energy", C.c_void_p), ("sumsq", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("energy_f32", C.c_void_p), ("energy_scale", C.c_double)]
 
 
 I32x3 = C.c_int32 * 3

@@ -37,6 +37,9 @@ struct RowRaw2D {
 #ifndef DN_Q1_2D_WAVES
 #define DN_Q1_2D_WAVES 2
 #endif
+#ifndef DN_PRIO_ROT
+#define DN_PRIO_ROT 3      // 0 = off (A/B switch); measured -7 % kernel time at the bench shape
+#endif
 
 template <int NGP, int E, bool VEC, int FL>
 __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const PoissonParams p) {
@@ -230,6 +233,23 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
     }
 #else
     for (; ey < ey_end; ++ey) {
+#if DN_PRIO_ROT
+        // rotate the wave priority with its progress: equal-priority waves are served oldest-first, so the four waves of
+        // a SIMD finish one after the other and the tail runs at low occupancy; a progress-dependent priority makes
+        // them advance at the same rate
+#if DN_PRIO_ROT == 2
+        switch ((ey - ey_begin) & 3) {
+#elif DN_PRIO_ROT == 3
+        switch (((ey_end - ey) >> 1) & 3) {
+#else
+        switch ((ey_end - ey) & 3) {          // s_setprio takes an immediate
+#endif
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
 #ifndef DN_ABLATE_MEM                      // timing experiment only: reuse the first row's data
         row_issue(ey + 1, raw);
 #endif

@@ -24,6 +24,9 @@ struct PlaneState3D {
 #ifndef DN_Q1_3D_WAVES
 #define DN_Q1_3D_WAVES 2
 #endif
+#ifndef DN_PRIO_ROT3D
+#define DN_PRIO_ROT3D 0
+#endif
 
 template <int NGP, int E, bool VEC, int FL>
 __global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(const PoissonParams p, const int chunks_x) {
@@ -363,6 +366,14 @@ __global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(cons
     __syncthreads();                       // every thread has read the first tile before it is overwritten
 #endif
     for (int ez = ez_begin; ez < ez_end; ++ez) {
+#if DN_PRIO_ROT3D
+        switch ((ez_end - ez) & 3) {       // progress-dependent wave priority (see the 2-D kernel)
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
         plane_stage(pd, SB);               // plane ez+1 (loads issued one layer ago)
 #ifndef DN_NO_PREFETCH3D
         issue_plane(ez + 2, pd);           // prefetch: lands while this layer is computed (the emit barrier is LDS-only)

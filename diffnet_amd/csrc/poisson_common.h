@@ -28,6 +28,8 @@ struct PoissonParams {
     unsigned* counter;     // arrival counter of the in-kernel final reduction (self-resetting)
     double* energy;        // final scalars (may be null)
     double* sumsq;
+    float* energy_f32;     // optional (float)(energy * energy_scale)
+    double energy_scale;
     int nx, ny, nz;        // nodes
     int nelx, nely, nelz;  // elements
     int rows_per_strip;    // element layers per strip along the marched axis
@@ -155,6 +157,7 @@ __device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, fl
         if (tid == 0) {
             if (p.energy) *p.energy = e;
             if (p.sumsq) *p.sumsq = s;
+            if (p.energy_f32) *p.energy_f32 = (float)(e * p.energy_scale);
             __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

@@ -328,11 +328,11 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     if (rc) return rc;
     if (!a || !a->u) return DN_E_BADARG;
     if (a->f && a->f_gp) return DN_E_BADARG;
-    if (!a->out && !a->energy && !a->sumsq) return DN_E_BADARG;
+    if (!a->out && !a->energy && !a->sumsq && !a->energy_f32) return DN_E_BADARG;
     if (m->nsd == 3 && m->degree != 1) return DN_E_UNSUPPORTED;
     const int P = m->degree;
     if (m->ngp < (P == 1 ? 2 : 3)) return DN_E_UNSUPPORTED;
-    const bool want_red = a->energy || a->sumsq;
+    const bool want_red = a->energy || a->sumsq || a->energy_f32;
     auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
     // vector loads/stores of NW nodes are legal when every row segment start is NW-element aligned
     auto vec_ok = [&](int NW) {
@@ -388,6 +388,7 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.part_energy = a->workspace ? reinterpret_cast<double*>(reinterpret_cast<char*>(a->workspace) + DN_WS_HEADER) : nullptr;
     pp.part_sumsq = pp.part_energy ? pp.part_energy + nwg : nullptr;
     pp.energy = a->energy; pp.sumsq = a->sumsq;
+    pp.energy_f32 = a->energy_f32; pp.energy_scale = a->energy_scale;
     pp.nx = m->nx; pp.ny = m->ny; pp.nz = m->nsd == 3 ? m->nz : 1;
     pp.nelx = (m->nx - 1) / P; pp.nely = (m->ny - 1) / P; pp.nelz = m->nsd == 3 ? (m->nz - 1) / P : 1;
     pp.want_sums = want_red ? 1 : 0;

@@ -168,9 +168,10 @@ def _workspace(dev, nbytes):
 
 
 def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
-                  out_scale=1.0, want_out=True, want_sums=True):
+                  out_scale=1.0, want_out=True, want_sums=True, loss_scale=None):
     """One launch of dn_poisson_apply.  Returns (out | None, sums | None) where sums is a float64 device
-    tensor [energy, sum(out_unscaled^2)].  See include/diffnet_hip.h for the operator definition."""
+    tensor [energy, sum(out_unscaled^2)].  With `loss_scale` a third value is returned: the 0-dim float32 tensor
+    energy * loss_scale written by the same launch.  See include/diffnet_hip.h for the operator definition."""
     nsd = geom.nsd
     u = _require(u, "u", nsd + 2)
     B = u.shape[0]
@@ -249,8 +250,16 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
         args.energy = sums.data_ptr()
         args.sumsq = sums.data_ptr() + 8
         args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    loss32 = None
+    if loss_scale is not None:
+        if not want_sums:
+            raise ValueError("loss_scale needs want_sums=True")
+        loss32 = torch.empty((), dtype=torch.float32, device=u.device)
+        args.energy_f32, args.energy_scale = loss32.data_ptr(), float(loss_scale)
     rc = _lib.lib().dn_poisson_apply(C.byref(mesh), C.byref(args), _stream(u))
     _lib.check(rc, "dn_poisson_apply")
+    if loss_scale is not None:
+        return out, sums, loss32
     return out, sums
 
 
@@ -261,10 +270,10 @@ class _EnergyLoss(torch.autograd.Function):
     def forward(ctx, u, geom, nu, f, f_gp, dirichlet, c, jac):
         B = u.shape[0]
         scale = 1.0 / (B * geom.nelem_total)
-        grad, sums = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac,
-                                   out_scale=scale, want_out=True, want_sums=True)
+        grad, _, loss = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac,
+                                      out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
         ctx.save_for_backward(grad)
-        return (sums[0] * scale).to(torch.float32)
+        return loss
 
     @staticmethod
     def backward(ctx, gout):
@@ -282,9 +291,9 @@ def energy_loss_and_grad(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.
     form bench.py measures (16 algorithmic bytes per node: read u, nu, f; write grad)."""
     B = u.shape[0]
     scale = 1.0 / (B * geom.nelem_total)
-    grad, sums = poisson_apply(geom, u.detach(), nu, f, f_gp, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac,
-                               out_scale=scale, want_out=True, want_sums=True)
-    return (sums[0] * scale).to(torch.float32), grad
+    grad, _, loss = poisson_apply(geom, u.detach(), nu, f, f_gp, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac,
+                                  out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
+    return loss, grad
 
 
 class _Residual(torch.autograd.Function):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 1
+#define DN_ABI_VERSION 2
 
 #define DN_E_BADARG (-1)    /* null pointer / non-positive size / unsupported combination   */
 #define DN_E_UNSUPPORTED (-2) /* (nsd, degree, ngp) outside the compiled instantiations      */
@@ -90,6 +90,9 @@ typedef struct dn_poisson_args {
                               zero-filled ONCE before its first use; every call leaves it ready for the next
                               (self-resetting arrival counter). One workspace per concurrently used stream. */
     int64_t workspace_bytes;
+    float *energy_f32;     /* optional device scalar: (float)(energy * energy_scale), e.g. the mean loss, written by the
+                              same launch (saves the caller two elementwise kernels per evaluation); needs workspace  */
+    double energy_scale;
 } dn_poisson_args;
 
 int dn_abi_version(void);
