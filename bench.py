@@ -132,13 +132,10 @@ def main():
     c = 1.0
     units_per_step = B * m.geom.nelem_total * m.geom.ngp_total
     dirichlet = [(bc, 0.0)]
-    total_loss = torch.zeros((), device=dev)
-
     def step():
         loss, grad = m.energy_loss_and_grad(u, nu, f, dirichlet=dirichlet, c=c)
         if dist is not None:
             dist.all_reduce(loss)          # global mean of the loss: the path's only exchange step
-        total_loss.add_(loss)
         return loss, grad
 
     for _ in range(args.warmup):
@@ -158,8 +155,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
-    # dominant-kernel time: HIP events on the launch stream around each dn_poisson_apply (fused kernel + the
-    # tiny fixed-order reduction kernel), K launches
+    # dominant-kernel time: HIP events on the launch stream around each dn_poisson_apply (ONE kernel: the fused
+    # Poisson kernel, whose last workgroup also does the fixed-order final reduction), K launches
     from diffnet_amd import ops
     K = min(args.steps, 100)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]

@@ -66,14 +66,14 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
     __shared__ double red[8];
     __shared__ int last_flag;
 
-    RowState2D<NGP, E> SA, SB;
+    RowState2D<NGP, E> SA;
     float CT[E][NGP], CDX[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         CDX[e] = 0.f;
-        SA.keep[e] = SB.keep[e] = 1.f;
+        SA.keep[e] = 1.f;
 #pragma unroll
-        for (int i = 0; i < NGP; ++i) { CT[e][i] = 0.f; SA.TN[e][i] = SB.TN[e][i] = 1.f; SA.TF[e][i] = SB.TF[e][i] = 0.f; }
+        for (int i = 0; i < NGP; ++i) { CT[e][i] = 0.f; SA.TN[e][i] = 1.f; SA.TF[e][i] = 0.f; }
     }
 
     // issue the raw loads of node row yr (clamped to the domain: a prefetch past the last row is discarded)
@@ -168,16 +168,52 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
         }
     };
 
-    // one element layer between the rows held in L (lower) and U (upper)
-    auto layer = [&](int ey, const RowState2D<NGP, E>& L, const RowState2D<NGP, E>& U) {
+    // One element layer between the staged lower row S (state, updated IN PLACE) and the freshly loaded upper row `r`:
+    // the upper row's x-stage values live only while their element is processed, so a second row state (and the copy
+    // between the two) is never materialised -- ~30 VGPRs less than staging the whole upper row first.
+    auto layer = [&](int ey, RowState2D<NGP, E>& S, RowRaw2D<E>& r) {
         const bool own_layer = ey >= ey_own;
         const float cnt = (own_layer && col_owner) ? 1.f : 0.f;
+        float keep_up[NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) keep_up[n] = 1.f;
+        if constexpr (BC_U8C) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (sb.mask[k] != nullptr) {
+                    const float val = p.bc[k].value;
+#pragma unroll
+                    for (int n = 0; n <= NW; ++n) {
+                        const bool set = n < NW ? ((r.m8[k][0] >> (8 * n)) & 0xffu) != 0u : r.m8[k][1] != 0u;
+                        r.u[n] = set ? val : r.u[n];
+                        if (n < NW) keep_up[n] = set ? 0.f : keep_up[n];
+                    }
+                }
+            }
+        } else if constexpr (BC_ANY) {
+            bc_apply<NW>(p, sb, r.bc, r.u, keep_up);
+        }
         float o[NW + 1], le1 = 0.f, le2 = 0.f;
 #pragma unroll
         for (int n = 0; n <= NW; ++n) o[n] = 0.f;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             if (ex0 + e < p.nelx) {       // elements beyond the domain are skipped (and: scheduling fence, see header)
+                // x-stage of the upper row for this element only
+                float TU1[NGP], TN1[NGP], TF1[NGP];
+                const float DX1 = r.u[e + 1] - r.u[e];
+#pragma unroll
+                for (int i = 0; i < NGP; ++i) { TU1[i] = fmaf(p.T.b[i][1], DX1, r.u[e]); TN1[i] = 1.f; TF1[i] = 0.f; }
+                if constexpr (HAS_NU) {
+                    const float d = r.n[e + 1] - r.n[e];
+#pragma unroll
+                    for (int i = 0; i < NGP; ++i) TN1[i] = fmaf(p.T.b[i][1], d, r.n[e]);
+                }
+                if constexpr (HAS_F) {
+                    const float d = r.f[e + 1] - r.f[e];
+#pragma unroll
+                    for (int i = 0; i < NGP; ++i) TF1[i] = fmaf(p.T.b[i][1], d, r.f[e]);
+                }
                 float fg[NGP * NGP];
                 if constexpr (FGP) {
                     const unsigned eo = (unsigned)ey * (unsigned)p.nelx + (unsigned)(ex0 + e);
@@ -186,12 +222,11 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
                 }
                 float ct0[NGP], ct1[NGP], cdx0, cdx1, e1, e2;
 #ifndef DN_ABLATE_COMPUTE
-                q1_layer_2d<NGP, FGP>(p.T, L.TU[e], U.TU[e], L.DX[e], U.DX[e], L.TN[e], U.TN[e], L.TF[e], U.TF[e], fg, ct0, ct1,
-                                      cdx0, cdx1, e1, e2);
+                q1_layer_2d<NGP, FGP>(p.T, S.TU[e], TU1, S.DX[e], DX1, S.TN[e], TN1, S.TF[e], TF1, fg, ct0, ct1, cdx0, cdx1, e1, e2);
 #else                                      // timing experiment only: keep every load alive with trivial arithmetic
 #pragma unroll
-                for (int i = 0; i < NGP; ++i) { ct0[i] = L.TU[e][i] + U.TN[e][i]; ct1[i] = U.TU[e][i] + U.TF[e][i]; }
-                cdx0 = L.DX[e]; cdx1 = U.DX[e]; e1 = cdx0; e2 = cdx1;
+                for (int i = 0; i < NGP; ++i) { ct0[i] = S.TU[e][i] + TN1[i]; ct1[i] = TU1[i] + TF1[i]; }
+                cdx0 = S.DX[e]; cdx1 = DX1; e1 = cdx0; e2 = cdx1;
 #endif
                 le1 += e1;
                 le2 += e2;
@@ -203,59 +238,51 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_kernel(const
                     ssum += t;
                     bsum = fmaf(p.T.b[i][1], t, bsum);
                     CT[e][i] = ct1[i];
+                    S.TU[e][i] = TU1[i];       // the upper row becomes the lower row of the next layer
+                    if constexpr (HAS_NU) S.TN[e][i] = TN1[i];
+                    if constexpr (HAS_F) S.TF[e][i] = TF1[i];
                 }
                 CDX[e] = cdx1;
+                S.DX[e] = DX1;
                 o[e + 1] += bsum;
                 o[e] += ssum - bsum;
             }
         }
         e1_acc = fmaf(cnt, le1, e1_acc);
         e2_acc = fmaf(cnt, le2, e2_acc);
-        emit_row(o, L.keep, ey, own_layer);
+        emit_row(o, S.keep, ey, own_layer);
+#pragma unroll
+        for (int n = 0; n < NW; ++n) S.keep[n] = keep_up[n];
     };
 
-#ifdef DN_STAGGER
-    // de-phase the workgroups: identical workgroups started together tend to run in lockstep (everybody loads, then
-    // everybody computes), so the load and compute phases of different workgroups do not overlap
-    for (int i = (int)((blockIdx.y + blockIdx.z) & 3u); i > 0; --i) __builtin_amdgcn_s_sleep(DN_STAGGER);
-#endif
     RowRaw2D<E> raw;
     row_issue(ey_begin, raw);
     row_stage(raw, SA);
     int ey = ey_begin;
 #ifdef DN_PREFETCH
-    row_issue(ey_begin + 1, raw);
-    for (; ey < ey_end; ++ey) {
-        row_stage(raw, SB);                // row ey+1: loads issued one layer ago
-        row_issue(ey + 2, raw);            // prefetch: in flight while this layer is computed
-        layer(ey, SA, SB);
-        SA = SB;
-    }
+#error "register prefetch was measured slower and has been removed; see profiles/README.md"
 #else
-    for (; ey < ey_end; ++ey) {
+    auto set_prio = [&](int e) {
 #if DN_PRIO_ROT
         // rotate the wave priority with its progress: equal-priority waves are served oldest-first, so the four waves of
         // a SIMD finish one after the other and the tail runs at low occupancy; a progress-dependent priority makes
         // them advance at the same rate
-#if DN_PRIO_ROT == 2
-        switch ((ey - ey_begin) & 3) {
-#elif DN_PRIO_ROT == 3
-        switch (((ey_end - ey) >> 1) & 3) {
-#else
-        switch ((ey_end - ey) & 3) {          // s_setprio takes an immediate
-#endif
+        switch (((ey_end - e) >> 1) & 3) {          // s_setprio takes an immediate
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
             case 2: __builtin_amdgcn_s_setprio(2); break;
             default: __builtin_amdgcn_s_setprio(3); break;
         }
 #endif
+    };
+    // (a two-layers-per-trip ping-pong of the row states removes the SA = SB copies but was measured slower: 131 vs 115
+    // VGPRs drops the occupancy from 4 to 3 waves per SIMD)
+    for (; ey < ey_end; ++ey) {
+        set_prio(ey);
 #ifndef DN_ABLATE_MEM                      // timing experiment only: reuse the first row's data
         row_issue(ey + 1, raw);
 #endif
-        row_stage(raw, SB);
-        layer(ey, SA, SB);
-        SA = SB;                           // the upper row becomes the lower row of the next layer
+        layer(ey, SA, raw);
     }
 #endif
     // the last strip also owns the top boundary row of the domain: only the layer below contributes

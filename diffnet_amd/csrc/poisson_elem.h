@@ -38,6 +38,7 @@ struct ElemTab {
     //   m[r] = sum_g w[g] * b[g]^r  (r = 0,1,2);  kx[r][ig] = wx[ig] * m[r]
     float m[3];
     float kx[3][4];
+    float q1c[4];        // alpha*hs0^2, alpha*hs1^2, hs0^2, hs1^2  (2-D Q1 layer: derivative scales applied once per element)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -344,7 +345,9 @@ __device__ __forceinline__ void q1_layer_2d(const ElemTab& T, const float (&TU0)
                                             const float (&TF0)[NGP], const float (&TF1)[NGP], const float* fg,
                                             float (&ct0)[NGP], float (&ct1)[NGP], float& cdx0, float& cdx1, float& e1,
                                             float& e2) {
-    float a1 = 0.f, a2 = 0.f;
+    // The 1/h factors of the derivatives are applied once per element (q1c[]) instead of once per Gauss point:
+    //   e1 = hs0^2 * sum_jg w Qx' r_jg^2 + hs1^2 * sum_ig Qy d_ig^2,   r = raw x-difference lerp, d = raw y-difference
+    float a1x = 0.f, a1y = 0.f, a2 = 0.f;
     // nu moments along x
     float S0 = 0.f, S1 = 0.f, dyn[NGP];
 #pragma unroll
@@ -358,25 +361,22 @@ __device__ __forceinline__ void q1_layer_2d(const ElemTab& T, const float (&TU0)
     float c1s = 0.f, css = 0.f;
 #pragma unroll
     for (int jg = 0; jg < NGP; ++jg) {
-        const float ux = T.hs[0] * fmaf(T.b[jg][1], ddx, DX0);
-        const float Qx = T.w[jg] * fmaf(T.b[jg][1], S1, S0);
-        const float qxu = Qx * ux;
-        a1 = fmaf(qxu, ux, a1);
-        const float cx = T.ahs[0] * qxu;
+        const float r = fmaf(T.b[jg][1], ddx, DX0);
+        const float t = fmaf(T.b[jg][1], S1, S0) * r;          // (nu-moment) * raw derivative
+        a1x = fmaf(T.w[jg] * t, r, a1x);
+        const float cx = T.w[jg] * t;
         css += cx;
         c1s = fmaf(T.b[jg][1], cx, c1s);
     }
-    cdx1 = c1s;
-    cdx0 = css - c1s;
-    const float nb = -T.beta;
+    const float kx = T.q1c[0];                                   // alpha * hs0^2
+    cdx1 = kx * c1s;
+    cdx0 = kx * css - cdx1;
+    const float nb = -T.beta, ky = T.q1c[1];                     // alpha * hs1^2
 #pragma unroll
     for (int ig = 0; ig < NGP; ++ig) {
         const float dyv = TU1[ig] - TU0[ig];
-        const float uy = T.hs[1] * dyv;
-        const float Qy = fmaf(T.kx[1][ig], dyn[ig], T.kx[0][ig] * TN0[ig]);
-        const float qyu = Qy * uy;
-        a1 = fmaf(qyu, uy, a1);
-        const float cyd = T.ahs[1] * qyu;
+        const float t = fmaf(T.kx[1][ig], dyn[ig], T.kx[0][ig] * TN0[ig]) * dyv;
+        a1y = fmaf(t, dyv, a1y);
         float cs, c1;
         if constexpr (FGP) {
             cs = 0.f; c1 = 0.f;
@@ -393,10 +393,10 @@ __device__ __forceinline__ void q1_layer_2d(const ElemTab& T, const float (&TU0)
         }
         a2 = fmaf(cs, TU0[ig], a2);
         a2 = fmaf(c1, dyv, a2);
-        ct1[ig] = fmaf(nb, c1, cyd);
+        ct1[ig] = fmaf(nb, c1, ky * t);
         ct0[ig] = fmaf(nb, cs, -ct1[ig]);
     }
-    e1 = a1;
+    e1 = fmaf(T.q1c[2], a1x, T.q1c[3] * a1y);                    // hs0^2 * a1x + hs1^2 * a1y
     e2 = a2;
 }
 

@@ -364,6 +364,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         pp.T.hs[d] = 0.5f * m->scale[d];
         pp.T.ahs[d] = a->alpha * pp.T.hs[d];
     }
+    pp.T.q1c[0] = a->alpha * pp.T.hs[0] * pp.T.hs[0]; pp.T.q1c[1] = a->alpha * pp.T.hs[1] * pp.T.hs[1];
+    pp.T.q1c[2] = pp.T.hs[0] * pp.T.hs[0];            pp.T.q1c[3] = pp.T.hs[1] * pp.T.hs[1];
     {   // moments of the 1-D rule against b = phi_1 (Q1 marching kernels), accumulated in double
         double mm[3] = {0.0, 0.0, 0.0};
         for (int g = 0; g < m->ngp; ++g) {
