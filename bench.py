@@ -117,8 +117,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("DN_DIST_BACKEND", "nccl")      # "gloo" only to rehearse the N > 1 logic on one GPU
+        local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -132,20 +137,34 @@ def main():
     c = 1.0
     units_per_step = B * m.geom.nelem_total * m.geom.ngp_total
     dirichlet = [(bc, 0.0)]
+    pending = []
+
     def step():
         loss, grad = m.energy_loss_and_grad(u, nu, f, dirichlet=dirichlet, c=c)
         if dist is not None:
-            dist.all_reduce(loss)          # global mean of the loss: the path's only exchange step
+            # the path's only exchange step: all-reduce of the 4-byte loss (RCCL).  Issued asynchronously so that the
+            # next evaluation's kernel does not queue behind the collective; waited one step later (and before the
+            # timed region closes), i.e. every step's loss IS reduced inside the timed region.
+            loss.div_(world)
+            pending.append((dist.all_reduce(loss, async_op=True), loss))
+            if len(pending) > 1:
+                pending.pop(0)[0].wait()
         return loss, grad
+
+    def drain():
+        while pending:
+            pending.pop(0)[0].wait()
 
     for _ in range(args.warmup):
         step()
+    drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
