@@ -5,16 +5,18 @@ with transposed convolutions + LeakyReLU, then ReflPad4 -> Conv3x3 -> Conv7x7.  
 activation commented out (:81) and so does this one."""
 from torch import nn
 
+from .fused import InstanceNormAct
+
 
 class Encoder(nn.Module):
     def __init__(self, in_channels=3, dim=64, n_downsample=3, encoder_type='convolutional'):
         super().__init__()
         # the reference's first InstanceNorm is declared with `dim` features after a 2*dim-channel conv: harmless
         # (affine=False) and kept so construction consumes the RNG identically
-        layers = [nn.ReflectionPad2d(3), nn.Conv2d(in_channels, dim * 2, 7), nn.InstanceNorm2d(dim), nn.LeakyReLU(0.2, inplace=True)]
+        layers = [nn.ReflectionPad2d(3), nn.Conv2d(in_channels, dim * 2, 7), InstanceNormAct(dim, slope=0.2), nn.Identity()]
         for i in range(n_downsample):
             cin, cout = (dim * 2 * (i + 1), dim * (i + 2) * 2) if i <= 3 else (dim * 10, dim * 10)
-            layers += [nn.Conv2d(cin, cout, 4, stride=2, padding=1), nn.InstanceNorm2d(cout), nn.ReLU(inplace=True)]
+            layers += [nn.Conv2d(cin, cout, 4, stride=2, padding=1), InstanceNormAct(cout, slope=0.0), nn.Identity()]
         self.model_blocks = nn.Sequential(*layers, nn.Tanh())
 
     def forward(self, x):
@@ -28,7 +30,7 @@ class Decoder(nn.Module):
         i = 0
         for i in reversed(range(n_upsample)):
             cin, cout = (dim * 10, dim * 10) if i > 3 else (dim * (i + 2) * 2, dim * (i + 1) * 2)
-            layers += [nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1), nn.InstanceNorm2d(cout), nn.LeakyReLU(0.2, inplace=True)]
+            layers += [nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1), InstanceNormAct(cout, slope=0.2), nn.Identity()]
         layers += [nn.ReflectionPad2d(4), nn.Conv2d(dim * (i + 1) * 2, out_channels, 3), nn.Conv2d(out_channels, out_channels, 7)]
         self.model_blocks = nn.Sequential(*layers)
         self.activation = nn.Sigmoid() if activation == 'sigmoid' else nn.ReLU()   # declared, not applied (as the reference)

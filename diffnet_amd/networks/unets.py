@@ -5,19 +5,22 @@ Sigmoid.  Input sizes must be multiples of 32 (>= 64: InstanceNorm needs more th
 import torch
 from torch import nn
 
+from .fused import InstanceNormAct
+
 
 def _down(cin, cout, normalize=True, dropout=0.0):
     layers = [nn.Conv2d(cin, cout, 4, 2, 1, bias=False)]
-    if normalize:
-        layers.append(nn.InstanceNorm2d(cout))
-    layers.append(nn.LeakyReLU(0.2))
+    if normalize:                                  # fused InstanceNorm + LeakyReLU (HIP); Identity keeps the reference's indices
+        layers += [InstanceNormAct(cout, slope=0.2), nn.Identity()]
+    else:
+        layers.append(nn.LeakyReLU(0.2))
     if dropout:
         layers.append(nn.Dropout(dropout))
     return nn.Sequential(*layers)
 
 
 def _up(cin, cout, dropout=0.0):
-    layers = [nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=False), nn.InstanceNorm2d(cout), nn.ReLU(inplace=True)]
+    layers = [nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=False), InstanceNormAct(cout, slope=0.0), nn.Identity()]
     if dropout:
         layers.append(nn.Dropout(dropout))
     return nn.Sequential(*layers)

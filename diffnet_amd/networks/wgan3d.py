@@ -5,14 +5,17 @@ Upsample x2 -> Conv3d 3^3 pad 1 -> Sigmoid.  Default torch initialisation (the r
 import torch
 from torch import nn
 
+from .fused import InstanceNormAct
+
 
 class UNetDown(nn.Module):
     def __init__(self, in_size, out_size, normalize=True, dropout=0.0):
         super().__init__()
         layers = [nn.Conv3d(in_size, out_size, 4, 2, 1, bias=False)]
-        if normalize:
-            layers.append(nn.InstanceNorm3d(out_size))
-        layers.append(nn.LeakyReLU(0.2))
+        if normalize:                              # fused InstanceNorm + LeakyReLU (HIP); Identity keeps the reference's indices
+            layers += [InstanceNormAct(out_size, slope=0.2), nn.Identity()]
+        else:
+            layers.append(nn.LeakyReLU(0.2))
         if dropout:
             layers.append(nn.Dropout(dropout))
         self.model = nn.Sequential(*layers)
@@ -24,7 +27,7 @@ class UNetDown(nn.Module):
 class UNetUp(nn.Module):
     def __init__(self, in_size, out_size, dropout=0.0):
         super().__init__()
-        layers = [nn.ConvTranspose3d(in_size, out_size, 4, 2, 1, bias=False), nn.InstanceNorm3d(out_size), nn.ReLU(inplace=True)]
+        layers = [nn.ConvTranspose3d(in_size, out_size, 4, 2, 1, bias=False), InstanceNormAct(out_size, slope=0.0), nn.Identity()]
         if dropout:
             layers.append(nn.Dropout(dropout))
         self.model = nn.Sequential(*layers)

@@ -138,6 +138,18 @@ int dn_fdm_stencil_fwd(const float *g_padded, float *out, int32_t batch, int32_t
 int dn_fdm_stencil_bwd(const float *grad_out, float *grad_g_padded, int32_t batch, int32_t ny, int32_t nx,
                        const float *kernel9, int32_t axis, float a, float b, void *stream);
 
+/* Fused InstanceNorm (affine = False, biased variance) + LeakyReLU/ReLU of the generator blocks
+ * (DiffNet/networks/unets.py:13-45, autoencoders.py:7-70, wgan3d.py:23-55): x, y (n_inst, spatial) contiguous with
+ * n_inst = B*C; mean, rstd (n_inst) are written by fwd and consumed by bwd.  slope: 0 = ReLU, 0.2 = LeakyReLU(0.2),
+ * 1 = no activation.  With few, large instances the work of one instance is sliced over several workgroups and the
+ * fp64 partial sums go through `workspace` (dn_instnorm_workspace_bytes(n_inst, spatial) bytes, 0 when not needed;
+ * no initialisation required).  Results are bitwise repeatable. */
+int64_t dn_instnorm_workspace_bytes(int64_t n_inst, int64_t spatial);
+int dn_instnorm_act_fwd(const float *x, float *y, float *mean, float *rstd, int64_t n_inst, int64_t spatial, float eps,
+                        float slope, void *workspace, int64_t workspace_bytes, void *stream);
+int dn_instnorm_act_bwd(const float *x, const float *mean, const float *rstd, const float *grad_y, float *grad_x,
+                        int64_t n_inst, int64_t spatial, float slope, void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

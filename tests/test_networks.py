@@ -60,3 +60,40 @@ def test_network_matches_reference_cpu(name):
 def test_network_matches_reference_gpu(name):
     z = np.load(os.path.join(GOLDEN, f"net_{name}.npz"))
     check(build(name), z, torch.device("cuda:0"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 5, 8, 8), (2, 4, 7, 9), (2, 3, 1, 2), (1, 2, 128, 128), (1, 3, 129, 129), (2, 3, 6, 5, 4),
+                                   (1, 2, 33, 32, 32), (1, 1, 64, 64, 64)])
+@pytest.mark.parametrize("slope", [0.2, 0.0, 1.0])
+def test_instnorm_act_hip_matches_torch(shape, slope):
+    """dn_instnorm_act_fwd/bwd (one fused kernel each way) against torch's InstanceNorm + LeakyReLU on the same device and
+    against the float64 CPU evaluation; odd spatial sizes take the scalar path, multiples of 4 the float4 path."""
+    import torch.nn.functional as F
+    from diffnet_amd.networks.fused import InstanceNormAct
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(shape, generator=g) * 3 + 1.5)
+    cot = torch.randn(shape, generator=g)
+    xd = x.double().requires_grad_(True)
+    yd = F.instance_norm(xd, eps=1e-5)
+    yd = yd if slope == 1.0 else F.leaky_relu(yd, slope)
+    gd, = torch.autograd.grad(yd, xd, cot.double())
+    xg = x.to(dev).requires_grad_(True)
+    y = InstanceNormAct(shape[1], slope=slope)(xg)
+    gx, = torch.autograd.grad(y, xg, cot.to(dev))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yd.detach().numpy(), rtol=2e-5, atol=2e-6)
+    # points within rounding of the activation kink may flip sides between fp32 and fp64: compare away from them
+    far = (yd.detach().abs() > 1e-4).numpy() | (slope == 1.0)
+    scale = float(gd.abs().max())
+    assert np.abs(gx.cpu().numpy() - gd.numpy())[far].max() <= 2e-5 * scale + 1e-6
+    # bitwise repeatable
+    y2 = InstanceNormAct(shape[1], slope=slope)(xg)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.gpu
+def test_instnorm_act_rejects_single_element():
+    from diffnet_amd.networks.fused import InstanceNormAct
+    with pytest.raises(ValueError):
+        InstanceNormAct(4, slope=0.2)(torch.zeros(2, 4, 1, 1, device="cuda"))
