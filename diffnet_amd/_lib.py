@@ -37,6 +37,15 @@ class DnPoissonArgs(C.Structure):
                 ("energy_f32", C.c_void_p), ("energy_scale", C.c_double)]
 
 
+class DnFsdtArgs(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("phi_x", C.c_void_p), ("phi_y", C.c_void_p),
+                ("bc_mask", C.c_void_p), ("mask_is_u8", C.c_int32), ("mask_batched", C.c_int32),
+                ("bc_field", C.c_void_p * 3), ("bc_field_batched", C.c_int32 * 3), ("bc_value", C.c_float * 3),
+                ("D11", C.c_float), ("D12", C.c_float), ("D22", C.c_float), ("D66", C.c_float), ("A44", C.c_float),
+                ("A55", C.c_float), ("q", C.c_float), ("wscale", C.c_float),
+                ("out", C.c_void_p * 3), ("sumsq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
 I32x3 = C.c_int32 * 3
 
 # name -> (restype, argtypes); must list every symbol of include/diffnet_hip.h
@@ -57,6 +66,8 @@ SYMBOLS = {
                                      C.c_float, C.c_float, C.c_void_p]),
     "dn_fdm_stencil_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32,
                                      C.c_float, C.c_float, C.c_void_p]),
+    "dn_fsdt_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
+    "dn_fsdt_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnFsdtArgs), C.c_void_p]),
     "dn_instnorm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "dn_instnorm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                       C.c_void_p, C.c_int64, C.c_void_p]),

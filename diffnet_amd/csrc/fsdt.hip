@@ -1,0 +1,411 @@
+// Fused first-order shear-deformation (Mindlin) plate residuals on structured Q_P meshes: Dirichlet substitution,
+// the nine Gauss-point evaluations of (w, phi_x, phi_y), the constitutive combinations, the three weak-form
+// residuals, their element->node assembly, the Dirichlet rows of the result and the three Frobenius sums in ONE pass.
+//
+// Replaces examples/elasticity/single_instance/e1_plate_bending_fsdt.py:128-232 of the reference (9 gauss_pt_evaluation
+// calls = 9 * ngp^2 convolutions, ~40 elementwise ops on (B, nbf, ngp^2, nel) tensors, 3 assemblies); SURVEY.md 8(a)
+// row a14, BASELINE.json configs[4] (512 x 512, Q2, 3 x 3 Gauss points).
+//
+//   Q_x  = A55 (phi_x + w,x)          Q_y  = A44 (phi_y + w,y)                     (A44, A55 carry K_s)
+//   M_xx = D11 phi_x,x + D12 phi_y,y  M_yy = D12 phi_x,x + D22 phi_y,y   M_xy = D66 (phi_x,y + phi_y,x)
+//   R1_a = sum_g JxW ( N_a,x Q_x  + N_a,y Q_y  - N_a q   )
+//   R2_a = sum_g JxW ( N_a,x M_xx + N_a,y M_xy + N_a Q_x )
+//   R3_a = sum_g JxW ( N_a,x M_xy + N_a,y M_yy + N_a Q_y )
+// The residual is the gradient of the plate energy, so its Jacobian is symmetric: the backward pass is the same kernel
+// applied to the masked cotangents with q = 0 and zero Dirichlet values (diffnet_amd/elasticity.py).
+//
+// Same mapping as the generic fused Poisson kernel (poisson_fused.hip): a thread owns one element column of a strip
+// and marches over element rows; node values and partially assembled outputs of the current layer stay in
+// registers; the contribution to the node column shared with the right neighbour goes through a double-buffered LDS
+// slot; strip / chunk seams are closed by recomputing one layer (no atomics, bitwise repeatable).
+#include <cstdlib>
+
+#include "poisson_common.h"
+
+namespace dn {
+
+struct FsdtParams {
+    float b[4][4], dx[4][4], dy[4][4];     // 1-D tables at the Gauss points (derivatives scaled by 2/h)
+    float w2[4][4];                        // w[jg] * w[ig] * wscale
+    float D11, D12, D22, D66, A44, A55, q;
+    const float* fld[3];                   // w, phi_x, phi_y
+    const void* mask;
+    int mask_is_u8, mask_batched;
+    const float* bcf[3];
+    int bcf_batched[3];
+    float bcv[3];
+    float* out[3];
+    double* part;                          // [3][nblocks] partial sums of squares
+    unsigned* counter;
+    double* sumsq;                         // 3 doubles
+    int nx, ny, nelx, nely, rows_per_strip, want_sums;
+};
+
+// Deterministic in-kernel final reduction of three scalars (same protocol as finish_sums in poisson_common.h).
+__device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&sq)[3], int tid, int nthreads, double* red, int* flag) {
+    const int nblocks = gridDim.x * gridDim.y * gridDim.z;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    double s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = block_sum((double)sq[k], red, tid, nthreads);
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) __hip_atomic_store(&p.part[(size_t)k * nblocks + blk], s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int nshard = nblocks < DN_NSHARD ? nblocks : DN_NSHARD;
+        const int shard = blk % nshard;
+        const unsigned in_shard = (unsigned)((nblocks - shard + nshard - 1) / nshard);
+        unsigned* sc = p.counter + 16 * (1 + shard);
+        int last = 0;
+        const unsigned prev = __hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == in_shard - 1) {
+            __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned prev2 = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (prev2 == (unsigned)(nshard - 1)) ? 1 : 0;
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag) {
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double e = 0.0;
+            for (int i = tid; i < nblocks; i += nthreads)
+                e += __hip_atomic_load(&p.part[(size_t)k * nblocks + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            e = block_sum(e, red, tid, nthreads);
+            if (tid == 0) p.sumsq[k] = e;
+        }
+        if (tid == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// One element: nodal values F[k][jb][ib] of the three fields -> nodal residual contributions g[k][jb][ib].
+template <int P, int NGP>
+__device__ __forceinline__ void fsdt_elem(const FsdtParams& p, const float (&F)[3][P + 1][P + 1], float (&g)[3][P + 1][P + 1]) {
+    constexpr int NB = P + 1;
+    float tv[3][NB][NGP], td[3][NB][NGP];      // x-stage: value / x-derivative at the x Gauss points, per node row
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int ig = 0; ig < NGP; ++ig) {
+                float a = 0.f, d = 0.f;
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) {
+                    a = fmaf(p.b[ig][ib], F[k][jb][ib], a);
+                    d = fmaf(p.dx[ig][ib], F[k][jb][ib], d);
+                }
+                tv[k][jb][ig] = a;
+                td[k][jb][ig] = d;
+            }
+    float rv[3][NB][NGP], rd[3][NB][NGP];      // cotangents of tv / td
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int ig = 0; ig < NGP; ++ig) rv[k][jb][ig] = rd[k][jb][ig] = 0.f;
+#pragma unroll
+    for (int jg = 0; jg < NGP; ++jg) {
+#pragma unroll
+        for (int ig = 0; ig < NGP; ++ig) {
+            float val[3], fx[3], fy[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float v = 0.f, x = 0.f, y = 0.f;
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) {
+                    v = fmaf(p.b[jg][jb], tv[k][jb][ig], v);
+                    x = fmaf(p.b[jg][jb], td[k][jb][ig], x);
+                    y = fmaf(p.dy[jg][jb], tv[k][jb][ig], y);
+                }
+                val[k] = v; fx[k] = x; fy[k] = y;
+            }
+            const float W = p.w2[jg][ig];
+            const float Qx = W * (p.A55 * (val[1] + fx[0])), Qy = W * (p.A44 * (val[2] + fy[0]));
+            const float Mxx = W * fmaf(p.D11, fx[1], p.D12 * fy[2]);
+            const float Myy = W * fmaf(p.D12, fx[1], p.D22 * fy[2]);
+            const float Mxy = W * (p.D66 * (fy[1] + fx[2]));
+            const float cv[3] = {-p.q * W, Qx, Qy}, cx[3] = {Qx, Mxx, Mxy}, cy[3] = {Qy, Mxy, Myy};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb) {
+                    rv[k][jb][ig] = fmaf(p.b[jg][jb], cv[k], rv[k][jb][ig]);
+                    rv[k][jb][ig] = fmaf(p.dy[jg][jb], cy[k], rv[k][jb][ig]);
+                    rd[k][jb][ig] = fmaf(p.b[jg][jb], cx[k], rd[k][jb][ig]);
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                float a = 0.f;
+#pragma unroll
+                for (int ig = 0; ig < NGP; ++ig) {
+                    a = fmaf(p.b[ig][ib], rv[k][jb][ig], a);
+                    a = fmaf(p.dx[ig][ib], rd[k][jb][ig], a);
+                }
+                g[k][jb][ib] = a;
+            }
+}
+
+// grid = (chunks_x, strips_y, B), block = T threads; one element column per thread.
+template <int P, int NGP>
+__global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
+    constexpr int NB = P + 1;
+    constexpr int NW = P;                  // nodes owned per thread per node row
+    const int T = blockDim.x;
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+    const int q = chunk * (T - 1) + tid;   // chunks overlap by one thread column
+    const int ex0 = q, x0 = ex0 * P;
+    const bool col_owner = !(chunk > 0 && tid == 0);
+    const int64_t nps = (int64_t)p.nx * p.ny;
+    const int R = p.rows_per_strip;
+    const int ey_own = strip * R;
+    const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;
+    const int ey_end = min(ey_own + R, p.nely);
+
+    const float* fb[3];
+    const float* bcf[3];
+    float* ob[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        fb[k] = p.fld[k] + (int64_t)b * nps;
+        bcf[k] = p.bcf[k] ? p.bcf[k] + (p.bcf_batched[k] ? (int64_t)b * nps : 0) : nullptr;
+        ob[k] = p.out[k] ? p.out[k] + (int64_t)b * nps : nullptr;
+    }
+    const int64_t mo = p.mask_batched ? (int64_t)b * nps : 0;
+    const uint8_t* m8 = (p.mask && p.mask_is_u8) ? reinterpret_cast<const uint8_t*>(p.mask) + mo : nullptr;
+    const float* mf = (p.mask && !p.mask_is_u8) ? reinterpret_cast<const float*>(p.mask) + mo : nullptr;
+
+    __shared__ float xch[2][3][P][256];
+    __shared__ double red[8];
+    __shared__ int last_flag;
+
+    float cu[3][NB][NW + 1], acc[3][NB][NW + 1];
+    unsigned fixed[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        fixed[r] = 0u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) acc[k][r][n] = 0.f;
+    }
+
+    // load node row yr into slot r; Dirichlet nodes (mask >= 0.5) take the boundary values
+    auto load_row = [&](int r, int yr) {
+        const unsigned rowoff = (unsigned)yr * (unsigned)p.nx;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) load_seg<NW, false>(fb[k], rowoff, x0, p.nx, cu[k][r]);
+        unsigned bits = 0u;
+        if (m8) {
+            uint8_t t[NW + 1];
+            load_seg<NW, false>(m8, rowoff, x0, p.nx, t);
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) bits |= (t[n] != 0) ? (1u << n) : 0u;
+        } else if (mf) {
+            float t[NW + 1];
+            load_seg<NW, false>(mf, rowoff, x0, p.nx, t);
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) bits |= (t[n] >= 0.5f) ? (1u << n) : 0u;
+        }
+        fixed[r] = bits;
+        if (m8 || mf) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (bcf[k]) {
+                    float t[NW + 1];
+                    load_seg<NW, false>(bcf[k], rowoff, x0, p.nx, t);
+#pragma unroll
+                    for (int n = 0; n <= NW; ++n) cu[k][r][n] = (bits & (1u << n)) ? t[n] : cu[k][r][n];
+                } else {
+#pragma unroll
+                    for (int n = 0; n <= NW; ++n) cu[k][r][n] = (bits & (1u << n)) ? p.bcv[k] : cu[k][r][n];
+                }
+            }
+        }
+    };
+
+    float sq[3] = {0.f, 0.f, 0.f};
+    int par = 0;
+
+    // Emit node row yr from acc[.][r] (+ the left neighbour's hand-over for n == 0); Dirichlet rows of the residual carry
+    // the boundary values (e1_plate_bending_fsdt.py:222-228), which cu holds at those nodes.
+    auto emit_row = [&](int r, int yr, bool owned_row) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xch[par][k][r % P][tid] = acc[k][r][NW];
+        __syncthreads();
+        if (owned_row && col_owner) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float left = (tid > 0) ? xch[par][k][r % P][tid - 1] : 0.f;
+                float o[NW];
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    float v = acc[k][r][n] + (n == 0 ? left : 0.f);
+                    v = (fixed[r] & (1u << n)) ? cu[k][r][n] : v;
+                    sq[k] = (x0 + n < p.nx) ? fmaf(v, v, sq[k]) : sq[k];
+                    o[n] = v;
+                }
+                if (ob[k]) store_seg<NW, false>(ob[k], (unsigned)yr * (unsigned)p.nx, x0, p.nx, o);
+            }
+        }
+    };
+
+    load_row(0, ey_begin * P);
+    for (int ey = ey_begin; ey < ey_end; ++ey) {
+#pragma unroll
+        for (int r = 1; r <= P; ++r) load_row(r, ey * P + r);
+        const bool own_layer = ey >= ey_own;
+        if (ex0 < p.nelx) {
+            float F[3][NB][NB], g[3][NB][NB];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int ib = 0; ib < NB; ++ib) F[k][jb][ib] = cu[k][jb][ib];
+            fsdt_elem<P, NGP>(p, F, g);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int ib = 0; ib < NB; ++ib) acc[k][jb][ib] += g[k][jb][ib];
+        }
+#pragma unroll
+        for (int r = 0; r < P; ++r) emit_row(r, ey * P + r, own_layer);
+        par ^= 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) {
+                cu[k][0][n] = cu[k][P][n];
+                acc[k][0][n] = acc[k][P][n];
+#pragma unroll
+                for (int r = 1; r <= P; ++r) acc[k][r][n] = 0.f;
+            }
+        fixed[0] = fixed[P];
+    }
+    if (ey_end == p.nely) emit_row(0, p.ny - 1, true);
+
+    if (p.want_sums) finish_sums3(p, sq, tid, T, red, &last_flag);
+}
+
+static inline int fs_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static constexpr int64_t FSDT_WS_HEADER = 64 * (1 + 64);
+
+struct FsdtGeom { int T, chunks, R, strips; };
+
+static FsdtGeom fsdt_plan(const dn_mesh* m) {
+    FsdtGeom g;
+    const int P = m->degree;
+    const int Q = (m->nx - 1) / P + 1;          // logical thread columns (one per element + the closing column)
+    const int nely = (m->ny - 1) / P;
+    double best = -1.0;
+    g.T = 64; g.chunks = 1;
+    for (int T = 64; T <= 256; T *= 2) {
+        const int chunks = Q <= T ? 1 : fs_ceil_div(Q - 1, T - 1);
+        const double util = (double)Q / ((double)chunks * T);
+        const double score = util + (T == 128 ? 0.005 : 0.0);
+        if (score > best) { best = score; g.T = T; g.chunks = chunks; }
+    }
+    const long long per_strip = (long long)g.chunks * m->batch;
+    int R = 32;
+    while (R > 4 && per_strip * fs_ceil_div(nely, R) < 2048) R /= 2;
+    if (R > nely) R = nely;
+    g.R = R < 1 ? 1 : R;
+    g.strips = fs_ceil_div(nely, g.R);
+    const char* e = getenv("DN_PLAN_FSDT");      // "T,R" (tuning experiments only)
+    int T, RR;
+    if (e && sscanf(e, "%d,%d", &T, &RR) == 2 && T >= 64 && T <= 256 && RR >= 1) {
+        g.T = T; g.R = RR > nely ? nely : RR;
+        g.chunks = Q <= T ? 1 : fs_ceil_div(Q - 1, T - 1);
+        g.strips = fs_ceil_div(nely, g.R);
+    }
+    return g;
+}
+
+static int fsdt_validate(const dn_mesh* m) {
+    if (!m || m->nsd != 2) return DN_E_BADARG;
+    if (m->degree < 1 || m->degree > 3 || m->ngp < 2 || m->ngp > 4) return DN_E_UNSUPPORTED;
+    if (m->batch < 1 || m->batch > 65535 || m->nx < 2 || m->ny < 2) return DN_E_BADARG;
+    if ((m->nx - 1) % m->degree || (m->ny - 1) % m->degree) return DN_E_BADARG;
+    if ((int64_t)m->nx * m->ny >= (1ll << 30)) return DN_E_UNSUPPORTED;
+    return 0;
+}
+
+template <int P>
+static int fsdt_launch(const FsdtParams& pp, const FsdtGeom& g, int ngp, int batch, hipStream_t s) {
+    dim3 grid(g.chunks, g.strips, batch), block(g.T);
+    switch (ngp) {
+        case 2: hipLaunchKernelGGL((fsdt2d_kernel<P, 2>), grid, block, 0, s, pp); return 0;
+        case 3: hipLaunchKernelGGL((fsdt2d_kernel<P, 3>), grid, block, 0, s, pp); return 0;
+        case 4: hipLaunchKernelGGL((fsdt2d_kernel<P, 4>), grid, block, 0, s, pp); return 0;
+        default: return DN_E_UNSUPPORTED;
+    }
+}
+
+}  // namespace dn
+
+using namespace dn;
+
+extern "C" int64_t dn_fsdt_workspace_bytes(const dn_mesh* m) {
+    if (fsdt_validate(m) != 0) return DN_E_BADARG;
+    const FsdtGeom g = fsdt_plan(m);
+    return FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * g.chunks * g.strips * m->batch;
+}
+
+extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stream) {
+    int rc = fsdt_validate(m);
+    if (rc) return rc;
+    if (!a || !a->w || !a->phi_x || !a->phi_y) return DN_E_BADARG;
+    if (!a->out[0] && !a->out[1] && !a->out[2] && !a->sumsq) return DN_E_BADARG;
+    const FsdtGeom g = fsdt_plan(m);
+    const int64_t nwg = (int64_t)g.chunks * g.strips * m->batch;
+    if (a->sumsq && (!a->workspace || a->workspace_bytes < FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
+
+    FsdtParams pp;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            pp.b[i][j] = m->basis[i][j];
+            pp.dx[i][j] = m->dbasis[i][j] * m->scale[0];
+            pp.dy[i][j] = m->dbasis[i][j] * m->scale[1];
+            pp.w2[i][j] = m->gpw[i] * (m->gpw[j] * a->wscale);
+        }
+    pp.D11 = a->D11; pp.D12 = a->D12; pp.D22 = a->D22; pp.D66 = a->D66; pp.A44 = a->A44; pp.A55 = a->A55; pp.q = a->q;
+    pp.fld[0] = a->w; pp.fld[1] = a->phi_x; pp.fld[2] = a->phi_y;
+    pp.mask = a->bc_mask; pp.mask_is_u8 = a->mask_is_u8; pp.mask_batched = a->mask_batched;
+    for (int k = 0; k < 3; ++k) {
+        pp.bcf[k] = a->bc_field[k]; pp.bcf_batched[k] = a->bc_field_batched[k]; pp.bcv[k] = a->bc_value[k];
+        pp.out[k] = a->out[k];
+    }
+    pp.counter = reinterpret_cast<unsigned*>(a->workspace);
+    pp.part = a->workspace ? reinterpret_cast<double*>(reinterpret_cast<char*>(a->workspace) + FSDT_WS_HEADER) : nullptr;
+    pp.sumsq = a->sumsq;
+    pp.nx = m->nx; pp.ny = m->ny;
+    pp.nelx = (m->nx - 1) / m->degree; pp.nely = (m->ny - 1) / m->degree;
+    pp.rows_per_strip = g.R;
+    pp.want_sums = a->sumsq ? 1 : 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (m->degree) {
+        case 1: rc = fsdt_launch<1>(pp, g, m->ngp, m->batch, s); break;
+        case 2: rc = fsdt_launch<2>(pp, g, m->ngp, m->batch, s); break;
+        default: rc = fsdt_launch<3>(pp, g, m->ngp, m->batch, s); break;
+    }
+    if (rc) return rc;
+    DN_LAUNCH_CHECK();
+    return 0;
+}

@@ -3,16 +3,53 @@ reference `examples/elasticity/single_instance/e1_plate_bending_fsdt.py:128-232`
 
 Three nodal fields (w, phi_x, phi_y); 9 Gauss-point evaluations, the constitutive combinations (eq. 4 of the
 script), three weak-form residuals and their element->node assembly, Dirichlet rows replaced by the boundary
-values.  Round-1 status: composed from the single-launch HIP operators (`gauss_pt_evaluation*`,
-`assemble`) -- any degree the operators support (the reference script is Q1; BASELINE configs[4] asks for Q2, whose
-assembly the reference does not have: it is `dn_assemble` with nbf = 3).  A fused three-field kernel in the style of
-`dn_poisson_apply` is listed in DESIGN.md section 6."""
+values.  `fsdt_residuals` / `fsdt_loss` are ONE fused launch (`dn_fsdt_apply`, csrc/fsdt.hip; degree 1..3 -- the
+reference script is Q1, BASELINE configs[4] asks for Q2) forward and one backward (the operator is the gradient of the
+plate energy, so its VJP is the same kernel on the masked cotangents).  `fsdt_residuals_composed` is the same
+computation spelled with the single-launch HIP operators (`gauss_pt_evaluation*`, `assemble`), kept as a second
+implementation for cross-checks."""
 import torch
+
+from . import ops
+
+
+def _constants(E, v, h, K_s):
+    D_11 = (E * h ** 3) / (12 * (1 - v ** 2))
+    D_12 = (E * v * h ** 3) / (12 * (1 - v ** 2))
+    D_66 = (E * h ** 3) / (12 * (1 + v))
+    A = (E * h) / (2 * (1 + v))
+    return dict(D11=D_11, D12=D_12, D22=D_11, D66=D_66, A44=K_s * A, A55=K_s * A)
+
+
+class _FsdtResiduals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, phi_x, phi_y, fem, bc, bc_values, consts, q, wscale):
+        outs, _ = ops.fsdt_apply(fem.geom, w, phi_x, phi_y, bc, bc_values, q=q, wscale=wscale, want_sums=False, **consts)
+        ctx.fem, ctx.bc, ctx.consts, ctx.wscale = fem, bc, consts, wscale
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        # J = M K M with K symmetric and M the projector onto the free nodes: J^T g = M K (M g).  Zero Dirichlet values
+        # give both projections (inputs and result rows on Dirichlet nodes become 0), q = 0 drops the load term.
+        gs = [g.contiguous() for g in (g1, g2, g3)]
+        outs, _ = ops.fsdt_apply(ctx.fem.geom, *gs, ctx.bc, (0.0, 0.0, 0.0), q=0.0, wscale=ctx.wscale, want_sums=False, **ctx.consts)
+        return outs[0], outs[1], outs[2], None, None, None, None, None, None
 
 
 def fsdt_residuals(fem, w, phi_x, phi_y, bc, w_bc=0.0, phi_x_bc=0.0, phi_y_bc=0.0, E=1.0, v=0.25, h=0.1, K_s=1.0, q=1.0,
                    hx=None, hy=None):
-    """Assembled residuals (R1, R2, R3) of the three FSDT equations; `bc >= 0.5` marks Dirichlet nodes."""
+    """Assembled residuals (R1, R2, R3) of the three FSDT equations; `bc >= 0.5` marks Dirichlet nodes.  One fused launch;
+    differentiable wrt the three fields."""
+    hx = fem.h if hx is None else hx
+    hy = fem.h if hy is None else hy
+    return _FsdtResiduals.apply(w, phi_x, phi_y, fem, bc, (w_bc, phi_x_bc, phi_y_bc), _constants(E, v, h, K_s), q,
+                                (0.5 * hx) * (0.5 * hy))
+
+
+def fsdt_residuals_composed(fem, w, phi_x, phi_y, bc, w_bc=0.0, phi_x_bc=0.0, phi_y_bc=0.0, E=1.0, v=0.25, h=0.1, K_s=1.0, q=1.0,
+                            hx=None, hy=None):
+    """Same residuals from the single-launch HIP operators (9 gauss_pt_eval launches + torch elementwise + 3 assemblies)."""
     hx = fem.h if hx is None else hx
     hy = fem.h if hy is None else hy
 
@@ -48,6 +85,27 @@ def fsdt_residuals(fem, w, phi_x, phi_y, bc, w_bc=0.0, phi_x_bc=0.0, phi_y_bc=0.
     return fix(R1, w_bc), fix(R2, phi_x_bc), fix(R3, phi_y_bc)
 
 
-def fsdt_loss(fem, w, phi_x, phi_y, bc, **kw):
-    """Frobenius norms of the three residuals (e1_plate_bending_fsdt.py:230-232)."""
-    return tuple(torch.norm(R, 'fro') for R in fsdt_residuals(fem, w, phi_x, phi_y, bc, **kw))
+class _FsdtLoss(torch.autograd.Function):
+    """The three Frobenius norms from the launch that computes the residuals (in-kernel fixed-order fp64 sums)."""
+
+    @staticmethod
+    def forward(ctx, w, phi_x, phi_y, fem, bc, bc_values, consts, q, wscale):
+        outs, sums = ops.fsdt_apply(fem.geom, w, phi_x, phi_y, bc, bc_values, q=q, wscale=wscale, want_sums=True, **consts)
+        norms = sums.sqrt().float()
+        ctx.save_for_backward(*outs, norms)
+        ctx.fem, ctx.bc, ctx.consts, ctx.wscale = fem, bc, consts, wscale
+        return norms[0], norms[1], norms[2]
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        *Rs, norms = ctx.saved_tensors
+        cots = [R * (g / n) for R, g, n in zip(Rs, (g1, g2, g3), norms)]           # d||R||/dR = R / ||R||
+        outs, _ = ops.fsdt_apply(ctx.fem.geom, *cots, ctx.bc, (0.0, 0.0, 0.0), q=0.0, wscale=ctx.wscale, want_sums=False, **ctx.consts)
+        return outs[0], outs[1], outs[2], None, None, None, None, None, None
+
+
+def fsdt_loss(fem, w, phi_x, phi_y, bc, w_bc=0.0, phi_x_bc=0.0, phi_y_bc=0.0, E=1.0, v=0.25, h=0.1, K_s=1.0, q=1.0, hx=None, hy=None):
+    """Frobenius norms of the three residuals (e1_plate_bending_fsdt.py:230-232); one launch forward, one backward."""
+    hx = fem.h if hx is None else hx
+    hy = fem.h if hy is None else hy
+    return _FsdtLoss.apply(w, phi_x, phi_y, fem, bc, (w_bc, phi_x_bc, phi_y_bc), _constants(E, v, h, K_s), q, (0.5 * hx) * (0.5 * hy))

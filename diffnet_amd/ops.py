@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import DnDirichlet, DnMesh, DnPoissonArgs, I32x3, DiffNetHipError
+from ._lib import DnDirichlet, DnFsdtArgs, DnMesh, DnPoissonArgs, I32x3, DiffNetHipError
 
 
 def _require(t, name, ndim=None):
@@ -341,6 +341,71 @@ class _ResidualLoss(torch.autograd.Function):
 
 def residual_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
     return _ResidualLoss.apply(u, geom, nu, f, f_gp, tuple(_norm_dirichlet(dirichlet)), float(jac))
+
+
+def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.0, D12=0.0, D22=1.0, D66=1.0, A44=1.0, A55=1.0,
+               q=0.0, wscale=1.0, want_out=True, want_sums=True):
+    """One launch of dn_fsdt_apply (include/diffnet_hip.h): the three assembled FSDT plate residuals of the fields
+    (B,1,ny,nx) and / or the float64 device tensor of their three sums of squares.  `bc`: Dirichlet node mask (fp32,
+    `>= 0.5`, or bool/uint8), per sample or shared; `bc_values[k]`: float or tensor the k-th field / residual takes there."""
+    if geom.nsd != 2:
+        raise DiffNetHipError("fsdt_apply: 2-D meshes only")
+    flds = [_require(t, n, 4) for t, n in ((w, "w"), (phi_x, "phi_x"), (phi_y, "phi_y"))]
+    B = flds[0].shape[0]
+    shape = (B, 1, *geom.node_shape)
+    for t in flds:
+        if tuple(t.shape) != shape:
+            raise ValueError(f"fsdt_apply: field shape {tuple(t.shape)} != {shape}")
+    keep = list(flds)
+    args = DnFsdtArgs()
+    args.w, args.phi_x, args.phi_y = (t.data_ptr() for t in flds)
+
+    def batched(t, name):
+        if tuple(t.shape[-2:]) != tuple(geom.node_shape) or t.numel() not in (B * geom.nnode_total, geom.nnode_total):
+            raise ValueError(f"fsdt_apply: {name} shape {tuple(t.shape)} does not match the mesh {shape}")
+        return 1 if (t.numel() == B * geom.nnode_total and B > 1) else 0
+
+    if bc is not None:
+        if not bc.is_cuda:
+            raise DiffNetHipError("fsdt_apply: bc mask must be on the GPU")
+        if bc.dtype in (torch.bool, torch.uint8):
+            m = bc.to(torch.uint8).contiguous()
+            args.mask_is_u8 = 1
+        else:
+            m = _require(bc, "bc")
+            args.mask_is_u8 = 0
+        args.mask_batched = batched(m, "bc")
+        args.bc_mask = m.data_ptr()
+        keep.append(m)
+        for k, v in enumerate(bc_values):
+            if isinstance(v, torch.Tensor) and v.numel() > 1:
+                v = _require(v, f"bc_values[{k}]")
+                args.bc_field_batched[k] = batched(v, f"bc_values[{k}]")
+                args.bc_field[k] = v.data_ptr()
+                keep.append(v)
+            else:
+                args.bc_value[k] = float(v)
+    args.D11, args.D12, args.D22, args.D66, args.A44, args.A55 = (float(x) for x in (D11, D12, D22, D66, A44, A55))
+    args.q, args.wscale = float(q), float(wscale)
+    mesh = geom.mesh_struct(B)
+    outs = None
+    if want_out:
+        outs = [torch.empty(shape, dtype=torch.float32, device=flds[0].device) for _ in range(3)]
+        for k in range(3):
+            args.out[k] = outs[k].data_ptr()
+    sums = None
+    if want_sums:
+        sums = torch.empty(3, dtype=torch.float64, device=flds[0].device)
+        nbytes = _lib.lib().dn_fsdt_workspace_bytes(C.byref(mesh))
+        if nbytes < 0:
+            _lib.check(int(nbytes), "dn_fsdt_workspace_bytes")
+        ws = _workspace(flds[0].device, nbytes)
+        keep.append(ws)
+        args.sumsq = sums.data_ptr()
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    rc = _lib.lib().dn_fsdt_apply(C.byref(mesh), C.byref(args), _stream(flds[0]))
+    _lib.check(rc, "dn_fsdt_apply")
+    return outs, sums
 
 
 def compute_winding_nodes(points, normals, area, q):

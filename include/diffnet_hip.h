@@ -138,6 +138,34 @@ int dn_fdm_stencil_fwd(const float *g_padded, float *out, int32_t batch, int32_t
 int dn_fdm_stencil_bwd(const float *grad_out, float *grad_g_padded, int32_t batch, int32_t ny, int32_t nx,
                        const float *kernel9, int32_t axis, float a, float b, void *stream);
 
+/* ---- fused FSDT (Mindlin) plate residuals ---------------------------------------------------------------------
+ * Replaces the loss body of examples/elasticity/single_instance/e1_plate_bending_fsdt.py:128-232 (9 Gauss-point
+ * evaluations of w, phi_x, phi_y, the constitutive combinations, three weak-form residuals, their assembly, the
+ * Dirichlet rows and the three Frobenius sums) by one launch; mesh: nsd = 2, degree 1..3, ngp 2..4.
+ *   fields (B,1,ny,nx) fp32; bc_mask marks Dirichlet nodes (fp32: >= 0.5 as in the script, u8: != 0; NULL = none);
+ *   on those nodes the inputs are replaced by bc_field[k] (or bc_value[k] when the pointer is NULL) and so are the
+ *   rows of the k-th residual.  A44, A55 include the shear correction K_s; wscale = (hx/2)(hy/2).
+ *   out[k]: assembled residual k (may be NULL); sumsq: 3 doubles, sum of squares of each residual field
+ *   (deterministic in-kernel reduction; needs the workspace, zero-filled once before first use).
+ * The operator is the gradient of the plate energy (symmetric Jacobian): the VJP wrt the fields is the same call on
+ * the masked cotangents with q = 0 and zero Dirichlet values. */
+typedef struct dn_fsdt_args {
+    const float *w, *phi_x, *phi_y;
+    const void *bc_mask;
+    int32_t mask_is_u8, mask_batched;
+    const float *bc_field[3];
+    int32_t bc_field_batched[3];
+    float bc_value[3];
+    float D11, D12, D22, D66, A44, A55, q;
+    float wscale;
+    float *out[3];
+    double *sumsq;
+    void *workspace;
+    int64_t workspace_bytes;
+} dn_fsdt_args;
+int64_t dn_fsdt_workspace_bytes(const dn_mesh *mesh);
+int dn_fsdt_apply(const dn_mesh *mesh, const dn_fsdt_args *args, void *stream);
+
 /* Fused InstanceNorm (affine = False, biased variance) + LeakyReLU/ReLU of the generator blocks
  * (DiffNet/networks/unets.py:13-45, autoencoders.py:7-70, wgan3d.py:23-55): x, y (n_inst, spatial) contiguous with
  * n_inst = B*C; mean, rstd (n_inst) are written by fwd and consumed by bwd.  slope: 0 = ReLU, 0.2 = LeakyReLU(0.2),
