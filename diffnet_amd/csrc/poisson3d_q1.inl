@@ -13,7 +13,7 @@
 
 namespace dn {
 
-enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8 };
+enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8, FL3_BC_U8C = 16 };   // FL3_BC_U8C: uint8 masks with constant values only
 
 template <int NGP, int E>
 struct PlaneState3D {
@@ -28,15 +28,35 @@ struct PlaneState3D {
 #define DN_PRIO_ROT3D 0
 #endif
 
-template <int NGP, int E, bool VEC, int FL>
-__global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(const PoissonParams p, const int chunks_x) {
+// NT: workgroup size the kernel is compiled for (256, 512 or 1024 threads).  Larger workgroups exist to make the in-plane
+// tile taller: the tile seam costs one recomputed thread row out of TY, and rows as wide as the mesh leave TY = 256 / TX
+// small (TX = 64 -> 4 rows = 33 % redundant work; 128 -> 2 rows = 100 %).  1024 threads need <= 128 VGPRs.
+template <int NGP, int E, bool VEC, int FL, int NT>
+__global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_q1m_kernel(const PoissonParams p, const int chunks_x,
+                                                                                             const int tiles_y, const int strips_z) {
     constexpr int NW = E;
     constexpr int G = NGP * NGP * NGP;
-    constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, FGP = (FL & FL3_FGP) != 0, BC_ANY = (FL & FL3_BC) != 0;
+    constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, FGP = (FL & FL3_FGP) != 0;
+    constexpr bool BC_U8C = (FL & FL3_BC_U8C) != 0, BC_ANY = (FL & (FL3_BC | FL3_BC_U8C)) != 0;
     const int TX = blockDim.x, TY = blockDim.y;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * TX + tx;
-    const int chunk = blockIdx.x % chunks_x, tile = blockIdx.x / chunks_x, strip = blockIdx.y, b = blockIdx.z;
+    // 1-D grid with an XCD-aware decode (cdna_hip_programming.md T1): workgroups are dealt round-robin to the 8 XCDs, each
+    // with its own L2.  In-plane neighbours share 2 of their TY + 1 node rows and z-neighbours one plane, so every XCD gets a
+    // contiguous range of the logical order (chunk fastest, then tile, strip, sample): the halo of a tile is then read
+    // from HBM once instead of once per XCD.  The remap is a bijection for any grid size.
+    unsigned lid = blockIdx.x;
+#ifndef DN_NO_XCD_MAP
+    {
+        const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
+        lid = xcd * base + min(xcd, rem) + idx;
+    }
+#endif
+    const int chunk = (int)(lid % (unsigned)chunks_x);
+    lid /= (unsigned)chunks_x;
+    const int tile = (int)(lid % (unsigned)tiles_y);
+    lid /= (unsigned)tiles_y;
+    const int strip = (int)(lid % (unsigned)strips_z), b = (int)(lid / (unsigned)strips_z);
     const int q = chunk * (TX - 1) + tx;
     const int ex0 = q * E, x0 = ex0;
     const int ey = tile * (TY - 1) + ty;          // element row == lower node row of this thread
@@ -55,8 +75,8 @@ __global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(cons
     const bool noderow_ok = ey < p.ny;            // thread's lower node row exists
 
     // hand-over slots: [parity][slot][thread]; 0 = right (row 0, n = E), 1..E = up (row 1, n < E), E+1 = up-right
-    __shared__ float xch[2][NW + 2][256];
-    __shared__ double red[8];
+    __shared__ float xch[2][NW + 2][NT];
+    __shared__ double red[NT / 64 + 1];
     __shared__ int last_flag;
 
     PlaneState3D<NGP, E> SA, SB;
@@ -205,12 +225,14 @@ __global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(cons
     // Direct form (default): every thread loads its two node rows itself (row ey+1 is also loaded by the next thread row;
     // the duplicate is served by L1/L2).  Measured 8-15 % faster than the LDS-tile form above at 128^3 / 256^3
     // (profiles/README.md): the tile adds a second barrier per plane and the kernel is not load-instruction bound.
+    // Holding the next plane's loads in registers one layer ahead was measured too: 115 -> 156 VGPRs, 8-17 % slower.
     struct Pending { int z; };
     auto issue_plane = [&](int z, Pending& pd) { pd.z = z; };
     auto plane_stage = [&](Pending& pd, PlaneState3D<NGP, E>& S) {
         const int z = min(pd.z, p.nz - 1);
         float ru[2][NW + 1], rn[2][NW + 1], rf[2][NW + 1];
         BcRaw<NW> braw[2];
+        uint8_t m8[2][2][NW + 1];
         unsigned rowoff[2];
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
@@ -219,9 +241,32 @@ __global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(cons
             load_seg<NW, VEC>(sb.u, rowoff[jb], x0, p.nx, ru[jb]);
             if constexpr (HAS_NU) load_seg<NW, VEC>(sb.nu, rowoff[jb], x0, p.nx, rn[jb]);
             if constexpr (HAS_F) load_seg<NW, VEC>(sb.f, rowoff[jb], x0, p.nx, rf[jb]);
-            if constexpr (BC_ANY) bc_issue<NW, VEC>(p, sb, rowoff[jb], x0, braw[jb]);
+            if constexpr (BC_U8C) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (sb.mask[k] != nullptr) load_seg<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff[jb], x0, p.nx, m8[jb][k]);
+            } else if constexpr (BC_ANY) {
+                bc_issue<NW, VEC>(p, sb, rowoff[jb], x0, braw[jb]);
+            }
         }
-        if constexpr (BC_ANY) {
+        if constexpr (BC_U8C) {            // uint8 masks, constant values: one compare + select per node and condition
+#pragma unroll
+            for (int n = 0; n < NW; ++n) S.keep[n] = 1.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (sb.mask[k] != nullptr) {
+                    const float val = p.bc[k].value;
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                        for (int n = 0; n <= NW; ++n) {
+                            const bool set = m8[jb][k][n] != 0;
+                            ru[jb][n] = set ? val : ru[jb][n];
+                            if (jb == 0 && n < NW) S.keep[n] = set ? 0.f : S.keep[n];
+                        }
+                }
+            }
+        } else if constexpr (BC_ANY) {
             float k1[NW];
             bc_apply<NW>(p, sb, braw[0], ru[0], S.keep);
             bc_apply<NW>(p, sb, braw[1], ru[1], k1);
@@ -365,6 +410,26 @@ __global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(cons
 #ifdef DN_3D_TILE
     __syncthreads();                       // every thread has read the first tile before it is overwritten
 #endif
+#if DN_NGP == 2 && !defined(DN_NO_PINGPONG3D)
+    // two layers per trip with the roles of the two plane states swapped: no state copy at the end of a layer
+    // (-1..3 % at 2x2x2 points; the larger rules do not have the registers for the doubled loop body)
+    {
+        int ez = ez_begin;
+        for (; ez + 1 < ez_end; ez += 2) {
+            plane_stage(pd, SB);
+            issue_plane(ez + 2, pd);
+            layer(ez, SA, SB);
+            plane_stage(pd, SA);
+            issue_plane(ez + 3, pd);
+            layer(ez + 1, SB, SA);
+        }
+        if (ez < ez_end) {
+            plane_stage(pd, SB);
+            layer(ez, SA, SB);
+            SA = SB;
+        }
+    }
+#else
     for (int ez = ez_begin; ez < ez_end; ++ez) {
 #if DN_PRIO_ROT3D
         switch ((ez_end - ez) & 3) {       // progress-dependent wave priority (see the 2-D kernel)
@@ -384,6 +449,7 @@ __global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(cons
         issue_plane(ez + 2, pd);
 #endif
     }
+#endif
     if (ez_end == p.nelz) {       // the last strip owns the top boundary plane: only the layer below contributes
         float o[2][NW + 1];
 #pragma unroll
@@ -402,15 +468,34 @@ __global__ void __launch_bounds__(256, DN_Q1_3D_WAVES) poisson3d_q1m_kernel(cons
 // ---- dispatch ---------------------------------------------------------------------------------------------
 template <int NGP, int E, bool VEC, int FL>
 static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
-    hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL>), dim3(g.chunks * g.tiles, g.strips, batch), dim3(g.TX, g.TY), 0, s, pp,
-                       g.chunks);
+    const dim3 grid((unsigned)((long long)g.chunks * g.tiles * g.strips * batch)), block(g.TX, g.TY);
+    if constexpr (NGP == 2 && E == 2) {       // the big-workgroup builds exist where the register budget allows them
+        if (g.TX * g.TY > 512) {
+            hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL, 1024>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+            return;
+        }
+        if (g.TX * g.TY > 256) {
+            hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL, 512>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL, 256>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
 }
 
 template <int NGP, int E, bool VEC>
 static void launch3_flags(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
     const int f = pp.fgp ? 2 : (pp.f ? 1 : 0);
     const bool bc = pp.bc[0].mask || pp.bc[1].mask;
-#define DN_L3(FLAGS) (bc ? launch3_one<NGP, E, VEC, (FLAGS) | FL3_BC>(pp, g, batch, s) : launch3_one<NGP, E, VEC, (FLAGS)>(pp, g, batch, s))
+    bool u8c = bc;
+    for (int k = 0; k < 2; ++k)
+        if (pp.bc[k].mask && (!pp.bc[k].mask_is_u8 || pp.bc[k].field)) u8c = false;
+#ifdef DN_3D_TILE
+    u8c = false;
+#endif
+#define DN_L3(FLAGS)                                                                   \
+    (!bc ? launch3_one<NGP, E, VEC, (FLAGS)>(pp, g, batch, s)                          \
+         : u8c ? launch3_one<NGP, E, VEC, (FLAGS) | FL3_BC_U8C>(pp, g, batch, s)       \
+               : launch3_one<NGP, E, VEC, (FLAGS) | FL3_BC>(pp, g, batch, s))
     if (pp.nu) {
         if (f == 0) DN_L3(FL3_NU);
         else if (f == 1) DN_L3(FL3_NU | FL3_F);

@@ -240,7 +240,8 @@ static Geom3D plan3d_env(const dn_mesh* m) {
     Geom3D g = plan3d(m);
     const char* e = getenv("DN_PLAN3D");
     int TX, TY, E, R;
-    if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY <= 256 && TX * TY >= 64 && (E == 1 || (E == 2 && m->ngp == 2)) && R >= 1) {
+    if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY >= 64 && (E == 1 || (E == 2 && m->ngp == 2)) && R >= 1 &&
+        TX * TY <= ((E == 2 && m->ngp == 2) ? 1024 : 256)) {
         const int nelz = m->nz - 1;
         g.TX = TX; g.TY = TY; g.E = E; g.R = R > nelz ? nelz : R;
         g.chunks = chunks_for((m->nx - 1) / E + 1, TX);
@@ -344,6 +345,7 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     };
     const bool allow_e4 = vec_ok(4);
     const long long nwg = num_workgroups(m, allow_e4);
+    if (nwg >= (1ll << 31)) return DN_E_UNSUPPORTED;                  // the 3-D launch is a 1-D grid
     if (want_red && (!a->workspace || a->workspace_bytes < DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
     if ((int64_t)m->nx * m->ny * (m->nsd == 3 ? m->nz : 1) >= (1ll << 30)) return DN_E_UNSUPPORTED;   // 32-bit in-sample offsets
 
