@@ -229,7 +229,11 @@ __global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_
     struct Pending { int z; };
     auto issue_plane = [&](int z, Pending& pd) { pd.z = z; };
     auto plane_stage = [&](Pending& pd, PlaneState3D<NGP, E>& S) {
+#ifndef DN_ABLATE_MEM3D
         const int z = min(pd.z, p.nz - 1);
+#else                                      // timing experiment only: every plane re-reads the strip's first plane (cache hits)
+        const int z = ez_begin;
+#endif
         float ru[2][NW + 1], rn[2][NW + 1], rf[2][NW + 1];
         BcRaw<NW> braw[2];
         uint8_t m8[2][2][NW + 1];
@@ -332,11 +336,13 @@ __global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_
 
     // Emit node plane z, row ey, nodes x0..x0+E-1 from o (+ the neighbours' hand-overs).
     auto emit_plane = [&](const float (&o)[2][NW + 1], const float (&keep)[NW], int z, bool owned_plane) {
+#ifndef DN_ABLATE_XCH3D                    // timing experiment only: drop the neighbour hand-over and its barrier
         xch[par][0][tid] = o[0][NW];
 #pragma unroll
         for (int n = 0; n < NW; ++n) xch[par][1 + n][tid] = o[1][n];
         xch[par][NW + 1][tid] = o[1][NW];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         if (owned_plane && owner && noderow_ok) {
             float v[NW];
 #pragma unroll
@@ -351,7 +357,11 @@ __global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_
                 sq_acc = fmaf(t, t, sq_acc);
                 v[n] = t * p.out_scale;
             }
+#ifndef DN_ABLATE_STORE3D
             if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)z * npl + (unsigned)ey * (unsigned)p.nx, x0, p.nx, v);
+#else
+            if (sb.out && v[0] == 123.456f) store_seg<NW, VEC>(sb.out, (unsigned)z * npl + (unsigned)ey * (unsigned)p.nx, x0, p.nx, v);
+#endif
         }
         par ^= 1;
     };
