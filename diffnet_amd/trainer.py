@@ -1,7 +1,12 @@
 """Minimal fit loop for `PDE` modules where pytorch_lightning is not installed (it is absent on the build and GPU
 boxes).  It drives exactly the hooks the reference scripts implement -- `configure_optimizers`, `training_step`
 (tensor or {"loss": tensor}), optional `validation_step`, callbacks with `on_train_epoch_end(trainer, module)` -- and
-nothing else; checkpointing, loggers and DDP remain Lightning's job when it is available."""
+nothing else; checkpointing, loggers and DDP remain Lightning's job when it is available.
+
+`Trainer(graph=True)`: for full-batch problems (one static batch, the shape of the reference's single-instance examples)
+the whole iteration -- forward, fused loss kernel, backward, optimizer update -- is captured once into a HIP graph and
+replayed, so a step costs one graph launch instead of ~50 kernel launches from Python (the small meshes of
+BASELINE configs[0] are launch-bound: tools/bench_graph.py)."""
 import torch
 
 
@@ -14,8 +19,9 @@ def _to(batch, device):
 
 
 class Trainer:
-    def __init__(self, max_epochs=1, device=None, callbacks=(), max_steps=None):
+    def __init__(self, max_epochs=1, device=None, callbacks=(), max_steps=None, graph=False, graph_warmup=3, log_every=1):
         self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.graph, self.graph_warmup, self.log_every = graph, graph_warmup, max(1, log_every)
         self.device = torch.device(device) if device is not None else torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
         self.callbacks = list(callbacks)
         self.current_epoch = 0
@@ -26,11 +32,62 @@ class Trainer:
     def _loss_of(out):
         return out["loss"] if isinstance(out, dict) else out
 
+    def _fit_graph(self, module, batch, opts):
+        """max_epochs iterations on one static batch; iterations after the warm-up are replays of one captured graph."""
+        if self.device.type != "cuda":
+            raise RuntimeError("Trainer(graph=True) needs a GPU")
+        if any(isinstance(o, torch.optim.LBFGS) for o in opts):
+            raise ValueError("Trainer(graph=True): closure-driven optimizers (LBFGS) re-evaluate a data-dependent number of times "
+                             "and cannot be captured; use Adam/SGD or graph=False")
+        batch = _to(batch, self.device)
+        for o in opts:
+            for grp in o.param_groups:
+                if "capturable" in grp:
+                    grp["capturable"] = True       # optimizer state (step counters) lives on the device
+
+        def iteration():
+            loss = None
+            for o in opts:
+                o.zero_grad(set_to_none=False)
+                loss = self._loss_of(module.training_step(batch, 0))
+                loss.backward()
+                o.step()
+            return loss
+
+        total = self.max_epochs if self.max_steps is None else min(self.max_epochs, self.max_steps)
+        module.train()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):              # warm-up iterations are ordinary training steps (allocations, autotuning)
+            for _ in range(min(self.graph_warmup, total)):
+                self.history.append(float(iteration().detach()))
+                self.global_step += 1
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        if self.global_step >= total:
+            return self
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_loss = iteration()
+        # the capture itself does not execute; every replay is one full iteration
+        while self.global_step < total:
+            g.replay()
+            self.global_step += 1
+            if self.global_step % self.log_every == 0 or self.global_step == total:
+                self.history.append(float(static_loss.detach()))
+        self.current_epoch = module.current_epoch = total - 1
+        self._graph = g
+        return self
+
     def fit(self, module, train_dataloaders, val_dataloaders=None):
         module.to(self.device)
         conf = module.configure_optimizers()
         opts, scheds = conf if isinstance(conf, tuple) else (conf, [])
         opts = list(opts) if isinstance(opts, (list, tuple)) else [opts]
+        if self.graph:
+            batches = list(train_dataloaders)
+            if len(batches) != 1 or scheds or val_dataloaders is not None or self.callbacks:
+                raise ValueError("Trainer(graph=True) captures ONE static iteration: a single batch, no schedulers / validation / callbacks")
+            return self._fit_graph(module, batches[0], opts)
         for epoch in range(self.max_epochs):
             self.current_epoch = module.current_epoch = epoch
             module.train()
@@ -43,7 +100,7 @@ class Trainer:
                         loss.backward()
                         return loss
                     loss = opt.step(closure)
-                self.history.append(float(loss))
+                self.history.append(float(loss.detach()))
                 self.global_step += 1
                 if self.max_steps is not None and self.global_step >= self.max_steps:
                     return self

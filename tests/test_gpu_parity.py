@@ -591,3 +591,31 @@ def test_fsdt_fused_full_size_q2_strips_and_chunks():
         del os.environ["DN_PLAN_FSDT"]
     for x, y in zip(Ka, Ka2):
         assert torch.equal(x, y)
+
+
+def test_graph_captured_training_iteration_matches_eager():
+    """Trainer(graph=True): the captured iteration (fused loss kernel through the C ABI + backward + Adam) replays to
+    exactly the parameters and losses of the eager loop with the same (capturable) optimizer."""
+    from torch import nn
+    from diffnet_amd import DiffNet2DFEM
+    from diffnet_amd.trainer import Trainer
+
+    class P(DiffNet2DFEM):
+        def training_step(self, batch, idx):
+            nu, f, bc = batch
+            return self.energy_loss(self.network[0], nu, f, dirichlet=[(bc, 0.0)], c=0.5)
+
+        def configure_optimizers(self):
+            return [torch.optim.Adam(self.network.parameters(), lr=1e-3, capturable=True)], []
+
+    n, outs = 33, {}
+    for graph in (False, True):
+        net = nn.ParameterList([nn.Parameter(torch.zeros(1, 1, n, n))])
+        m = P(net, domain_size=n, ngp_1d=2)
+        batch = (seeded((1, 1, n, n), 5, lo=0.5), seeded((1, 1, n, n), 6), boundary_mask((1, 1, n, n)))
+        tr = Trainer(max_epochs=40, graph=graph, device=dev()).fit(m, [batch])
+        outs[graph] = (m.network[0].detach().clone(), tr.history)
+    assert len(outs[True][1]) == len(outs[False][1]) == 40
+    assert outs[True][1] == outs[False][1]
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert np.isfinite(outs[True][1]).all() and outs[True][1][-1] != outs[True][1][0]
