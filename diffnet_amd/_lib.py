@@ -68,6 +68,11 @@ SYMBOLS = {
                                      C.c_float, C.c_float, C.c_void_p]),
     "dn_fsdt_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
     "dn_fsdt_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnFsdtArgs), C.c_void_p]),
+    "dn_upconv_out_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "dn_upconv_out_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int,
+                                    C.c_void_p, C.c_int64, C.c_void_p]),
+    "dn_upconv_out_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "dn_instnorm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "dn_instnorm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                       C.c_void_p, C.c_int64, C.c_void_p]),

@@ -1,0 +1,263 @@
+// Fused output block of the 2-D U-Net generator: Upsample(x2, nearest) -> ZeroPad2d((1,0,1,0)) -> Conv2d(C -> 1, 4x4,
+// padding 1, bias) -> Sigmoid  (reference DiffNet/networks/unets.py:68-74, `self.final`), forward and both backward
+// passes.  torch materialises the upsampled (B, C, 2h, 2w) tensor and its padded copy (4.3 GB each at C = 64, 512^2,
+// B = 64) and runs a C -> 1 convolution on it; that block is ~60 % of a U-Net training step on MI355X
+// (profiles/r1_unet_step_*.csv).  Here the low-resolution input is read once.
+//
+// With U[y][x] = in[y >> 1][x >> 1] (zero outside), the block is  z[Y][X] = b + sum_c sum_{ky,kx} W[c][ky][kx] U[c][Y+ky-2][X+kx-2].
+// Output row Y = 2i + a reads low-resolution rows  a = 0: {i-1: ky 0,1; i: ky 2,3},  a = 1: {i-1: ky 0; i: ky 1,2; i+1: ky 3},
+// so the 2 x 2 outputs of low-resolution pixel (i, j) need the 3 x 3 neighbourhood of `in` and 25 instead of 64 MACs per
+// channel (taps that fall on the same low-resolution pixel are pre-summed: `weff`, 25 floats per channel).  Transposed:
+// in[i] feeds output rows 2i-1 .. 2i+3 with row-tap sets {3}, {2,3}, {1,2}, {0,1}, {0}  ->  5 x 5 backward weights.
+#include "dn_common.h"
+
+namespace dn {
+
+// forward effective weights [C][25]: phase (0,0) 2x2 | (0,1) 2x3 | (1,0) 3x2 | (1,1) 3x3, neighbour offsets -1..+1
+// backward effective weights [C][25]: [dy][dx], gradient rows 2i-1+dy, columns 2j-1+dx
+__global__ void upconv_weff_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float W[4][4];
+    for (int ky = 0; ky < 4; ++ky)
+        for (int kx = 0; kx < 4; ++kx) W[ky][kx] = w[(c * 4 + ky) * 4 + kx];
+    // row groups per phase: a = 0: {0,1},{2,3};  a = 1: {0},{1,2},{3}
+    auto rsum = [&](int a, int g, int kx) {
+        if (a == 0) return g == 0 ? W[0][kx] + W[1][kx] : W[2][kx] + W[3][kx];
+        return g == 0 ? W[0][kx] : (g == 1 ? W[1][kx] + W[2][kx] : W[3][kx]);
+    };
+    auto tap = [&](int a, int gy, int b, int gx) {
+        if (b == 0) return gx == 0 ? rsum(a, gy, 0) + rsum(a, gy, 1) : rsum(a, gy, 2) + rsum(a, gy, 3);
+        return gx == 0 ? rsum(a, gy, 0) : (gx == 1 ? rsum(a, gy, 1) + rsum(a, gy, 2) : rsum(a, gy, 3));
+    };
+    float* o = wf + c * 25;
+    int n = 0;
+    for (int gy = 0; gy < 2; ++gy) for (int gx = 0; gx < 2; ++gx) o[n++] = tap(0, gy, 0, gx);
+    for (int gy = 0; gy < 2; ++gy) for (int gx = 0; gx < 3; ++gx) o[n++] = tap(0, gy, 1, gx);
+    for (int gy = 0; gy < 3; ++gy) for (int gx = 0; gx < 2; ++gx) o[n++] = tap(1, gy, 0, gx);
+    for (int gy = 0; gy < 3; ++gy) for (int gx = 0; gx < 3; ++gx) o[n++] = tap(1, gy, 1, gx);
+    // backward: row-tap sets for dy = 0..4 (gradient row 2i-1+dy): {3},{2,3},{1,2},{0,1},{0}
+    const int lo[5] = {3, 2, 1, 0, 0}, hi[5] = {3, 3, 2, 1, 0};
+    float* ob = wb + c * 25;
+    for (int dy = 0; dy < 5; ++dy)
+        for (int dx = 0; dx < 5; ++dx) {
+            float s = 0.f;
+            for (int ky = lo[dy]; ky <= hi[dy]; ++ky)
+                for (int kx = lo[dx]; kx <= hi[dx]; ++kx) s += W[ky][kx];
+            ob[dy * 5 + dx] = s;
+        }
+}
+
+__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + __expf(-z)); }
+
+// One thread per low-resolution pixel: 3 x 3 neighbourhood per channel from global memory (neighbouring lanes share
+// the lines: L1 hits), weights through scalar loads (uniform index), 2 x 2 outputs.
+__global__ void __launch_bounds__(256) upconv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wf,
+                                                         const float* __restrict__ bias_ptr, float* __restrict__ out, int C, int h, int w,
+                                                         int act) {
+    const float bias = bias_ptr ? bias_ptr[0] : 0.f;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (j >= w || i >= h) return;
+    const size_t plane = (size_t)h * w;
+    const float* ib = in + (size_t)b * C * plane;
+    const int im = i > 0 ? i - 1 : i, ip = i < h - 1 ? i + 1 : i, jm = j > 0 ? j - 1 : j, jp = j < w - 1 ? j + 1 : j;
+    const float zt = i > 0 ? 1.f : 0.f, zb = i < h - 1 ? 1.f : 0.f, zl = j > 0 ? 1.f : 0.f, zr = j < w - 1 ? 1.f : 0.f;   // zero padding
+    const unsigned o00 = im * w + jm, o01 = im * w + j, o02 = im * w + jp, o10 = i * w + jm, o11 = i * w + j, o12 = i * w + jp,
+                   o20 = ip * w + jm, o21 = ip * w + j, o22 = ip * w + jp;
+    float z00 = bias, z01 = bias, z10 = bias, z11 = bias;
+    for (int c = 0; c < C; ++c) {
+        const float* p = ib + (size_t)c * plane;
+        const float* k = wf + c * 25;
+        const float v00 = p[o00] * (zt * zl), v01 = p[o01] * zt, v02 = p[o02] * (zt * zr);
+        const float v10 = p[o10] * zl, v11 = p[o11], v12 = p[o12] * zr;
+        const float v20 = p[o20] * (zb * zl), v21 = p[o21] * zb, v22 = p[o22] * (zb * zr);
+        z00 += k[0] * v00 + k[1] * v01 + k[2] * v10 + k[3] * v11;
+        z01 += k[4] * v00 + k[5] * v01 + k[6] * v02 + k[7] * v10 + k[8] * v11 + k[9] * v12;
+        z10 += k[10] * v00 + k[11] * v01 + k[12] * v10 + k[13] * v11 + k[14] * v20 + k[15] * v21;
+        z11 += k[16] * v00 + k[17] * v01 + k[18] * v02 + k[19] * v10 + k[20] * v11 + k[21] * v12 + k[22] * v20 + k[23] * v21 + k[24] * v22;
+    }
+    if (act) { z00 = sigmoidf(z00); z01 = sigmoidf(z01); z10 = sigmoidf(z10); z11 = sigmoidf(z11); }
+    float* ob = out + (size_t)b * 4 * plane + (size_t)(2 * i) * (2 * w) + 2 * j;
+    *reinterpret_cast<float2*>(ob) = make_float2(z00, z01);
+    *reinterpret_cast<float2*>(ob + 2 * w) = make_float2(z10, z11);
+}
+
+// gz = gout * y (1 - y) (sigmoid) or gout, zero outside the image
+__device__ __forceinline__ float gz_at(const float* __restrict__ g, const float* __restrict__ y, int Y, int X, int H, int W, int act) {
+    if (Y < 0 || Y >= H || X < 0 || X >= W) return 0.f;
+    const float gv = g[(size_t)Y * W + X];
+    if (!act) return gv;
+    const float yv = y[(size_t)Y * W + X];
+    return gv * yv * (1.f - yv);
+}
+
+// grad wrt the low-resolution input: one thread per pixel, the 5 x 5 gradient patch in registers, loop over channels.
+__global__ void __launch_bounds__(256) upconv_bwd_data_kernel(const float* __restrict__ gout, const float* __restrict__ y,
+                                                              const float* __restrict__ wb, float* __restrict__ gin, int C, int h, int w,
+                                                              int act) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (j >= w || i >= h) return;
+    const int H = 2 * h, W = 2 * w;
+    const float* gb = gout + (size_t)b * H * W;
+    const float* yb = y ? y + (size_t)b * H * W : nullptr;
+    float G[25];
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) G[dy * 5 + dx] = gz_at(gb, yb, 2 * i - 1 + dy, 2 * j - 1 + dx, H, W, act);
+    const size_t plane = (size_t)h * w;
+    float* ob = gin + (size_t)b * C * plane + (size_t)i * w + j;
+    for (int c = 0; c < C; ++c) {
+        const float* k = wb + c * 25;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) s = fmaf(k[t], G[t], s);
+        ob[(size_t)c * plane] = s;
+    }
+}
+
+// grad wrt the 4 x 4 x C weights and the bias.  gW[c][ky][kx] = sum_p in[c][p] * S[ky][kx][p] with S the 2 x 2 box sum of gz at
+// rows 2i+2-ky .. +1, columns 2j+2-kx .. +1.  A workgroup walks its share of the pixels 256 at a time: every thread
+// computes the 16 box sums of its pixel into LDS and stages `in` for CCH channels, then thread (c, tap quad) accumulates
+// 4 outputs over the 256 pixels.  Per-workgroup partials are summed in index order by upconv_wsum_kernel.
+constexpr int UC_CCH = 64;      // channels staged per pass
+__global__ void __launch_bounds__(256) upconv_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                                const float* __restrict__ y, float* __restrict__ part, int B, int C, int h,
+                                                                int w, int act, int tiles_per_wg) {
+    __shared__ __attribute__((aligned(16))) float S[256][20];      // [pixel][tap], rows padded to 80 B (float4 reads)
+    __shared__ float V[UC_CCH][257];        // [channel][pixel]
+    const int tid = threadIdx.x;
+    const int H = 2 * h, W = 2 * w;
+    const size_t plane = (size_t)h * w;
+    const long npix = (long)B * h * w;
+    const int nc_pass = (C + UC_CCH - 1) / UC_CCH;
+    // thread roles in the accumulation phase: channel cc = tid / 4 (0..63), taps 4 * (tid % 4) .. +3
+    const int cc = tid >> 2, t4 = (tid & 3) * 4;
+    float bias_acc = 0.f;
+    float* pw = part + (size_t)blockIdx.x * (C * 16 + 1);
+    for (int pass = 0; pass < nc_pass; ++pass) {
+        const int c0 = pass * UC_CCH;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < tiles_per_wg; ++t) {
+            const long p = ((long)blockIdx.x * tiles_per_wg + t) * 256 + tid;
+            const bool ok = p < npix;
+            int b = 0, i = 0, j = 0;
+            if (ok) { b = (int)(p / plane); const int r = (int)(p % plane); i = r / w; j = r % w; }
+            __syncthreads();
+            {   // box sums of this thread's pixel
+                float G[25];
+                const float* gb = gout + (size_t)b * H * W;
+                const float* yb = y ? y + (size_t)b * H * W : nullptr;
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 5; ++dx) G[dy * 5 + dx] = ok ? gz_at(gb, yb, 2 * i - 1 + dy, 2 * j - 1 + dx, H, W, act) : 0.f;
+                // rows 2i+2-ky, 2i+3-ky  ->  patch rows dy = 3-ky, 4-ky
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const int dy = 3 - ky, dx = 3 - kx;
+                        S[tid][ky * 4 + kx] = (G[dy * 5 + dx] + G[dy * 5 + dx + 1]) + (G[(dy + 1) * 5 + dx] + G[(dy + 1) * 5 + dx + 1]);
+                    }
+                if (pass == 0) bias_acc += (G[1 * 5 + 1] + G[1 * 5 + 2]) + (G[2 * 5 + 1] + G[2 * 5 + 2]);   // rows 2i, 2i+1
+            }
+            const float* ib = in + (size_t)b * C * plane + (size_t)i * w + j;
+            for (int c = 0; c < UC_CCH; ++c) V[c][tid] = (ok && c0 + c < C) ? ib[(size_t)(c0 + c) * plane] : 0.f;
+            __syncthreads();
+#pragma unroll 8
+            for (int q = 0; q < 256; ++q) {
+                const float v = V[cc][q];
+                const float4 sv = *reinterpret_cast<const float4*>(&S[q][t4]);
+                acc[0] = fmaf(v, sv.x, acc[0]);
+                acc[1] = fmaf(v, sv.y, acc[1]);
+                acc[2] = fmaf(v, sv.z, acc[2]);
+                acc[3] = fmaf(v, sv.w, acc[3]);
+            }
+        }
+        if (c0 + cc < C) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pw[(c0 + cc) * 16 + t4 + k] = acc[k];
+        }
+    }
+    __shared__ double red[8];
+    const double bs = block_sum((double)bias_acc, red, tid, 256);
+    if (tid == 0) pw[C * 16] = (float)bs;
+}
+
+__global__ void upconv_wsum_kernel(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gbias, int nwg, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n) return;                          // k == n: the bias entry
+    double s = 0.0;
+    for (int g = 0; g < nwg; ++g) s += (double)part[(size_t)g * (n + 1) + k];
+    if (k < n) gw[k] = (float)s;
+    else if (gbias) *gbias = (float)s;
+}
+
+static int uc_plan(int64_t npix, int& nwg, int& tiles_per_wg) {
+    const int64_t tiles = (npix + 255) / 256;
+    int64_t want = 2048;                       // ~8 workgroups per CU
+    if (want > tiles) want = tiles;
+    tiles_per_wg = (int)((tiles + want - 1) / want);
+    nwg = (int)((tiles + tiles_per_wg - 1) / tiles_per_wg);
+    return 0;
+}
+
+}  // namespace dn
+
+using namespace dn;
+
+static int uc_check(int64_t B, int64_t C, int64_t h, int64_t w) {
+    if (B < 1 || C < 1 || h < 1 || w < 1 || B > 65535 || C > 4096 || h > 32768 || w > 32768) return DN_E_BADARG;
+    if (B * C * h * w >= (1ll << 40)) return DN_E_UNSUPPORTED;
+    return 0;
+}
+
+extern "C" int64_t dn_upconv_out_workspace_bytes(int64_t B, int64_t C, int64_t h, int64_t w) {
+    if (uc_check(B, C, h, w)) return DN_E_BADARG;
+    int nwg, tpw;
+    uc_plan(B * h * w, nwg, tpw);
+    return (int64_t)sizeof(float) * (2 * C * 25 + (int64_t)nwg * (C * 16 + 1));
+}
+
+extern "C" int dn_upconv_out_fwd(const float* in, const float* weight, const float* bias, float* out, int64_t B, int64_t C, int64_t h,
+                                 int64_t w, int act, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (int rc = uc_check(B, C, h, w)) return rc;
+    if (!in || !weight || !out || !workspace || workspace_bytes < dn_upconv_out_workspace_bytes(B, C, h, w)) return DN_E_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* wf = static_cast<float*>(workspace);
+    float* wb = wf + C * 25;
+    hipLaunchKernelGGL(upconv_weff_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, weight, wf, wb, (int)C);
+    hipLaunchKernelGGL(upconv_fwd_kernel, dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)B), dim3(256), 0, s, in, wf, bias,
+                       out, (int)C, (int)h, (int)w, act);
+    DN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dn_upconv_out_bwd(const float* in, const float* weight, const float* out, const float* grad_out, float* grad_in,
+                                 float* grad_weight, float* grad_bias, int64_t B, int64_t C, int64_t h, int64_t w, int act, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+    if (int rc = uc_check(B, C, h, w)) return rc;
+    if (!weight || !grad_out || (act && !out)) return DN_E_BADARG;
+    if (!workspace || workspace_bytes < dn_upconv_out_workspace_bytes(B, C, h, w)) return DN_E_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* wf = static_cast<float*>(workspace);
+    float* wb = wf + C * 25;
+    float* part = wb + C * 25;
+    if (grad_in) {
+        hipLaunchKernelGGL(upconv_weff_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, weight, wf, wb, (int)C);
+        hipLaunchKernelGGL(upconv_bwd_data_kernel, dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)B), dim3(256), 0, s, grad_out,
+                           act ? out : nullptr, wb, grad_in, (int)C, (int)h, (int)w, act);
+    }
+    if (grad_weight) {
+        if (!in) return DN_E_BADARG;
+        int nwg, tpw;
+        uc_plan(B * h * w, nwg, tpw);
+        hipLaunchKernelGGL(upconv_bwd_weight_kernel, dim3((unsigned)nwg), dim3(256), 0, s, in, grad_out, act ? out : nullptr, part, (int)B, (int)C,
+                           (int)h, (int)w, act, tpw);
+        const int n = (int)C * 16;
+        hipLaunchKernelGGL(upconv_wsum_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, part, grad_weight, grad_bias, nwg, n);
+    }
+    DN_LAUNCH_CHECK();
+    return 0;
+}

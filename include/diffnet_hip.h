@@ -166,6 +166,20 @@ typedef struct dn_fsdt_args {
 int64_t dn_fsdt_workspace_bytes(const dn_mesh *mesh);
 int dn_fsdt_apply(const dn_mesh *mesh, const dn_fsdt_args *args, void *stream);
 
+/* ---- fused output block of the 2-D U-Net generator ----------------------------------------------------------
+ * Upsample(x2, nearest) -> ZeroPad2d((1,0,1,0)) -> Conv2d(C -> 1, 4x4, padding 1, bias) -> Sigmoid
+ * (DiffNet/networks/unets.py:68-74, `self.final`) without materialising the upsampled tensor.
+ *   in (B,C,h,w), weight (1,C,4,4), bias (1) device pointer or NULL, out / grad_out (B,1,2h,2w); act: 1 = sigmoid, 0 = none.
+ * bwd: grad_in (B,C,h,w), grad_weight (1,C,4,4), grad_bias (1); any of the three may be NULL (grad_bias needs
+ * grad_weight).  `out` is the forward result (needed when act = 1).  workspace: dn_upconv_out_workspace_bytes, no
+ * initialisation required.  Weight-gradient partial sums are combined in a fixed order (bitwise repeatable). */
+int64_t dn_upconv_out_workspace_bytes(int64_t B, int64_t C, int64_t h, int64_t w);
+int dn_upconv_out_fwd(const float *in, const float *weight, const float *bias, float *out, int64_t B, int64_t C, int64_t h,
+                      int64_t w, int act, void *workspace, int64_t workspace_bytes, void *stream);
+int dn_upconv_out_bwd(const float *in, const float *weight, const float *out, const float *grad_out, float *grad_in,
+                      float *grad_weight, float *grad_bias, int64_t B, int64_t C, int64_t h, int64_t w, int act, void *workspace,
+                      int64_t workspace_bytes, void *stream);
+
 /* Fused InstanceNorm (affine = False, biased variance) + LeakyReLU/ReLU of the generator blocks
  * (DiffNet/networks/unets.py:13-45, autoencoders.py:7-70, wgan3d.py:23-55): x, y (n_inst, spatial) contiguous with
  * n_inst = B*C; mean, rstd (n_inst) are written by fwd and consumed by bwd.  slope: 0 = ReLU, 0.2 = LeakyReLU(0.2),
