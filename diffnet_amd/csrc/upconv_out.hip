@@ -121,30 +121,35 @@ __global__ void __launch_bounds__(256) upconv_bwd_data_kernel(const float* __res
 // computes the 16 box sums of its pixel into LDS and stages `in` for CCH channels, then thread (c, tap quad) accumulates
 // 4 outputs over the 256 pixels.  Per-workgroup partials are summed in index order by upconv_wsum_kernel.
 constexpr int UC_CCH = 64;      // channels staged per pass
+constexpr int UC_TP = 128;      // pixels per tile (44 KB of LDS per workgroup: three workgroups per CU)
 __global__ void __launch_bounds__(256) upconv_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                                 const float* __restrict__ y, float* __restrict__ part, int B, int C, int h,
                                                                 int w, int act, int tiles_per_wg) {
-    __shared__ __attribute__((aligned(16))) float S[256][20];      // [pixel][tap], rows padded to 80 B (float4 reads)
-    __shared__ float V[UC_CCH][257];        // [channel][pixel]
+    __shared__ __attribute__((aligned(16))) float S[UC_TP][20];      // [pixel][tap], rows padded to 80 B (float4 reads)
+    __shared__ float V[UC_CCH][UC_TP + 1];                            // [channel][pixel]
+    __shared__ double red[8];
     const int tid = threadIdx.x;
     const int H = 2 * h, W = 2 * w;
     const size_t plane = (size_t)h * w;
     const long npix = (long)B * h * w;
     const int nc_pass = (C + UC_CCH - 1) / UC_CCH;
-    // thread roles in the accumulation phase: channel cc = tid / 4 (0..63), taps 4 * (tid % 4) .. +3
+    // staging roles: pixel pp = tid % 128, channel parity half = tid / 128; accumulation roles: channel cc = tid / 4,
+    // taps 4 * (tid % 4) .. +3
+    const int pp = tid & (UC_TP - 1), half = tid >> 7;
     const int cc = tid >> 2, t4 = (tid & 3) * 4;
     float bias_acc = 0.f;
-    float* pw = part + (size_t)blockIdx.x * (C * 16 + 1);
+    const size_t nwg = gridDim.x;
+    float* pw = part + blockIdx.x;             // partials are stored [output][workgroup]
     for (int pass = 0; pass < nc_pass; ++pass) {
         const int c0 = pass * UC_CCH;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < tiles_per_wg; ++t) {
-            const long p = ((long)blockIdx.x * tiles_per_wg + t) * 256 + tid;
+            const long p = ((long)blockIdx.x * tiles_per_wg + t) * UC_TP + pp;
             const bool ok = p < npix;
             int b = 0, i = 0, j = 0;
             if (ok) { b = (int)(p / plane); const int r = (int)(p % plane); i = r / w; j = r % w; }
             __syncthreads();
-            {   // box sums of this thread's pixel
+            if (half == 0) {   // box sums of this thread's pixel
                 float G[25];
                 const float* gb = gout + (size_t)b * H * W;
                 const float* yb = y ? y + (size_t)b * H * W : nullptr;
@@ -158,15 +163,16 @@ __global__ void __launch_bounds__(256) upconv_bwd_weight_kernel(const float* __r
 #pragma unroll
                     for (int kx = 0; kx < 4; ++kx) {
                         const int dy = 3 - ky, dx = 3 - kx;
-                        S[tid][ky * 4 + kx] = (G[dy * 5 + dx] + G[dy * 5 + dx + 1]) + (G[(dy + 1) * 5 + dx] + G[(dy + 1) * 5 + dx + 1]);
+                        S[pp][ky * 4 + kx] = (G[dy * 5 + dx] + G[dy * 5 + dx + 1]) + (G[(dy + 1) * 5 + dx] + G[(dy + 1) * 5 + dx + 1]);
                     }
                 if (pass == 0) bias_acc += (G[1 * 5 + 1] + G[1 * 5 + 2]) + (G[2 * 5 + 1] + G[2 * 5 + 2]);   // rows 2i, 2i+1
             }
             const float* ib = in + (size_t)b * C * plane + (size_t)i * w + j;
-            for (int c = 0; c < UC_CCH; ++c) V[c][tid] = (ok && c0 + c < C) ? ib[(size_t)(c0 + c) * plane] : 0.f;
+#pragma unroll 8
+            for (int c = half; c < UC_CCH; c += 2) V[c][pp] = (ok && c0 + c < C) ? ib[(size_t)(c0 + c) * plane] : 0.f;
             __syncthreads();
 #pragma unroll 8
-            for (int q = 0; q < 256; ++q) {
+            for (int q = 0; q < UC_TP; ++q) {
                 const float v = V[cc][q];
                 const float4 sv = *reinterpret_cast<const float4*>(&S[q][t4]);
                 acc[0] = fmaf(v, sv.x, acc[0]);
@@ -177,26 +183,32 @@ __global__ void __launch_bounds__(256) upconv_bwd_weight_kernel(const float* __r
         }
         if (c0 + cc < C) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pw[(c0 + cc) * 16 + t4 + k] = acc[k];
+            for (int k = 0; k < 4; ++k) pw[(size_t)((c0 + cc) * 16 + t4 + k) * nwg] = acc[k];
         }
     }
-    __shared__ double red[8];
     const double bs = block_sum((double)bias_acc, red, tid, 256);
-    if (tid == 0) pw[C * 16] = (float)bs;
+    if (tid == 0) pw[(size_t)(C * 16) * nwg] = (float)bs;
 }
 
-__global__ void upconv_wsum_kernel(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gbias, int nwg, int n) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// Sum of the per-workgroup partials, one wave per output: lanes stride over the workgroups (partials are stored
+// [output][workgroup], so the reads are coalesced), fp64 accumulation, fixed butterfly order.
+__global__ void __launch_bounds__(256) upconv_wsum_kernel(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gbias,
+                                                          int nwg, int n) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k > n) return;                          // k == n: the bias entry
+    const float* pk = part + (size_t)k * nwg;
     double s = 0.0;
-    for (int g = 0; g < nwg; ++g) s += (double)part[(size_t)g * (n + 1) + k];
-    if (k < n) gw[k] = (float)s;
-    else if (gbias) *gbias = (float)s;
+    for (int g = lane; g < nwg; g += 64) s += (double)pk[g];
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (k < n) gw[k] = (float)s;
+        else if (gbias) *gbias = (float)s;
+    }
 }
 
 static int uc_plan(int64_t npix, int& nwg, int& tiles_per_wg) {
-    const int64_t tiles = (npix + 255) / 256;
-    int64_t want = 2048;                       // ~8 workgroups per CU
+    const int64_t tiles = (npix + UC_TP - 1) / UC_TP;
+    int64_t want = 3072;                       // 3 resident workgroups per CU x 4 rounds
     if (want > tiles) want = tiles;
     tiles_per_wg = (int)((tiles + want - 1) / want);
     nwg = (int)((tiles + tiles_per_wg - 1) / tiles_per_wg);
@@ -256,7 +268,7 @@ extern "C" int dn_upconv_out_bwd(const float* in, const float* weight, const flo
         hipLaunchKernelGGL(upconv_bwd_weight_kernel, dim3((unsigned)nwg), dim3(256), 0, s, in, grad_out, act ? out : nullptr, part, (int)B, (int)C,
                            (int)h, (int)w, act, tpw);
         const int n = (int)C * 16;
-        hipLaunchKernelGGL(upconv_wsum_kernel, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, part, grad_weight, grad_bias, nwg, n);
+        hipLaunchKernelGGL(upconv_wsum_kernel, dim3((unsigned)((n + 1 + 3) / 4)), dim3(256), 0, s, part, grad_weight, grad_bias, nwg, n);
     }
     DN_LAUNCH_CHECK();
     return 0;
