@@ -73,6 +73,11 @@ SYMBOLS = {
                                     C.c_void_p, C.c_int64, C.c_void_p]),
     "dn_upconv_out_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dn_upconv3d_out_workspace_bytes": (C.c_int64, [C.c_int64] * 5),
+    "dn_upconv3d_out_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                      C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dn_upconv3d_out_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "dn_instnorm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "dn_instnorm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                       C.c_void_p, C.c_int64, C.c_void_p]),

@@ -107,3 +107,47 @@ def upsample_pad_conv4(x, weight, bias=None, sigmoid=True):
         raise _lib.DiffNetHipError("upsample_pad_conv4: float32 CUDA tensors (B,C,h,w) and 4x4 weights only")
     outs = [_UpConvOut.apply(x, weight[co:co + 1], None if bias is None else bias[co:co + 1], sigmoid) for co in range(weight.shape[0])]
     return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
+
+
+class _UpConv3dOut(torch.autograd.Function):
+    """Upsample(x2) -> Conv3d(C -> 1, 3x3x3, padding 1) -> optional Sigmoid, one output channel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x, weight = x.contiguous(), weight.contiguous()
+        B, Cn, d, h, w = x.shape
+        out = torch.empty((B, 1, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+        nbytes = _lib.lib().dn_upconv3d_out_workspace_bytes(B, Cn, d, h, w)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "dn_upconv3d_out_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        rc = _lib.lib().dn_upconv3d_out_fwd(_p(x), _p(weight), _p(bias), _p(out), B, Cn, d, h, w, int(act), _p(ws), nbytes, _stream(x))
+        _lib.check(rc, "dn_upconv3d_out_fwd")
+        ctx.save_for_backward(x, weight, out)
+        ctx.act, ctx.has_bias = int(act), bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight, out = ctx.saved_tensors
+        gout = gout.contiguous()
+        B, Cn, d, h, w = x.shape
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        gx = torch.empty_like(x) if need_x else None
+        gw = torch.empty_like(weight) if need_w else None
+        gb = torch.empty(1, dtype=torch.float32, device=x.device) if (need_w and ctx.has_bias) else None
+        nbytes = _lib.lib().dn_upconv3d_out_workspace_bytes(B, Cn, d, h, w)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        rc = _lib.lib().dn_upconv3d_out_bwd(_p(x), _p(weight), _p(out), _p(gout), _p(gx), _p(gw), _p(gb), B, Cn, d, h, w, ctx.act, _p(ws),
+                                            nbytes, _stream(x))
+        _lib.check(rc, "dn_upconv3d_out_bwd")
+        return gx, gw, gb, None
+
+
+def upsample_conv3(x, weight, bias=None, sigmoid=True):
+    """The 3-D generator's output block on the HIP kernels: x (B,C,d,h,w), weight (Cout,C,3,3,3), bias (Cout) ->
+    (B,Cout,2d,2h,2w); one launch set per output channel."""
+    if not (x.is_cuda and x.dtype == torch.float32 and tuple(weight.shape[-3:]) == (3, 3, 3) and x.dim() == 5):
+        raise _lib.DiffNetHipError("upsample_conv3: float32 CUDA tensors (B,C,d,h,w) and 3x3x3 weights only")
+    outs = [_UpConv3dOut.apply(x, weight[co:co + 1], None if bias is None else bias[co:co + 1], sigmoid) for co in range(weight.shape[0])]
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 1)

@@ -5,7 +5,7 @@ Upsample x2 -> Conv3d 3^3 pad 1 -> Sigmoid.  Default torch initialisation (the r
 import torch
 from torch import nn
 
-from .fused import InstanceNormAct
+from .fused import InstanceNormAct, upsample_conv3
 
 
 class UNetDown(nn.Module):
@@ -60,4 +60,9 @@ class GoodGenerator(nn.Module):
         u = self.up4(u, d3)
         u = self.up5(u, d2)
         u = self.up6(u, d1)
+        if u.is_cuda and u.dtype == torch.float32:
+            # Upsample -> Conv3d(32 -> out, 3^3) -> Sigmoid as one HIP kernel each way (dn_upconv3d_out_*); self.final keeps
+            # the parameters (state_dict keys final.1.weight / final.1.bias)
+            conv = self.final[1]
+            return upsample_conv3(u, conv.weight, conv.bias, sigmoid=True)
         return self.final(u)

@@ -180,6 +180,16 @@ int dn_upconv_out_bwd(const float *in, const float *weight, const float *out, co
                       float *grad_weight, float *grad_bias, int64_t B, int64_t C, int64_t h, int64_t w, int act, void *workspace,
                       int64_t workspace_bytes, void *stream);
 
+/* 3-D counterpart: Upsample(x2, nearest) -> Conv3d(C -> 1, 3x3x3, padding 1, bias) -> Sigmoid
+ * (DiffNet/networks/wgan3d.py:88-92, `GoodGenerator.final`).  in (B,C,d,h,w), weight (1,C,3,3,3), out (B,1,2d,2h,2w);
+ * arguments as for dn_upconv_out_*. */
+int64_t dn_upconv3d_out_workspace_bytes(int64_t B, int64_t C, int64_t d, int64_t h, int64_t w);
+int dn_upconv3d_out_fwd(const float *in, const float *weight, const float *bias, float *out, int64_t B, int64_t C, int64_t d,
+                        int64_t h, int64_t w, int act, void *workspace, int64_t workspace_bytes, void *stream);
+int dn_upconv3d_out_bwd(const float *in, const float *weight, const float *out, const float *grad_out, float *grad_in,
+                        float *grad_weight, float *grad_bias, int64_t B, int64_t C, int64_t d, int64_t h, int64_t w, int act,
+                        void *workspace, int64_t workspace_bytes, void *stream);
+
 /* Fused InstanceNorm (affine = False, biased variance) + LeakyReLU/ReLU of the generator blocks
  * (DiffNet/networks/unets.py:13-45, autoencoders.py:7-70, wgan3d.py:23-55): x, y (n_inst, spatial) contiguous with
  * n_inst = B*C; mean, rstd (n_inst) are written by fwd and consumed by bwd.  slope: 0 = ReLU, 0.2 = LeakyReLU(0.2),

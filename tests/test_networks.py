@@ -136,3 +136,42 @@ def test_fused_output_block_matches_torch_modules(B, C, h, w, cout, sigmoid):
     y2 = upsample_pad_conv4(xg, wg, bg, sigmoid=sigmoid)
     gw2, = torch.autograd.grad(y2, [wg], cot.to(dev))
     assert torch.equal(y, y2) and torch.equal(gw, gw2)            # fixed-order reductions
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,d,h,w,cout", [(2, 32, 6, 5, 8, 1), (1, 3, 4, 7, 9, 2), (1, 40, 3, 4, 66, 1), (2, 4, 1, 1, 1, 1), (1, 32, 16, 16, 16, 1)])
+@pytest.mark.parametrize("sigmoid", [True, False])
+def test_fused_output_block_3d_matches_torch_modules(B, C, d, h, w, cout, sigmoid):
+    """dn_upconv3d_out_fwd/bwd against Upsample -> Conv3d(3^3, padding 1) -> Sigmoid in float64 on the CPU (the reference's
+    `GoodGenerator.final`, wgan3d.py:88-92): output, input gradient, weight and bias gradients."""
+    from torch import nn
+    from diffnet_amd.networks.fused import upsample_conv3
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, C, d, h, w, generator=g)
+    conv = nn.Conv3d(C, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.2)
+        conv.bias.copy_(torch.randn(conv.bias.shape, generator=g))
+    cot = torch.randn(B, cout, 2 * d, 2 * h, 2 * w, generator=g)
+    ref = nn.Sequential(nn.Upsample(scale_factor=2), conv, *([nn.Sigmoid()] if sigmoid else [])).double()
+    xd = x.double().requires_grad_(True)
+    yd = ref(xd)
+    gxd, gwd, gbd = torch.autograd.grad(yd, [xd, ref[1].weight, ref[1].bias], cot.double())
+    xg = x.to(dev).requires_grad_(True)
+    wg = conv.weight.detach().float().to(dev).requires_grad_(True)
+    bg = conv.bias.detach().float().to(dev).requires_grad_(True)
+    y = upsample_conv3(xg, wg, bg, sigmoid=sigmoid)
+    gx, gw, gb = torch.autograd.grad(y, [xg, wg, bg], cot.to(dev))
+
+    def close(a, b, tol):
+        a, b = a.detach().cpu().double().numpy(), b.detach().numpy()
+        assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-30), (np.abs(a - b).max(), np.abs(b).max())
+
+    close(y, yd, 2e-6)
+    close(gx, gxd, 5e-6)
+    close(gw, gwd, 2e-5)
+    close(gb, gbd, 2e-5)
+    y2 = upsample_conv3(xg, wg, bg, sigmoid=sigmoid)
+    gw2, = torch.autograd.grad(y2, [wg], cot.to(dev))
+    assert torch.equal(y, y2) and torch.equal(gw, gw2)
