@@ -78,6 +78,9 @@ SYMBOLS = {
                                       C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "dn_upconv3d_out_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dn_conv3d_k4s2_wrw_workspace_bytes": (C.c_int64, [C.c_int64] * 6),
+    "dn_conv3d_k4s2_wrw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                     C.c_void_p, C.c_int64, C.c_void_p]),
     "dn_instnorm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "dn_instnorm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                       C.c_void_p, C.c_int64, C.c_void_p]),

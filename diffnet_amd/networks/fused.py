@@ -151,3 +151,86 @@ def upsample_conv3(x, weight, bias=None, sigmoid=True):
         raise _lib.DiffNetHipError("upsample_conv3: float32 CUDA tensors (B,C,d,h,w) and 3x3x3 weights only")
     outs = [_UpConv3dOut.apply(x, weight[co:co + 1], None if bias is None else bias[co:co + 1], sigmoid) for co in range(weight.shape[0])]
     return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
+
+
+def _wrw3d(fine, coarse):
+    """grad_weight (M, CN, 4,4,4) of a 4^3 / stride 2 / padding 1 (transposed) convolution: dn_conv3d_k4s2_wrw."""
+    fine, coarse = fine.contiguous(), coarse.contiguous()
+    B, CN = fine.shape[:2]
+    M, (d, h, w) = coarse.shape[1], coarse.shape[2:]
+    gw = torch.empty((M, CN, 4, 4, 4), dtype=torch.float32, device=fine.device)
+    nbytes = _lib.lib().dn_conv3d_k4s2_wrw_workspace_bytes(B, CN, M, d, h, w)
+    if nbytes < 0:
+        _lib.check(int(nbytes), "dn_conv3d_k4s2_wrw_workspace_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=fine.device)
+    rc = _lib.lib().dn_conv3d_k4s2_wrw(_p(fine), _p(coarse), _p(gw), B, CN, M, d, h, w, _p(ws), nbytes, _stream(fine))
+    _lib.check(rc, "dn_conv3d_k4s2_wrw")
+    return gw
+
+
+_S2, _P1, _D1, _OP0 = [2, 2, 2], [1, 1, 1], [1, 1, 1], [0, 0, 0]
+
+
+class _Conv3dK4S2(torch.autograd.Function):
+    """Conv3d(4^3, stride 2, padding 1, no bias): MIOpen forward / input gradient, HIP weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.conv3d(x, weight, None, 2, 1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, weight, None, _S2, _P1, _D1, False, _OP0, 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            gw = _wrw3d(fine=x, coarse=gy)
+        return gx, gw
+
+
+class _ConvT3dK4S2(torch.autograd.Function):
+    """ConvTranspose3d(4^3, stride 2, padding 1, no bias): MIOpen forward / input gradient, HIP weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.conv_transpose3d(x, weight, None, 2, 1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, weight, None, _S2, _P1, _D1, True, _OP0, 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            gw = _wrw3d(fine=gy, coarse=x)
+        return gx, gw
+
+
+def _k4s2(m, x, coarse_channels):
+    return (x.is_cuda and x.dtype == torch.float32 and m.bias is None and tuple(m.kernel_size) == (4, 4, 4) and tuple(m.stride) == (2, 2, 2)
+            and tuple(m.padding) == (1, 1, 1) and tuple(m.dilation) == (1, 1, 1) and m.groups == 1 and coarse_channels <= 128
+            and tuple(getattr(m, "output_padding", (0, 0, 0))) == (0, 0, 0))
+
+
+class Conv3dS2(nn.Conv3d):
+    """nn.Conv3d whose weight gradient runs on dn_conv3d_k4s2_wrw when the layer is 4^3 / stride 2 / padding 1 / no bias on
+    even-sized float32 GPU inputs (every UNetDown of the 3-D generator); anything else takes torch's path."""
+
+    def forward(self, x):
+        if _k4s2(self, x, self.out_channels) and all(s % 2 == 0 for s in x.shape[2:]):
+            return _Conv3dK4S2.apply(x, self.weight)
+        return super().forward(x)
+
+
+class ConvTranspose3dS2(nn.ConvTranspose3d):
+    """nn.ConvTranspose3d counterpart (every UNetUp of the 3-D generator)."""
+
+    def forward(self, x, output_size=None):
+        if output_size is None and _k4s2(self, x, self.in_channels):
+            return _ConvT3dK4S2.apply(x, self.weight)
+        return super().forward(x, output_size)

@@ -5,13 +5,13 @@ Upsample x2 -> Conv3d 3^3 pad 1 -> Sigmoid.  Default torch initialisation (the r
 import torch
 from torch import nn
 
-from .fused import InstanceNormAct, upsample_conv3
+from .fused import Conv3dS2, ConvTranspose3dS2, InstanceNormAct, upsample_conv3
 
 
 class UNetDown(nn.Module):
     def __init__(self, in_size, out_size, normalize=True, dropout=0.0):
         super().__init__()
-        layers = [nn.Conv3d(in_size, out_size, 4, 2, 1, bias=False)]
+        layers = [Conv3dS2(in_size, out_size, 4, 2, 1, bias=False)]           # nn.Conv3d + HIP weight gradient
         if normalize:                              # fused InstanceNorm + LeakyReLU (HIP); Identity keeps the reference's indices
             layers += [InstanceNormAct(out_size, slope=0.2), nn.Identity()]
         else:
@@ -27,7 +27,7 @@ class UNetDown(nn.Module):
 class UNetUp(nn.Module):
     def __init__(self, in_size, out_size, dropout=0.0):
         super().__init__()
-        layers = [nn.ConvTranspose3d(in_size, out_size, 4, 2, 1, bias=False), InstanceNormAct(out_size, slope=0.0), nn.Identity()]
+        layers = [ConvTranspose3dS2(in_size, out_size, 4, 2, 1, bias=False), InstanceNormAct(out_size, slope=0.0), nn.Identity()]
         if dropout:
             layers.append(nn.Dropout(dropout))
         self.model = nn.Sequential(*layers)

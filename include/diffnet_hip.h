@@ -190,6 +190,16 @@ int dn_upconv3d_out_bwd(const float *in, const float *weight, const float *out, 
                         float *grad_weight, float *grad_bias, int64_t B, int64_t C, int64_t d, int64_t h, int64_t w, int act,
                         void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Weight gradient of the 4x4x4 / stride 2 / padding 1 3-D convolutions and transposed convolutions of the generator
+ * (DiffNet/networks/wgan3d.py:23-55):
+ *     grad_weight[m][cn][kz][ky][kx] = sum_{b,i,j,k} coarse[b][m][i][j][k] * fine[b][cn][2i+kz-1][2j+ky-1][2k+kx-1]
+ *   Conv3d:          coarse = grad_out (B,cout,d,h,w), fine = input    (B,cin,2d,2h,2w),  grad_weight (cout,cin,4,4,4)
+ *   ConvTranspose3d: coarse = input    (B,cin,d,h,w),  fine = grad_out (B,cout,2d,2h,2w), grad_weight (cin,cout,4,4,4)
+ * M (channels of `coarse`) <= 128.  Fixed-order partial sums (bitwise repeatable); workspace needs no initialisation. */
+int64_t dn_conv3d_k4s2_wrw_workspace_bytes(int64_t B, int64_t CN, int64_t M, int64_t d, int64_t h, int64_t w);
+int dn_conv3d_k4s2_wrw(const float *fine, const float *coarse, float *grad_weight, int64_t B, int64_t CN, int64_t M, int64_t d,
+                       int64_t h, int64_t w, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* Fused InstanceNorm (affine = False, biased variance) + LeakyReLU/ReLU of the generator blocks
  * (DiffNet/networks/unets.py:13-45, autoencoders.py:7-70, wgan3d.py:23-55): x, y (n_inst, spatial) contiguous with
  * n_inst = B*C; mean, rstd (n_inst) are written by fwd and consumed by bwd.  slope: 0 = ReLU, 0.2 = LeakyReLU(0.2),

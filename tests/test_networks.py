@@ -175,3 +175,42 @@ def test_fused_output_block_3d_matches_torch_modules(B, C, d, h, w, cout, sigmoi
     y2 = upsample_conv3(xg, wg, bg, sigmoid=sigmoid)
     gw2, = torch.autograd.grad(y2, [wg], cot.to(dev))
     assert torch.equal(y, y2) and torch.equal(gw, gw2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,n", [(1, 1, 16, 16), (2, 16, 32, 8), (1, 3, 5, 6), (2, 64, 128, 4), (1, 20, 40, 10)])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_conv3d_k4s2_weight_gradient_matches_float64(B, cin, cout, n, transposed):
+    """dn_conv3d_k4s2_wrw (through Conv3dS2 / ConvTranspose3dS2) against the float64 CPU gradient of the stock torch
+    layer; forward output and input gradient (MIOpen) are checked alongside."""
+    from torch import nn
+    from diffnet_amd.networks.fused import Conv3dS2, ConvTranspose3dS2
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(17)
+    if transposed:
+        ref, mod = nn.ConvTranspose3d(cin, cout, 4, 2, 1, bias=False), ConvTranspose3dS2(cin, cout, 4, 2, 1, bias=False)
+        shape = (B, cin, n // 2, n // 2, n // 2) if n >= 4 else (B, cin, n, n, n)
+    else:
+        ref, mod = nn.Conv3d(cin, cout, 4, 2, 1, bias=False), Conv3dS2(cin, cout, 4, 2, 1, bias=False)
+        shape = (B, cin, n, n, n)
+    mod.load_state_dict(ref.state_dict())
+    x = torch.randn(shape)
+    xd = x.double().requires_grad_(True)
+    refd = ref.double()
+    yd = refd(xd)
+    cot = torch.randn(yd.shape)
+    gxd, gwd = torch.autograd.grad(yd, [xd, refd.weight], cot.double())
+    mod = mod.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    y = mod(xg)
+    gx, gw = torch.autograd.grad(y, [xg, mod.weight], cot.to(dev))
+
+    def close(a, b, tol):
+        a, b = a.detach().cpu().double().numpy(), b.detach().numpy()
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-30), (np.abs(a - b).max(), np.abs(b).max())
+
+    close(y, yd, 1e-4)
+    close(gx, gxd, 1e-4)
+    close(gw, gwd, 2e-5)
+    gw2, = torch.autograd.grad(mod(xg), [mod.weight], cot.to(dev))
+    assert torch.equal(gw, gw2)
