@@ -13,6 +13,7 @@
 namespace dn {
 
 constexpr int WR_TP = 64;        // coarse positions per tile
+constexpr int WR_FEW = 16;       // up to this many workgroups per fine channel: thread-per-output final sum
 
 template <int MR>                // MR = ceil(M / 16): rows per thread
 __global__ void __launch_bounds__(256) conv3d_wrw_kernel(const float* __restrict__ fine, const float* __restrict__ coarse,
@@ -82,15 +83,30 @@ __global__ void __launch_bounds__(256) conv3d_wrw_kernel(const float* __restrict
             }
         }
     }
-    const size_t nwg = gridDim.x;
+    // partial layout: few workgroups -> [workgroup][output] (summed by one thread per output, coalesced; with a single
+    // workgroup `part` IS grad_weight); many -> [output][workgroup] (summed by one wave per output, coalesced)
+    const size_t nwg = gridDim.x, nout = (size_t)M * CN * 64;
+    const bool wg_major = nwg <= WR_FEW;
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
         const int m = m0 + 16 * r;
         if (m < M) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) part[((size_t)(m * CN + cn) * 64 + t4 + q) * nwg + blockIdx.x] = acc[r][q];
+            for (int q = 0; q < 4; ++q) {
+                const size_t o = (size_t)(m * CN + cn) * 64 + t4 + q;
+                part[wg_major ? blockIdx.x * nout + o : o * nwg + blockIdx.x] = acc[r][q];
+            }
         }
     }
+}
+
+// few workgroups: one thread per output, partials [workgroup][output]
+__global__ void __launch_bounds__(256) conv3d_wsum_few_kernel(const float* __restrict__ part, float* __restrict__ gw, int nwg, long n) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    double s = 0.0;
+    for (int g = 0; g < nwg; ++g) s += (double)part[(size_t)g * n + k];
+    gw[k] = (float)s;
 }
 
 // one wave per output: coalesced fp64 sum of the per-workgroup partials
@@ -128,18 +144,18 @@ extern "C" int64_t dn_conv3d_k4s2_wrw_workspace_bytes(int64_t B, int64_t CN, int
     if (int rc = wr_check(B, CN, M, d, h, w)) return rc;
     int nwg, tpw;
     wr_plan(B * d * h * w, CN, nwg, tpw);
-    return (int64_t)sizeof(float) * M * CN * 64 * nwg;
+    return nwg == 1 ? 0 : (int64_t)sizeof(float) * M * CN * 64 * nwg;
 }
 
 extern "C" int dn_conv3d_k4s2_wrw(const float* fine, const float* coarse, float* grad_weight, int64_t B, int64_t CN, int64_t M, int64_t d,
                                   int64_t h, int64_t w, void* workspace, int64_t workspace_bytes, void* stream) {
     if (int rc = wr_check(B, CN, M, d, h, w)) return rc;
     if (!fine || !coarse || !grad_weight) return DN_E_BADARG;
-    if (!workspace || workspace_bytes < dn_conv3d_k4s2_wrw_workspace_bytes(B, CN, M, d, h, w)) return DN_E_WORKSPACE;
     int nwg, tpw;
     wr_plan(B * d * h * w, CN, nwg, tpw);
+    if (nwg > 1 && (!workspace || workspace_bytes < dn_conv3d_k4s2_wrw_workspace_bytes(B, CN, M, d, h, w))) return DN_E_WORKSPACE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    float* part = static_cast<float*>(workspace);
+    float* part = nwg == 1 ? grad_weight : static_cast<float*>(workspace);
     const dim3 grid((unsigned)nwg, (unsigned)CN), block(256);
     const int MR = (int)((M + 15) / 16);
 #define DN_WR(R) hipLaunchKernelGGL((conv3d_wrw_kernel<R>), grid, block, 0, s, fine, coarse, part, (int)B, (int)CN, (int)M, (int)d, (int)h, (int)w, tpw)
@@ -151,7 +167,8 @@ extern "C" int dn_conv3d_k4s2_wrw(const float* fine, const float* coarse, float*
     }
 #undef DN_WR
     const long n = (long)M * CN * 64;
-    hipLaunchKernelGGL(conv3d_wsum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, grad_weight, nwg, n);
+    if (nwg > WR_FEW) hipLaunchKernelGGL(conv3d_wsum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, grad_weight, nwg, n);
+    else if (nwg > 1) hipLaunchKernelGGL(conv3d_wsum_few_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, grad_weight, nwg, n);
     DN_LAUNCH_CHECK();
     return 0;
 }

@@ -15,34 +15,29 @@ namespace dn {
 // wf[c][phase = a*4+b*2+e][gz*4+gy*2+gx]   (gz = 0: lower plane of the phase's pair, 1: upper)
 // wb[c][dz*16+dy*4+dx]                      (gradient voxel 2i-1+dz, 2j-1+dy, 2k-1+dx)
 __global__ void upconv3d_weff_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one thread per effective weight: ids [0, 64 C) forward, [64 C, 128 C) backward
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 128 * C) return;
+    const int c = (id % (64 * C)) / 64, o = id % 64;
     const float* W = w + c * 27;
-    // tap range of group g in phase a:  a = 0: g0 = {0}, g1 = {1,2};  a = 1: g0 = {0,1}, g1 = {2}
-    auto lo = [](int a, int g) { return a == 0 ? (g == 0 ? 0 : 1) : (g == 0 ? 0 : 2); };
-    auto hi = [](int a, int g) { return a == 0 ? (g == 0 ? 0 : 2) : (g == 0 ? 1 : 2); };
-    for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 2; ++b)
-            for (int e = 0; e < 2; ++e)
-                for (int gz = 0; gz < 2; ++gz)
-                    for (int gy = 0; gy < 2; ++gy)
-                        for (int gx = 0; gx < 2; ++gx) {
-                            float s = 0.f;
-                            for (int kz = lo(a, gz); kz <= hi(a, gz); ++kz)
-                                for (int ky = lo(b, gy); ky <= hi(b, gy); ++ky)
-                                    for (int kx = lo(e, gx); kx <= hi(e, gx); ++kx) s += W[(kz * 3 + ky) * 3 + kx];
-                            wf[(c * 8 + a * 4 + b * 2 + e) * 8 + gz * 4 + gy * 2 + gx] = s;
-                        }
-    const int blo[4] = {2, 1, 0, 0}, bhi[4] = {2, 2, 1, 0};
-    for (int dz = 0; dz < 4; ++dz)
-        for (int dy = 0; dy < 4; ++dy)
-            for (int dx = 0; dx < 4; ++dx) {
-                float s = 0.f;
-                for (int kz = blo[dz]; kz <= bhi[dz]; ++kz)
-                    for (int ky = blo[dy]; ky <= bhi[dy]; ++ky)
-                        for (int kx = blo[dx]; kx <= bhi[dx]; ++kx) s += W[(kz * 3 + ky) * 3 + kx];
-                wb[c * 64 + dz * 16 + dy * 4 + dx] = s;
-            }
+    int lz, hz, ly, hy, lx, hx;
+    if (id < 64 * C) {
+        // tap range of group g in phase a:  a = 0: g0 = {0}, g1 = {1,2};  a = 1: g0 = {0,1}, g1 = {2}
+        auto lo = [](int a, int g) { return a == 0 ? (g == 0 ? 0 : 1) : (g == 0 ? 0 : 2); };
+        auto hi = [](int a, int g) { return a == 0 ? (g == 0 ? 0 : 2) : (g == 0 ? 1 : 2); };
+        const int ph = o / 8, g = o % 8;
+        const int a = ph >> 2, b = (ph >> 1) & 1, e = ph & 1, gz = g >> 2, gy = (g >> 1) & 1, gx = g & 1;
+        lz = lo(a, gz); hz = hi(a, gz); ly = lo(b, gy); hy = hi(b, gy); lx = lo(e, gx); hx = hi(e, gx);
+    } else {
+        const int blo[4] = {2, 1, 0, 0}, bhi[4] = {2, 2, 1, 0};
+        const int dz = o / 16, dy = (o / 4) % 4, dx = o % 4;
+        lz = blo[dz]; hz = bhi[dz]; ly = blo[dy]; hy = bhi[dy]; lx = blo[dx]; hx = bhi[dx];
+    }
+    float s = 0.f;
+    for (int kz = lz; kz <= hz; ++kz)
+        for (int ky = ly; ky <= hy; ++ky)
+            for (int kx = lx; kx <= hx; ++kx) s += W[(kz * 3 + ky) * 3 + kx];
+    (id < 64 * C ? wf : wb)[c * 64 + o] = s;
 }
 
 __device__ __forceinline__ float sigmoid3(float z) { return 1.f / (1.f + __expf(-z)); }
@@ -290,7 +285,7 @@ extern "C" int dn_upconv3d_out_fwd(const float* in, const float* weight, const f
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* wf = static_cast<float*>(workspace);
     float* wb = wf + C * 64;
-    hipLaunchKernelGGL(upconv3d_weff_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, weight, wf, wb, (int)C);
+    hipLaunchKernelGGL(upconv3d_weff_kernel, dim3((unsigned)((128 * C + 255) / 256)), dim3(256), 0, s, weight, wf, wb, (int)C);
     hipLaunchKernelGGL(upconv3d_fwd_kernel, dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)(B * d)), dim3(256), 0, s, in, wf,
                        bias, out, (int)C, (int)d, (int)h, (int)w, act);
     DN_LAUNCH_CHECK();
@@ -308,7 +303,7 @@ extern "C" int dn_upconv3d_out_bwd(const float* in, const float* weight, const f
     float* wb = wf + C * 64;
     float* part = wb + C * 64;
     if (grad_in) {
-        hipLaunchKernelGGL(upconv3d_weff_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, weight, wf, wb, (int)C);
+        hipLaunchKernelGGL(upconv3d_weff_kernel, dim3((unsigned)((128 * C + 255) / 256)), dim3(256), 0, s, weight, wf, wb, (int)C);
         hipLaunchKernelGGL(upconv3d_bwd_data_kernel, dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)(B * d)), dim3(256), 0, s,
                            grad_out, act ? out : nullptr, wb, grad_in, (int)C, (int)d, (int)h, (int)w, act);
     }

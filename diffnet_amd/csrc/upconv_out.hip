@@ -16,36 +16,33 @@ namespace dn {
 // forward effective weights [C][25]: phase (0,0) 2x2 | (0,1) 2x3 | (1,0) 3x2 | (1,1) 3x3, neighbour offsets -1..+1
 // backward effective weights [C][25]: [dy][dx], gradient rows 2i-1+dy, columns 2j-1+dx
 __global__ void upconv_weff_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float W[4][4];
-    for (int ky = 0; ky < 4; ++ky)
-        for (int kx = 0; kx < 4; ++kx) W[ky][kx] = w[(c * 4 + ky) * 4 + kx];
-    // row groups per phase: a = 0: {0,1},{2,3};  a = 1: {0},{1,2},{3}
-    auto rsum = [&](int a, int g, int kx) {
-        if (a == 0) return g == 0 ? W[0][kx] + W[1][kx] : W[2][kx] + W[3][kx];
-        return g == 0 ? W[0][kx] : (g == 1 ? W[1][kx] + W[2][kx] : W[3][kx]);
-    };
-    auto tap = [&](int a, int gy, int b, int gx) {
-        if (b == 0) return gx == 0 ? rsum(a, gy, 0) + rsum(a, gy, 1) : rsum(a, gy, 2) + rsum(a, gy, 3);
-        return gx == 0 ? rsum(a, gy, 0) : (gx == 1 ? rsum(a, gy, 1) + rsum(a, gy, 2) : rsum(a, gy, 3));
-    };
-    float* o = wf + c * 25;
-    int n = 0;
-    for (int gy = 0; gy < 2; ++gy) for (int gx = 0; gx < 2; ++gx) o[n++] = tap(0, gy, 0, gx);
-    for (int gy = 0; gy < 2; ++gy) for (int gx = 0; gx < 3; ++gx) o[n++] = tap(0, gy, 1, gx);
-    for (int gy = 0; gy < 3; ++gy) for (int gx = 0; gx < 2; ++gx) o[n++] = tap(1, gy, 0, gx);
-    for (int gy = 0; gy < 3; ++gy) for (int gx = 0; gx < 3; ++gx) o[n++] = tap(1, gy, 1, gx);
-    // backward: row-tap sets for dy = 0..4 (gradient row 2i-1+dy): {3},{2,3},{1,2},{0,1},{0}
-    const int lo[5] = {3, 2, 1, 0, 0}, hi[5] = {3, 3, 2, 1, 0};
-    float* ob = wb + c * 25;
-    for (int dy = 0; dy < 5; ++dy)
-        for (int dx = 0; dx < 5; ++dx) {
-            float s = 0.f;
-            for (int ky = lo[dy]; ky <= hi[dy]; ++ky)
-                for (int kx = lo[dx]; kx <= hi[dx]; ++kx) s += W[ky][kx];
-            ob[dy * 5 + dx] = s;
-        }
+    // one thread per effective weight: ids [0, 25 C) forward, [25 C, 50 C) backward
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 50 * C) return;
+    const bool fwd = id < 25 * C;
+    const int c = (id % (25 * C)) / 25, o = id % 25;
+    const float* W = w + c * 16;
+    int ly, hy, lx, hx;
+    if (fwd) {
+        // phase (a, b) and group (gy, gx) of entry o: (0,0) 2x2 | (0,1) 2x3 | (1,0) 3x2 | (1,1) 3x3
+        int a, b, gy, gx;
+        if (o < 4) { a = 0; b = 0; gy = o / 2; gx = o % 2; }
+        else if (o < 10) { a = 0; b = 1; gy = (o - 4) / 3; gx = (o - 4) % 3; }
+        else if (o < 16) { a = 1; b = 0; gy = (o - 10) / 2; gx = (o - 10) % 2; }
+        else { a = 1; b = 1; gy = (o - 16) / 3; gx = (o - 16) % 3; }
+        // tap range of group g in phase a:  a = 0: {0,1},{2,3};  a = 1: {0},{1,2},{3}
+        auto lo = [](int a_, int g) { return a_ == 0 ? 2 * g : (g == 0 ? 0 : (g == 1 ? 1 : 3)); };
+        auto hi = [](int a_, int g) { return a_ == 0 ? 2 * g + 1 : (g == 0 ? 0 : (g == 1 ? 2 : 3)); };
+        ly = lo(a, gy); hy = hi(a, gy); lx = lo(b, gx); hx = hi(b, gx);
+    } else {
+        // gradient row 2i-1+dy: tap sets {3},{2,3},{1,2},{0,1},{0}
+        const int blo[5] = {3, 2, 1, 0, 0}, bhi[5] = {3, 3, 2, 1, 0};
+        ly = blo[o / 5]; hy = bhi[o / 5]; lx = blo[o % 5]; hx = bhi[o % 5];
+    }
+    float s = 0.f;
+    for (int ky = ly; ky <= hy; ++ky)
+        for (int kx = lx; kx <= hx; ++kx) s += W[ky * 4 + kx];
+    (fwd ? wf : wb)[c * 25 + o] = s;
 }
 
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + __expf(-z)); }
@@ -239,7 +236,7 @@ extern "C" int dn_upconv_out_fwd(const float* in, const float* weight, const flo
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* wf = static_cast<float*>(workspace);
     float* wb = wf + C * 25;
-    hipLaunchKernelGGL(upconv_weff_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, weight, wf, wb, (int)C);
+    hipLaunchKernelGGL(upconv_weff_kernel, dim3((unsigned)((50 * C + 255) / 256)), dim3(256), 0, s, weight, wf, wb, (int)C);
     hipLaunchKernelGGL(upconv_fwd_kernel, dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)B), dim3(256), 0, s, in, wf, bias,
                        out, (int)C, (int)h, (int)w, act);
     DN_LAUNCH_CHECK();
@@ -257,7 +254,7 @@ extern "C" int dn_upconv_out_bwd(const float* in, const float* weight, const flo
     float* wb = wf + C * 25;
     float* part = wb + C * 25;
     if (grad_in) {
-        hipLaunchKernelGGL(upconv_weff_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, weight, wf, wb, (int)C);
+        hipLaunchKernelGGL(upconv_weff_kernel, dim3((unsigned)((50 * C + 255) / 256)), dim3(256), 0, s, weight, wf, wb, (int)C);
         hipLaunchKernelGGL(upconv_bwd_data_kernel, dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)B), dim3(256), 0, s, grad_out,
                            act ? out : nullptr, wb, grad_in, (int)C, (int)h, (int)w, act);
     }

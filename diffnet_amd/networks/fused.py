@@ -162,7 +162,7 @@ def _wrw3d(fine, coarse):
     nbytes = _lib.lib().dn_conv3d_k4s2_wrw_workspace_bytes(B, CN, M, d, h, w)
     if nbytes < 0:
         _lib.check(int(nbytes), "dn_conv3d_k4s2_wrw_workspace_bytes")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=fine.device)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=fine.device) if nbytes else None
     rc = _lib.lib().dn_conv3d_k4s2_wrw(_p(fine), _p(coarse), _p(gw), B, CN, M, d, h, w, _p(ws), nbytes, _stream(fine))
     _lib.check(rc, "dn_conv3d_k4s2_wrw")
     return gw
