@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 ALG_BYTES_PER_NODE = 16        # read u, nu, f + write grad_u, fp32
+PIPE = 4                       # loss all-reduces in flight (N > 1)
 
 
 def make_inputs(shape, dev, seed):
@@ -143,11 +144,12 @@ def main():
         loss, grad = m.energy_loss_and_grad(u, nu, f, dirichlet=dirichlet, c=c)
         if dist is not None:
             # the path's only exchange step: all-reduce of the 4-byte loss (RCCL).  Issued asynchronously so that the
-            # next evaluation's kernel does not queue behind the collective; waited one step later (and before the
-            # timed region closes), i.e. every step's loss IS reduced inside the timed region.
+            # next evaluation's kernel does not queue behind the collective; waited PIPE steps later (a small-message
+            # all-reduce over xGMI is latency-bound at tens of microseconds, comparable to one 75 us step) and drained
+            # before the timed region closes, i.e. every step's loss IS reduced inside the timed region.
             loss.div_(world)
             pending.append((dist.all_reduce(loss, async_op=True), loss))
-            if len(pending) > 1:
+            if len(pending) > PIPE:
                 pending.pop(0)[0].wait()
         return loss, grad
 

@@ -86,10 +86,11 @@ rows = [
     poisson(3, 128, 2, 4, "cfg2 3-D 128^3 Q1 2x2x2 B=4"),
     poisson(3, 256, 2, 1, "cfg3 3-D 256^3 Q1 2x2x2 B=1 (one GPU holds the whole mesh)"),
     poisson(3, 129, 3, 2, "     3-D 129^3 Q1 3x3x3 B=2"),
-    fsdt(513, 2, 3, 1, "cfg4 FSDT 513^2 Q2 3x3 B=1 fused (fwd+bwd launches)"),
-    fsdt(513, 2, 3, 8, "cfg4 FSDT 513^2 Q2 3x3 B=8 fused"),
-    fsdt(513, 2, 3, 32, "cfg4 FSDT 513^2 Q2 3x3 B=32 fused"),
+    fsdt(1025, 2, 3, 1, "cfg4 FSDT 1025^2 nodes = 512^2 Q2 elements, 3x3, B=1 fused (fwd+bwd launches)"),
+    fsdt(1025, 2, 3, 8, "cfg4 FSDT 1025^2 Q2 3x3 B=8 fused"),
+    fsdt(513, 2, 3, 1, "cfg4 FSDT 513^2 Q2 3x3 B=1 fused (small variant)"),
     fsdt(513, 2, 3, 1, "cfg4 FSDT 513^2 Q2 3x3 B=1 composed from operators", composed=True),
+    fsdt(1025, 2, 3, 1, "cfg4 FSDT 1025^2 Q2 3x3 B=1 composed from operators", composed=True),
     fsdt(512, 1, 2, 8, "     FSDT 512^2 Q1 2x2 B=8 fused (the reference script's element)"),
 ]
 for r in rows:
