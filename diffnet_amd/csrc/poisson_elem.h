@@ -50,74 +50,8 @@ __device__ __forceinline__ void elem2d(const ElemTab& T, const float (&u)[P + 1]
                                        float& e1, float& e2) {
     constexpr int NB = P + 1;
     float a1 = 0.f, a2 = 0.f;
-    if constexpr (P == 1) {
-        float b1[NGP];
-#pragma unroll
-        for (int i = 0; i < NGP; ++i) b1[i] = T.b[i][1];
-        const float dx0 = u[0][1] - u[0][0], dx1 = u[1][1] - u[1][0], ddx = dx1 - dx0;
-        const float n0 = nu[0][1] - nu[0][0], n1 = nu[1][1] - nu[1][0];
-        const float f0 = f[0][1] - f[0][0], f1 = f[1][1] - f[1][0];
-        float tv0[NGP], dyv[NGP], uy[NGP], uy2[NGP], ux[NGP], ux2[NGP], tn0[NGP], dyn[NGP], tf0[NGP], dyf[NGP];
-#pragma unroll
-        for (int i = 0; i < NGP; ++i) {
-            tv0[i] = fmaf(b1[i], dx0, u[0][0]);
-            dyv[i] = fmaf(b1[i], dx1, u[1][0]) - tv0[i];
-            uy[i] = T.hs[1] * dyv[i];
-            uy2[i] = uy[i] * uy[i];
-            ux[i] = T.hs[0] * fmaf(b1[i], ddx, dx0);   // index i is jg here
-            ux2[i] = ux[i] * ux[i];
-            tn0[i] = fmaf(b1[i], n0, nu[0][0]);
-            dyn[i] = fmaf(b1[i], n1, nu[1][0]) - tn0[i];
-            if constexpr (!FGP) {
-                tf0[i] = fmaf(b1[i], f0, f[0][0]);
-                dyf[i] = fmaf(b1[i], f1, f[1][0]) - tf0[i];
-            }
-        }
-        float Qx[NGP], Qy[NGP], c1[NGP], cs[NGP];
-#pragma unroll
-        for (int i = 0; i < NGP; ++i) Qx[i] = Qy[i] = c1[i] = cs[i] = 0.f;
-#pragma unroll
-        for (int jg = 0; jg < NGP; ++jg) {
-#pragma unroll
-            for (int ig = 0; ig < NGP; ++ig) {
-                const float val = fmaf(b1[jg], dyv[ig], tv0[ig]);
-                const float nuv = fmaf(b1[jg], dyn[ig], tn0[ig]);
-                float fv;
-                if constexpr (FGP) fv = fg[jg * NGP + ig];
-                else fv = fmaf(b1[jg], dyf[ig], tf0[ig]);
-                const float Wn = T.w2[jg][ig] * nuv;
-                const float Wf = T.w2[jg][ig] * fv;
-                a1 = fmaf(Wn, ux2[jg] + uy2[ig], a1);
-                a2 = fmaf(Wf, val, a2);
-                Qx[jg] += Wn;
-                Qy[ig] += Wn;
-                cs[ig] += Wf;
-                c1[ig] = fmaf(b1[jg], Wf, c1[ig]);
-            }
-        }
-        // transposes (cs, c1 still lack the factor -beta)
-        float cdx1 = 0.f, cdxs = 0.f;
-#pragma unroll
-        for (int jg = 0; jg < NGP; ++jg) {
-            const float cx = T.ahs[0] * (Qx[jg] * ux[jg]);
-            cdx1 = fmaf(b1[jg], cx, cdx1);
-            cdxs += cx;
-        }
-        const float cdx0 = cdxs - cdx1;
-        float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;   // row sums / b-weighted sums of cot(tv[jb][ig])
-        const float nb = -T.beta;
-#pragma unroll
-        for (int ig = 0; ig < NGP; ++ig) {
-            const float cyd = T.ahs[1] * (Qy[ig] * uy[ig]);
-            const float ct1 = fmaf(nb, c1[ig], cyd);       // cot of tv[1][ig]
-            const float ct0 = fmaf(nb, cs[ig], -ct1);      // cot of tv[0][ig]
-            s0 += ct0; s1 += ct1;
-            t0 = fmaf(b1[ig], ct0, t0);
-            t1 = fmaf(b1[ig], ct1, t1);
-        }
-        g[0][1] = t0 + cdx0; g[0][0] = s0 - g[0][1];
-        g[1][1] = t1 + cdx1; g[1][0] = s1 - g[1][1];
-    } else {
+    static_assert(P >= 2, "Q1 elements run through the marching kernels (q1_layer_2d / q1_layer_3d)");
+    {
         // generic degree: table driven sum factorisation
         float tv[NB][NGP], td[NB][NGP], tn[NB][NGP], tf[NB][NGP];
 #pragma unroll
@@ -177,153 +111,6 @@ __device__ __forceinline__ void elem2d(const ElemTab& T, const float (&u)[P + 1]
                 }
                 g[jb][ib] = a;
             }
-    }
-    e1 = a1;
-    e2 = a2;
-}
-
-// ---------------------------------------------------------------------------------------------
-// 3-D Q1 element (trilinear hexahedron), lerp form.  u/nu/f: [kb][jb][ib]; fg: [(kg*NGP+jg)*NGP+ig].
-// ---------------------------------------------------------------------------------------------
-template <int NGP, bool FGP>
-__device__ __forceinline__ void elem3d_q1(const ElemTab& T, const float (&u)[2][2][2], const float (&nu)[2][2][2],
-                                          const float (&f)[2][2][2], const float* fg, float (&g)[2][2][2], float& e1,
-                                          float& e2) {
-    float b1[NGP];
-#pragma unroll
-    for (int i = 0; i < NGP; ++i) b1[i] = T.b[i][1];
-    float a1 = 0.f, a2 = 0.f;
-    // ---- forward: x stage, y stage
-    float dx[2][2];            // u differences along x            [kb][jb]
-    float tv0[2][NGP];         // tv[kb][0][ig]
-    float dyv[2][NGP];         // tv[kb][1][ig] - tv[kb][0][ig]
-    float vx0[2], ddx[2];      // vx[kb][jg] = fma(b1[jg], ddx[kb], vx0[kb])
-    float tn0[2][NGP], dyn[2][NGP], tf0[2][NGP], dyf[2][NGP];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        dx[kb][0] = u[kb][0][1] - u[kb][0][0];
-        dx[kb][1] = u[kb][1][1] - u[kb][1][0];
-        vx0[kb] = dx[kb][0];
-        ddx[kb] = dx[kb][1] - dx[kb][0];
-        const float n0 = nu[kb][0][1] - nu[kb][0][0], n1 = nu[kb][1][1] - nu[kb][1][0];
-        const float f0 = f[kb][0][1] - f[kb][0][0], f1 = f[kb][1][1] - f[kb][1][0];
-#pragma unroll
-        for (int ig = 0; ig < NGP; ++ig) {
-            tv0[kb][ig] = fmaf(b1[ig], dx[kb][0], u[kb][0][0]);
-            dyv[kb][ig] = fmaf(b1[ig], dx[kb][1], u[kb][1][0]) - tv0[kb][ig];
-            tn0[kb][ig] = fmaf(b1[ig], n0, nu[kb][0][0]);
-            dyn[kb][ig] = fmaf(b1[ig], n1, nu[kb][1][0]) - tn0[kb][ig];
-            if constexpr (!FGP) {
-                tf0[kb][ig] = fmaf(b1[ig], f0, f[kb][0][0]);
-                dyf[kb][ig] = fmaf(b1[ig], f1, f[kb][1][0]) - tf0[kb][ig];
-            }
-        }
-    }
-    // gradient components depend on two of the three Gauss indices only
-    float ux[NGP][NGP], uy[NGP][NGP];   // ux[kg][jg], uy[kg][ig]
-#pragma unroll
-    for (int jg = 0; jg < NGP; ++jg) {
-        const float q0 = fmaf(b1[jg], ddx[0], vx0[0]), q1 = fmaf(b1[jg], ddx[1], vx0[1]);
-#pragma unroll
-        for (int kg = 0; kg < NGP; ++kg) ux[kg][jg] = T.hs[0] * fmaf(b1[kg], q1 - q0, q0);
-    }
-#pragma unroll
-    for (int ig = 0; ig < NGP; ++ig) {
-        const float d = dyv[1][ig] - dyv[0][ig];
-#pragma unroll
-        for (int kg = 0; kg < NGP; ++kg) uy[kg][ig] = T.hs[1] * fmaf(b1[kg], d, dyv[0][ig]);
-    }
-    float Qx[NGP][NGP], Qy[NGP][NGP];
-#pragma unroll
-    for (int a = 0; a < NGP; ++a)
-#pragma unroll
-        for (int b = 0; b < NGP; ++b) Qx[a][b] = Qy[a][b] = 0.f;
-    float cT0[2][NGP], cD[2][NGP];   // cot of tv[kb][0][ig] (direct path) and of dyv[kb][ig]
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ig = 0; ig < NGP; ++ig) cT0[kb][ig] = cD[kb][ig] = 0.f;
-    const float nb = -T.beta;
-#pragma unroll
-    for (int jg = 0; jg < NGP; ++jg) {
-#pragma unroll
-        for (int ig = 0; ig < NGP; ++ig) {
-            const float vv0 = fmaf(b1[jg], dyv[0][ig], tv0[0][ig]);
-            const float vv1 = fmaf(b1[jg], dyv[1][ig], tv0[1][ig]);
-            const float dz = vv1 - vv0;
-            const float uz = T.hs[2] * dz, uz2 = uz * uz;
-            const float nn0 = fmaf(b1[jg], dyn[0][ig], tn0[0][ig]);
-            const float dn = fmaf(b1[jg], dyn[1][ig], tn0[1][ig]) - nn0;
-            float ff0 = 0.f, df = 0.f;
-            if constexpr (!FGP) {
-                ff0 = fmaf(b1[jg], dyf[0][ig], tf0[0][ig]);
-                df = fmaf(b1[jg], dyf[1][ig], tf0[1][ig]) - ff0;
-            }
-            float Qz = 0.f, cs = 0.f, c1 = 0.f;
-#pragma unroll
-            for (int kg = 0; kg < NGP; ++kg) {
-                const float W = T.w[kg] * T.w2[jg][ig];
-                const float val = fmaf(b1[kg], dz, vv0);
-                const float nuv = fmaf(b1[kg], dn, nn0);
-                float fv;
-                if constexpr (FGP) fv = fg[(kg * NGP + jg) * NGP + ig];
-                else fv = fmaf(b1[kg], df, ff0);
-                const float Wn = W * nuv, Wf = W * fv;
-                a1 = fmaf(Wn, ux[kg][jg] * ux[kg][jg] + uy[kg][ig] * uy[kg][ig] + uz2, a1);
-                a2 = fmaf(Wf, val, a2);
-                Qx[kg][jg] += Wn;
-                Qy[kg][ig] += Wn;
-                Qz += Wn;
-                cs += Wf;
-                c1 = fmaf(b1[kg], Wf, c1);
-            }
-            // cot of vv1 / vv0 (value path + z-derivative path)
-            const float cz = T.ahs[2] * (Qz * uz);
-            const float cv1 = fmaf(nb, c1, cz), cv0 = fmaf(nb, cs, -cv1);
-            // y-stage transpose: vv[kb] = fma(b1[jg], dyv[kb][ig], tv0[kb][ig])
-            cT0[0][ig] += cv0; cD[0][ig] = fmaf(b1[jg], cv0, cD[0][ig]);
-            cT0[1][ig] += cv1; cD[1][ig] = fmaf(b1[jg], cv1, cD[1][ig]);
-        }
-    }
-    // y-derivative path: uy[kg][ig] = hs1 * fma(b1[kg], dyv1-dyv0, dyv0)
-#pragma unroll
-    for (int ig = 0; ig < NGP; ++ig) {
-        float s = 0.f, t = 0.f;
-#pragma unroll
-        for (int kg = 0; kg < NGP; ++kg) {
-            const float cy = T.ahs[1] * (Qy[kg][ig] * uy[kg][ig]);
-            s += cy; t = fmaf(b1[kg], cy, t);
-        }
-        cD[1][ig] += t;
-        cD[0][ig] += s - t;
-    }
-    // x-derivative path: ux[kg][jg] = hs0 * fma(b1[kg], q1-q0, q0), q_kb = fma(b1[jg], ddx[kb], vx0[kb])
-    float cX0[2] = {0.f, 0.f}, cDD[2] = {0.f, 0.f};   // cot of vx0[kb] (= dx[kb][0]) and of ddx[kb]
-#pragma unroll
-    for (int jg = 0; jg < NGP; ++jg) {
-        float s = 0.f, t = 0.f;
-#pragma unroll
-        for (int kg = 0; kg < NGP; ++kg) {
-            const float cx = T.ahs[0] * (Qx[kg][jg] * ux[kg][jg]);
-            s += cx; t = fmaf(b1[kg], cx, t);
-        }
-        const float ca1 = t, ca0 = s - t;
-        cX0[0] += ca0; cDD[0] = fmaf(b1[jg], ca0, cDD[0]);
-        cX0[1] += ca1; cDD[1] = fmaf(b1[jg], ca1, cDD[1]);
-    }
-    // x-stage transpose
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        float s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
-#pragma unroll
-        for (int ig = 0; ig < NGP; ++ig) {
-            const float c1_ = cD[kb][ig], c0_ = cT0[kb][ig] - c1_;
-            s0 += c0_; t0 = fmaf(b1[ig], c0_, t0);
-            s1 += c1_; t1 = fmaf(b1[ig], c1_, t1);
-        }
-        const float cdx1 = cDD[kb], cdx0 = cX0[kb] - cDD[kb];
-        g[kb][0][1] = t0 + cdx0; g[kb][0][0] = s0 - g[kb][0][1];
-        g[kb][1][1] = t1 + cdx1; g[kb][1][0] = s1 - g[kb][1][1];
     }
     e1 = a1;
     e2 = a2;
