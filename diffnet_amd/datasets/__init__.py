@@ -1,0 +1,88 @@
+"""Input generators of the reference's example problems (reference: DiffNet/datasets/**).
+
+Every dataset yields `(inputs, forcing)`: `inputs` a float32 tensor (C, *N) whose channels are the coefficient / domain
+indicator field and the Dirichlet masks (bc1: u = 1 there, bc2: u = 0), `forcing` (1, *N).  The classes keep the reference's
+names, constructor arguments, attributes and sample counts; they are built on one small base class instead of one copy
+of the boilerplate per problem.
+
+`DeviceLoader` serves a static dataset from HBM: the samples are stacked once on the device and batches are views, so
+no DataLoader worker or PCIe copy sits in front of a 75-microsecond loss kernel."""
+import numpy as np
+import torch
+from torch.utils import data
+
+
+class GridDataset(data.Dataset):
+    """A fixed list of channel arrays + a forcing array, repeated `n_samples` times (the reference's single-instance
+    datasets return the same sample for every index)."""
+
+    n_samples = 100
+
+    def channels(self):
+        return [self.domain, self.bc1, self.bc2]
+
+    def forcing_array(self):
+        f = getattr(self, "forcing", None)
+        return np.zeros_like(self.domain) if f is None else f
+
+    def __len__(self):
+        return self.n_samples
+
+    def __getitem__(self, index):
+        inputs = np.array(self.channels())
+        return torch.FloatTensor(inputs), torch.FloatTensor(self.forcing_array()).unsqueeze(0)
+
+
+class StackedDataset(data.Dataset):
+    """Per-sample channel stacks `dataset[i]` of shape (C, *N) (the reference's parametric datasets)."""
+
+    forcing_value = 0.0
+
+    def __len__(self):
+        return self.n_samples
+
+    def __getitem__(self, index):
+        inputs = self.dataset[index]
+        forcing = np.full_like(inputs[0], self.forcing_value)
+        return torch.FloatTensor(inputs), torch.FloatTensor(forcing).unsqueeze(0)
+
+
+def faces(shape, *which):
+    """Zero array of `shape` with the named boundary faces set to 1: ("axis", index) pairs, e.g. (0, 0), (1, -1); "all"."""
+    m = np.zeros(shape)
+    if which == ("all",):
+        which = [(ax, i) for ax in range(len(shape)) for i in (0, -1)]
+    for ax, i in which:
+        idx = [slice(None)] * len(shape)
+        idx[ax] = i
+        m[tuple(idx)] = 1
+    return m
+
+
+def unit_grid(n):
+    """np.meshgrid(linspace(0,1,n), linspace(0,1,n)): xx varies along axis 1, yy along axis 0."""
+    t = np.linspace(0, 1, n)
+    return np.meshgrid(t, t)
+
+
+class DeviceLoader:
+    """Iterate a dataset in batches that already live on `device`.  Static datasets (every reference dataset) are
+    materialised once; `shuffle` permutes sample indices per epoch on the device."""
+
+    def __init__(self, dataset, batch_size, device="cuda", shuffle=False, drop_last=False, max_samples=None):
+        n = len(dataset) if max_samples is None else min(len(dataset), max_samples)
+        samples = [dataset[i] for i in range(n)]
+        self.tensors = tuple(torch.stack([s[k] for s in samples]).to(device) for k in range(len(samples[0])))
+        self.batch_size, self.shuffle, self.drop_last, self.n = batch_size, shuffle, drop_last, n
+
+    def __len__(self):
+        return self.n // self.batch_size if self.drop_last else -(-self.n // self.batch_size)
+
+    def __iter__(self):
+        order = torch.randperm(self.n, device=self.tensors[0].device) if self.shuffle else None
+        for b in range(len(self)):
+            lo, hi = b * self.batch_size, min((b + 1) * self.batch_size, self.n)
+            if order is None:
+                yield tuple(t[lo:hi] for t in self.tensors)
+            else:
+                yield tuple(t[order[lo:hi]] for t in self.tensors)

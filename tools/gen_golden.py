@@ -487,7 +487,7 @@ def gen_winding(outdir):
 
 
 if __name__ == "__main__":
-    if "--fdm" in sys.argv:
+    if "--fdm" in sys.argv or "--datasets" in sys.argv:
         pass
     elif "--winding" in sys.argv:
         install_shims()
@@ -521,3 +521,84 @@ def gen_fdm(outdir):
 if __name__ == "__main__" and "--fdm" in sys.argv:
     install_shims()
     gen_fdm(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))
+
+
+def gen_datasets(outdir):
+    """Datasets: first sample, length and auxiliary attributes of every reference dataset class; the
+    file-based ones run on small synthetic files whose bytes are stored in the fixture so the test can recreate them."""
+    import tempfile
+    import PIL.Image
+    from DiffNet.datasets.single_instances import rectangles, cuboids, circles, Lshaped, images as s_images, voxels, klsum as s_klsum
+    from DiffNet.datasets.parametric import images as p_images, klsum as p_klsum
+    from DiffNet import gen_input_calc
+    out = {}
+
+    def put(tag, ds, attrs=()):
+        x, f = ds[min(1, len(ds) - 1)]
+        out[tag + "/inputs"], out[tag + "/forcing"], out[tag + "/len"] = T(x), T(f), np.array(len(ds))
+        for a in attrs:
+            v = getattr(ds, a)
+            out[tag + "/attr_" + a] = T(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+
+    n = 72          # larger than the hard-coded 64-grid offsets of the immersed shapes
+    for name in ("Rectangle", "RectangleManufactured", "AdvDiff1dRectangle", "AdvDiff2dRectangle", "AllenCahnIceMeltRectangle",
+                 "RectangleManufacturedNonZeroBC", "RectangleHelmholtzManufactured", "RectangleHelmholtzDeltaForce",
+                 "RectangleManufacturedStokes", "RectangleIM", "RectangleIMBack"):
+        attrs = {"AllenCahnIceMeltRectangle": ("u0", "initial_guess"), "RectangleManufacturedNonZeroBC": ("u_exact",)}.get(name, ())
+        put("rect/" + name, getattr(rectangles, name)(domain_size=n), attrs)
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    put("rect/SpaceTimeRectangleManufactured", rectangles.SpaceTimeRectangleManufactured(domain_size=24), ("u0", "initial_guess"))
+    put("cuboid/Cuboid", cuboids.Cuboid(domain_size=12))
+    put("cuboid/CuboidManufactured", cuboids.CuboidManufactured(domain_size=12))
+    put("circle/CircleIMBack", circles.CircleIMBack(domain_size=n))
+    put("lshaped/LShaped", Lshaped.LShaped(domain_size=n))
+    g = np.random.RandomState(7)
+    with tempfile.TemporaryDirectory() as tmp:
+        # images: three small grey PNGs with blobs
+        imgdir = os.path.join(tmp, "imgs")
+        os.makedirs(imgdir)
+        for k in range(3):
+            a = np.zeros((20, 28), dtype=np.uint8)
+            r0, c0 = g.randint(2, 8), g.randint(2, 12)
+            a[r0:r0 + g.randint(3, 9), c0:c0 + g.randint(3, 12)] = g.randint(1, 255)
+            path = os.path.join(imgdir, f"shape{k}.png")
+            PIL.Image.fromarray(a).save(path)
+            out[f"files/img{k}"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+        put("img/single_ImageIMBack", s_images.ImageIMBack(os.path.join(imgdir, "shape1.png")))
+        put("img/single_Disk", s_images.Disk(os.path.join(imgdir, "shape2.png")))
+        for name in ("ImageIMBack", "ImageIMBackObject", "ImageIMBackNeumann"):
+            put("img/param_" + name, getattr(p_images, name)(imgdir))
+        # voxels: 9 x 7 x 5 object in a 48^3 background (offset 32 is hard-coded in the reference)
+        vox = (g.rand(9, 7, 5) > 0.5).astype(np.uint8) * 254
+        prefix = os.path.join(tmp, "obj_")
+        vox.flatten(order="F").tofile(prefix + "inouts.raw")
+        cfg = "voxel config\n0.0 0.0 0.0\n1.0 1.0 1.0\n9 7 5\n0.1 0.1 0.1\n100\n20\n"
+        open(prefix + "VoxelConfig.txt", "w").write(cfg)
+        out["files/vox_raw"] = np.frombuffer(open(prefix + "inouts.raw", "rb").read(), dtype=np.uint8)
+        out["files/vox_cfg"] = np.frombuffer(cfg.encode(), dtype=np.uint8)
+        put("vox/VoxelIMBackRAW", voxels.VoxelIMBackRAW(prefix, domain_size=48))
+        # KL sums
+        coeffs = g.randn(5, 6)
+        np.save(os.path.join(tmp, "coeffs.npy"), coeffs)
+        np.savetxt(os.path.join(tmp, "coeff.txt"), coeffs[3])
+        out["files/kl_coeffs"] = coeffs
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            ks = p_klsum.KLSumStochastic(os.path.join(tmp, "coeffs.npy"), domain_size=20, kl_terms=6)
+            ks4 = p_klsum.KLSumStochastic(os.path.join(tmp, "coeffs.npy"), domain_size=20, kl_terms=4)
+        put("kl/param_KLSumStochastic", ks)
+        out["kl/param_all"] = np.stack([T(ks[i][0]) for i in range(len(ks))])
+        out["kl/param_terms4"] = np.stack([T(ks4[i][0]) for i in range(len(ks4))])
+        put("kl/param_Dataset", p_klsum.Dataset(os.path.join(tmp, "coeff.txt"), domain_size=20))
+        put("kl/single_Dataset", s_klsum.Dataset(os.path.join(tmp, "coeff.txt"), domain_size=20))
+    for eta in (0.1, 0.2, 0.5, 0.7, 1.0):
+        out[f"kl/omega_{eta}"] = gen_input_calc.calculate_omega_based_on_eta(eta)
+    out["kl/nu3d"] = gen_input_calc.generate_diffusivity_tensor(coeffs[0], output_size=6, nsd=3)
+    np.savez_compressed(os.path.join(outdir, "datasets.npz"), **out)
+    print("datasets", len(out), "arrays")
+
+
+if __name__ == "__main__" and "--datasets" in sys.argv:
+    install_shims()
+    gen_datasets(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))
