@@ -112,3 +112,18 @@ def test_device_loader_batches_on_cpu():
     assert batches[0][0].shape == (8, 3, 16, 16) and batches[0][1].shape == (8, 1, 16, 16)
     dl2 = DeviceLoader(RectangleManufactured(16), batch_size=8, device="cpu", max_samples=20, shuffle=True, drop_last=True)
     assert len(list(dl2)) == 2
+
+
+def test_point_cloud_dataset_of_the_flagship_script(z, tmp_path):
+    """`PointClouds` (IBN_2D.py:35-84): npz layout, affine placement, squared-segment 'area' weights, sample layout."""
+    from DiffNet.datasets.parametric.pointclouds import PointClouds
+    prefix = str(tmp_path) + os.sep
+    np.savez(prefix + "point_cloud.npz", z["files/pc_points"])
+    np.savez(prefix + "normals.npz", z["files/pc_normals"])
+    ds = PointClouds(prefix, type='val', domain_size=24)
+    x, f, snk = ds[4]
+    assert len(ds) == int(z["pc/len"]) and x.shape == (40, 5)
+    np.testing.assert_array_equal(x.numpy(), z["pc/inputs"])
+    np.testing.assert_array_equal(f.numpy(), z["pc/forcing"])
+    np.testing.assert_array_equal(snk.numpy(), z["pc/sink"])
+    np.testing.assert_array_equal(ds.area, z["pc/area"])

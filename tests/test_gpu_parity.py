@@ -619,3 +619,24 @@ def test_graph_captured_training_iteration_matches_eager():
     assert outs[True][1] == outs[False][1]
     assert torch.equal(outs[True][0], outs[False][0])
     assert np.isfinite(outs[True][1]).all() and outs[True][1][-1] != outs[True][1][0]
+
+
+def test_flagship_ibn2d_flow_trains_on_the_fused_kernels():
+    """examples/ibn_2d_parametric.py (the flow of IBN_2D.py:111-170): point clouds -> winding-number mask (HIP) -> U-Net ->
+    fused energy loss.  The fused loss equals the reference's loss body on the drop-in operators on the same batch, and a
+    few epochs reduce it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ex_ibn2d", os.path.join(os.path.dirname(GOLDEN), "..", "examples", "ibn_2d_parametric.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    losses, model, loader = ex.run(size=64, shapes=32, epochs=6, batch=16, net="unet", verbose=False)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    model.eval()
+    batch = next(iter(loader))
+    with torch.no_grad():
+        u, src, f, snk = model.forward(batch)
+        assert 0.02 < float(src.mean()) < 0.6                      # the winding-number mask marks the shapes' interiors
+        fused = float(model.loss(u, src, f, snk))
+        model.dropin = True
+        ref = float(model.loss(u, src, f, snk))
+    np.testing.assert_allclose(fused, ref, rtol=2e-5)

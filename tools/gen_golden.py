@@ -592,6 +592,17 @@ def gen_datasets(outdir):
         out["kl/param_terms4"] = np.stack([T(ks4[i][0]) for i in range(len(ks4))])
         put("kl/param_Dataset", p_klsum.Dataset(os.path.join(tmp, "coeff.txt"), domain_size=20))
         put("kl/single_Dataset", s_klsum.Dataset(os.path.join(tmp, "coeff.txt"), domain_size=20))
+    # the PointClouds dataset of the flagship script (IBN_2D.py:35-84) on six synthetic closed curves
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    from diffnet_amd.datasets.parametric.pointclouds import write_star_shapes
+    ibn = load_script("IBN/poisson-2d/parametric/IBN_2D.py", "ref_ibn2d_ds")
+    with tempfile.TemporaryDirectory() as tmp:
+        raw, nrm = write_star_shapes(tmp + os.sep, n_shapes=6, n_points=40, seed=3)
+        out["files/pc_points"], out["files/pc_normals"] = raw, nrm
+        ds = ibn.PointClouds(tmp + os.sep, type='val', domain_size=24)
+        x, f, snk = ds[4]
+        out["pc/inputs"], out["pc/forcing"], out["pc/sink"], out["pc/len"] = T(x), T(f), T(snk), np.array(len(ds))
+        out["pc/area"] = ds.area
     for eta in (0.1, 0.2, 0.5, 0.7, 1.0):
         out[f"kl/omega_{eta}"] = gen_input_calc.calculate_omega_based_on_eta(eta)
     out["kl/nu3d"] = gen_input_calc.generate_diffusivity_tensor(coeffs[0], output_size=6, nsd=3)
