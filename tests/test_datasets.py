@@ -127,3 +127,17 @@ def test_point_cloud_dataset_of_the_flagship_script(z, tmp_path):
     np.testing.assert_array_equal(f.numpy(), z["pc/forcing"])
     np.testing.assert_array_equal(snk.numpy(), z["pc/sink"])
     np.testing.assert_array_equal(ds.area, z["pc/area"])
+
+
+def test_topo3d_dataset_layout(tmp_path):
+    """`TopoDataset3D` (IBN_3D.py:76-106): one npz per object, (source, sink, forcing) samples, 100 / 25 split."""
+    from DiffNet.datasets.parametric.topo3d import TopoDataset3D, write_blob_objects
+    write_blob_objects(str(tmp_path), n_objects=5, domain_size=8, seed=1)
+    ds = TopoDataset3D(str(tmp_path), domain_size=8, mode='train')
+    assert len(ds) == 5 and len(TopoDataset3D(str(tmp_path), domain_size=8, mode='val')) == 0
+    src, snk, f = ds[2]
+    assert src.shape == snk.shape == f.shape == (1, 8, 8, 8) and float(f.abs().max()) == 0.0
+    ref = np.load(os.path.join(str(tmp_path), ds.list_IDs[2]))['arr_0']
+    np.testing.assert_array_equal(src.numpy(), ref)
+    b = snk[0].numpy()
+    assert b[0].all() and b[-1].all() and b[:, 0].all() and b[:, :, -1].all() and b[1:-1, 1:-1, 1:-1].sum() == 0

@@ -640,3 +640,21 @@ def test_flagship_ibn2d_flow_trains_on_the_fused_kernels():
         model.dropin = True
         ref = float(model.loss(u, src, f, snk))
     np.testing.assert_allclose(fused, ref, rtol=2e-5)
+
+
+def test_flagship_ibn3d_flow_trains_on_the_fused_kernels():
+    """examples/ibn_3d_parametric.py (IBN_3D.py:109-162): voxel object -> GoodGenerator (HIP output block + weight gradients)
+    -> fused 3-D energy loss; equals the reference loss body on the drop-in operators; a few epochs reduce it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ex_ibn3d", os.path.join(os.path.dirname(GOLDEN), "..", "examples", "ibn_3d_parametric.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    losses, model, loader = ex.run(size=32, objects=8, epochs=5, batch=2, verbose=False)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    model.eval()
+    with torch.no_grad():
+        u, src, snk, f = model.forward(next(iter(loader)))
+        fused = float(model.loss(u, src, snk, f))
+        model.dropin = True
+        ref = float(model.loss(u, src, snk, f))
+    np.testing.assert_allclose(fused, ref, rtol=2e-5)
