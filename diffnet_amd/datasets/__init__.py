@@ -67,11 +67,14 @@ def unit_grid(n):
 
 class DeviceLoader:
     """Iterate a dataset in batches that already live on `device`.  Static datasets (every reference dataset) are
-    materialised once; `shuffle` permutes sample indices per epoch on the device."""
+    materialised once; `shuffle` permutes sample indices per epoch on the device.  `rank` / `world` select a strided
+    shard for data-parallel training (`Trainer(strategy="ddp")`)."""
 
-    def __init__(self, dataset, batch_size, device="cuda", shuffle=False, drop_last=False, max_samples=None):
+    def __init__(self, dataset, batch_size, device="cuda", shuffle=False, drop_last=False, max_samples=None, rank=0, world=1):
         n = len(dataset) if max_samples is None else min(len(dataset), max_samples)
-        samples = [dataset[i] for i in range(n)]
+        n -= n % world                                  # equal shards: every rank runs the same number of steps
+        samples = [dataset[i] for i in range(rank, n, world)]     # data-parallel ranks take every world-th sample
+        n = len(samples)
         self.tensors = tuple(torch.stack([s[k] for s in samples]).to(device) for k in range(len(samples[0])))
         self.batch_size, self.shuffle, self.drop_last, self.n = batch_size, shuffle, drop_last, n
 

@@ -19,8 +19,10 @@ def _to(batch, device):
 
 
 class Trainer:
-    def __init__(self, max_epochs=1, device=None, callbacks=(), max_steps=None, graph=False, graph_warmup=3, log_every=1):
+    def __init__(self, max_epochs=1, device=None, callbacks=(), max_steps=None, graph=False, graph_warmup=3, log_every=1,
+                 strategy=None):
         self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.strategy = strategy
         self.graph, self.graph_warmup, self.log_every = graph, graph_warmup, max(1, log_every)
         self.device = torch.device(device) if device is not None else torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
         self.callbacks = list(callbacks)
@@ -78,8 +80,26 @@ class Trainer:
         self._graph = g
         return self
 
+    def _wrap_ddp(self, module):
+        """strategy="ddp" (the reference's `pl.Trainer(strategy='ddp')`, IBN_3D.py:193-195): one process per GPU, the
+        network replicated, gradients averaged by bucketed all-reduces (RCCL on ROCm) overlapped with backward.  The
+        process group must exist (torchrun / torch.distributed.run); every rank feeds its own shard of the data, e.g.
+        `DeviceLoader(..., rank=r, world=n)`."""
+        import torch.distributed as dist
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('Trainer(strategy="ddp") needs an initialised process group (launch with torch.distributed.run)')
+        if dist.get_world_size() > 1 and any(p.requires_grad for p in module.network.parameters()):
+            ids = [self.device.index] if self.device.type == "cuda" else None
+            module.network = DDP(module.network, device_ids=ids)
+        return module
+
     def fit(self, module, train_dataloaders, val_dataloaders=None):
         module.to(self.device)
+        if self.strategy == "ddp":
+            self._wrap_ddp(module)
+        elif self.strategy is not None:
+            raise ValueError(f"unknown strategy {self.strategy!r} (None or 'ddp')")
         conf = module.configure_optimizers()
         opts, scheds = conf if isinstance(conf, tuple) else (conf, [])
         opts = list(opts) if isinstance(opts, (list, tuple)) else [opts]
