@@ -5,8 +5,12 @@
 // launch produces all G channels: a thread owns one element, keeps its nbf^nsd nodal values in
 // registers and streams the G x nbf^nsd table out of LDS (wave-uniform address => broadcast reads).
 // HBM: read 4 B/node (+ overlap served by L1/L2), write 4*G B/element -- write dominated.
-// The adjoint is in gather form: a thread owns one node and sums, in a fixed order, the
-// contributions of the <= 2^nsd elements that contain it, so every output is written exactly once.
+// The adjoint writes every output exactly once and sums in a fixed order.  Standard FEM layout (stride = nbf - 1): tiled
+// element-centric kernel (gpe_bwd_tiled_kernel: gradient planes read once, coalesced, 4 planes x R elements in flight
+// per thread; contributions staged in LDS, nodes gathered from LDS); branch-free per-node gather kernels where the LDS
+// tile does not fit (3-D Q2/Q3) and a general gather for arbitrary strides.  Assembly: branch-free per-node gather.
+#include <cstdlib>
+
 #include "dn_common.h"
 
 namespace dn {
@@ -88,6 +92,281 @@ __global__ void __launch_bounds__(256) gpe_bwd_kernel(const float* __restrict__ 
                     for (int gi = 0; gi < g.G; ++gi) s = fmaf(tab[gi * NBT + aa], gsrc[(int64_t)gi * nel_s + e], s);
                 }
         gin[idx] = s;
+    }
+}
+
+// Standard FEM layout (stride == NB - 1: neighbouring elements share one node layer): a node lies in at most two elements
+// per axis -- e1 = min(x / S, nel - 1) with local index l1 = x - e1 S, and, when l1 == 0 and e1 >= 1, also e1 - 1 with local
+// index S.  Branch-free gather: the <= 2^NSD candidate elements are addressed with clamped indices, their table-weighted
+// sums over the G Gauss points run as independent chains (loads batched by the compiler), invalid candidates are
+// selected away, and the partial sums are combined in a fixed order (lower element first, x fastest).
+template <int NSD>
+struct NodeCand {
+    int e[3][2], l[3][2];
+    bool ok[3][2];
+};
+
+template <int NSD, int NB>
+__device__ __forceinline__ NodeCand<NSD> node_candidates(const int (&xyz)[3], const GpeGeom& g) {
+    constexpr int S = NB - 1;
+    NodeCand<NSD> c;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (d >= NSD) { c.e[d][0] = c.e[d][1] = 0; c.l[d][0] = c.l[d][1] = 0; c.ok[d][0] = false; c.ok[d][1] = true; continue; }
+        const int e1 = min(xyz[d] / S, g.nel[d] - 1), l1 = xyz[d] - e1 * S;
+        c.e[d][1] = e1; c.l[d][1] = l1; c.ok[d][1] = true;
+        c.ok[d][0] = (l1 == 0) && (e1 >= 1);                 // slot 0: the lower neighbour, local index S
+        c.e[d][0] = max(e1 - 1, 0); c.l[d][0] = S;
+    }
+    return c;
+}
+
+template <int NSD, int NB>
+__global__ void __launch_bounds__(256) gpe_bwd_std_kernel(const float* __restrict__ gout, const float* __restrict__ tables,
+                                                          float* __restrict__ gin, const GpeGeom g) {
+    constexpr int NBT = NSD == 1 ? NB : (NSD == 2 ? NB * NB : NB * NB * NB);
+    constexpr int NC = 1 << NSD;
+    // table transposed to [local node][Gauss point], rows padded to a multiple of 4: a candidate's G weights are
+    // contiguous and come in with float4 LDS reads
+    extern __shared__ __attribute__((aligned(16))) float tabT[];
+    const int GP = (g.G + 3) & ~3;
+    for (int i = threadIdx.x; i < NBT * GP; i += blockDim.x) {
+        const int a = i / GP, gi = i - a * GP;
+        tabT[i] = gi < g.G ? tables[gi * NBT + a] : 0.f;
+    }
+    __syncthreads();
+    const unsigned nel_s = (unsigned)(g.nel[0] * g.nel[1] * g.nel[2]);
+    const int64_t nps = (int64_t)g.n[0] * g.n[1] * g.n[2];
+    const int64_t total = nps * g.batch;
+    const unsigned gmax = (unsigned)(g.G - 1);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / nps);
+        const unsigned nd = (unsigned)(idx - (int64_t)b * nps);
+        const int xyz[3] = {(int)(nd % (unsigned)g.n[0]), (int)((nd / (unsigned)g.n[0]) % (unsigned)g.n[1]),
+                            (int)(nd / ((unsigned)g.n[0] * (unsigned)g.n[1]))};
+        const NodeCand<NSD> c = node_candidates<NSD, NB>(xyz, g);
+        const float* gsrc = gout + (int64_t)b * g.G * nel_s;
+        unsigned eo[NC], ao[NC];
+        bool ok[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {               // q bits: x = bit 0, y = bit 1, z = bit 2; 0 = lower neighbour
+            const int cx = q & 1, cy = NSD > 1 ? (q >> 1) & 1 : 1, cz = NSD > 2 ? (q >> 2) & 1 : 1;
+            eo[q] = ((unsigned)c.e[2][cz] * (unsigned)g.nel[1] + (unsigned)c.e[1][cy]) * (unsigned)g.nel[0] + (unsigned)c.e[0][cx];
+            ao[q] = (unsigned)((c.l[2][cz] * NB + c.l[1][cy]) * NB + c.l[0][cx]) * (unsigned)GP;
+            ok[q] = c.ok[0][cx] && (NSD > 1 ? c.ok[1][cy] : true) && (NSD > 2 ? c.ok[2][cz] : true);
+        }
+        float part[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) part[q] = 0.f;
+        for (int g0 = 0; g0 < GP; g0 += 4) {
+            // the padded weights are zero; their (clamped, valid) loads contribute nothing
+            const unsigned o0 = (unsigned)g0 * nel_s, o1 = min((unsigned)g0 + 1, gmax) * nel_s, o2 = min((unsigned)g0 + 2, gmax) * nel_s,
+                           o3 = min((unsigned)g0 + 3, gmax) * nel_s;
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const float4 w = *reinterpret_cast<const float4*>(&tabT[ao[q] + g0]);
+                float p = part[q];
+                p = fmaf(w.x, gsrc[o0 + eo[q]], p);
+                p = fmaf(w.y, gsrc[o1 + eo[q]], p);
+                p = fmaf(w.z, gsrc[o2 + eo[q]], p);
+                p = fmaf(w.w, gsrc[o3 + eo[q]], p);
+                part[q] = p;
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) sum += ok[q] ? part[q] : 0.f;
+        gin[idx] = sum;
+    }
+}
+
+// Same gather with the table as given ([Gauss point][local node], one LDS read per weight): faster than the transposed
+// form for 3-D Q2/Q3, where most nodes have few valid candidates and the 112-byte rows of the transposed table conflict.
+template <int NSD, int NB>
+__global__ void __launch_bounds__(256) gpe_bwd_std_scalar_kernel(const float* __restrict__ gout, const float* __restrict__ tables,
+                                                                 float* __restrict__ gin, const GpeGeom g) {
+    constexpr int NBT = NSD == 1 ? NB : (NSD == 2 ? NB * NB : NB * NB * NB);
+    constexpr int NC = 1 << NSD;
+    extern __shared__ __attribute__((aligned(16))) float tabT[];
+    for (int i = threadIdx.x; i < g.G * NBT; i += blockDim.x) tabT[i] = tables[i];
+    __syncthreads();
+    const unsigned nel_s = (unsigned)(g.nel[0] * g.nel[1] * g.nel[2]);
+    const int64_t nps = (int64_t)g.n[0] * g.n[1] * g.n[2];
+    const int64_t total = nps * g.batch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / nps);
+        const unsigned nd = (unsigned)(idx - (int64_t)b * nps);
+        const int xyz[3] = {(int)(nd % (unsigned)g.n[0]), (int)((nd / (unsigned)g.n[0]) % (unsigned)g.n[1]),
+                            (int)(nd / ((unsigned)g.n[0] * (unsigned)g.n[1]))};
+        const NodeCand<NSD> c = node_candidates<NSD, NB>(xyz, g);
+        const float* gsrc = gout + (int64_t)b * g.G * nel_s;
+        unsigned eo[NC], ao[NC];
+        bool ok[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int cx = q & 1, cy = NSD > 1 ? (q >> 1) & 1 : 1, cz = NSD > 2 ? (q >> 2) & 1 : 1;
+            eo[q] = ((unsigned)c.e[2][cz] * (unsigned)g.nel[1] + (unsigned)c.e[1][cy]) * (unsigned)g.nel[0] + (unsigned)c.e[0][cx];
+            ao[q] = (unsigned)((c.l[2][cz] * NB + c.l[1][cy]) * NB + c.l[0][cx]);
+            ok[q] = c.ok[0][cx] && (NSD > 1 ? c.ok[1][cy] : true) && (NSD > 2 ? c.ok[2][cz] : true);
+        }
+        float part[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) part[q] = 0.f;
+        for (int gi = 0; gi < g.G; ++gi) {
+            const float* gp = gsrc + (size_t)gi * nel_s;
+            const float* tp = tabT + gi * NBT;
+#pragma unroll
+            for (int q = 0; q < NC; ++q) part[q] = fmaf(tp[ao[q]], gp[eo[q]], part[q]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) sum += ok[q] ? part[q] : 0.f;
+        gin[idx] = sum;
+    }
+}
+
+// Element-centric adjoint for the standard layout (the fast path): a workgroup owns a tile of 32 x 32 elements (2-D) or
+// 32 x 8 x 8 elements (3-D); thread (tx, ty) walks the tile's element rows / planes.  Phase A: per element the G
+// gradient values are read once (coalesced) and its NB^NSD nodal contributions sum_g tab[g][a] gout[g] (table through
+// scalar loads: uniform index) go to LDS as contrib[a][element] -- one slot per (element, a), no conflicts.  Phase B: the
+// tile's nodes are gathered from LDS (<= 2^NSD slots each, lower element first: fixed order) and written once.  Tiles
+// overlap by one element layer on the high side (recomputed) and own the nodes above their low face.
+template <int NSD, int NB>
+__global__ void __launch_bounds__(256) gpe_bwd_tiled_kernel(const float* __restrict__ gout, const float* __restrict__ tables,
+                                                            float* __restrict__ gin, const GpeGeom g, const int tiles_x, const int tiles_y,
+                                                            const int tiles_z) {
+    constexpr int S = NB - 1;
+    constexpr int NBT = NSD == 2 ? NB * NB : NB * NB * NB;
+    constexpr int TX = 32, TY = NSD == 2 ? 32 : 8, TZ = NSD == 2 ? 1 : 8;       // elements per tile (incl. the recomputed layer)
+    constexpr int TE = TX * TY * TZ;
+    constexpr int LX = TX * S + 1, LY = TY * S + 1, LZ = NSD == 2 ? 1 : TZ * S + 1;
+    extern __shared__ float contrib[];                                          // [NBT][TZ][TY][TX]
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                     // 32 x 8 threads
+    unsigned t = blockIdx.x;
+    const int tix = (int)(t % (unsigned)tiles_x); t /= (unsigned)tiles_x;
+    const int tiy = (int)(t % (unsigned)tiles_y); t /= (unsigned)tiles_y;
+    const int tiz = (int)(t % (unsigned)tiles_z);
+    const int b = (int)(t / (unsigned)tiles_z);
+    const int ex0 = tix * (TX - 1), ey0 = tiy * (TY - 1), ez0 = NSD == 2 ? 0 : tiz * (TZ - 1);
+    const unsigned nel_s = (unsigned)(g.nel[0] * g.nel[1] * g.nel[2]);
+    const int64_t nps = (int64_t)g.n[0] * g.n[1] * g.n[2];
+    const float* gsrc = gout + (int64_t)b * g.G * nel_s;
+    // phase A.  this thread's elements: 2-D: (tx, ty + 8 r), r < 4;  3-D: (tx, ty, r), r < 8.  The Gauss-point planes are
+    // walked four at a time and all R elements' loads of a chunk are issued before their FMAs (4 R loads in flight per
+    // thread: the planes are megabytes apart, so a one-load-at-a-time loop is latency bound).
+    constexpr int R = TE / 256;
+    const int ex = ex0 + tx;
+    unsigned eoff[R];
+    bool valid[R];
+    float c[R][NBT];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int ly_e = NSD == 2 ? ty + 8 * r : ty, lz_e = NSD == 2 ? 0 : r;
+        const int ey = ey0 + ly_e, ez = ez0 + lz_e;
+        valid[r] = ex < g.nel[0] && ey < g.nel[1] && ez < g.nel[2];
+        eoff[r] = ((unsigned)min(ez, g.nel[2] - 1) * (unsigned)g.nel[1] + (unsigned)min(ey, g.nel[1] - 1)) * (unsigned)g.nel[0] +
+                  (unsigned)min(ex, g.nel[0] - 1);
+#pragma unroll
+        for (int a = 0; a < NBT; ++a) c[r][a] = 0.f;
+    }
+    const int gmax = g.G - 1;
+    for (int g0 = 0; g0 < g.G; g0 += 4) {
+        float v[R][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t po = (size_t)min(g0 + k, gmax) * nel_s;          // clamped: the duplicate gets a zero weight below
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r][k] = gsrc[po + eoff[r]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool live = g0 + k <= gmax;
+            const float* tp = tables + min(g0 + k, gmax) * NBT;
+#pragma unroll
+            for (int a = 0; a < NBT; ++a) {
+                const float w = live ? tp[a] : 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) c[r][a] = fmaf(w, v[r][k], c[r][a]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int ly_e = NSD == 2 ? ty + 8 * r : ty, lz_e = NSD == 2 ? 0 : r;
+        const int slot = (lz_e * TY + ly_e) * TX + tx;
+#pragma unroll
+        for (int a = 0; a < NBT; ++a) contrib[a * TE + slot] = valid[r] ? c[r][a] : 0.f;      // elements beyond the mesh contribute zero
+    }
+    __syncthreads();
+    // phase B.  owned nodes: local index 1 .. (T-1) S per axis (0 too on the first tile; the whole tile on the last)
+    float* dst = gin + (int64_t)b * nps;
+    const int lox = tix == 0 ? 0 : 1, loy = tiy == 0 ? 0 : 1, loz = (NSD == 2 || tiz == 0) ? 0 : 1;
+    const int HX = tix == tiles_x - 1 ? LX - 1 : (TX - 1) * S, HY = tiy == tiles_y - 1 ? LY - 1 : (TY - 1) * S;
+    const int HZ = NSD == 2 ? 0 : (tiz == tiles_z - 1 ? LZ - 1 : (TZ - 1) * S);
+    for (int i = threadIdx.x; i < LX * LY * LZ; i += 256) {
+        const int lx = i % LX, ly = (i / LX) % LY, lz = i / (LX * LY);
+        const int x = ex0 * S + lx, y = ey0 * S + ly, z = ez0 * S + lz;
+        if (!(lx >= lox && lx <= HX && ly >= loy && ly <= HY && lz >= loz && lz <= HZ && x < g.n[0] && y < g.n[1] && z < g.n[2])) continue;
+        // per axis: upper element e1 = min(l / S, T - 1) with local index l - e1 S; lower neighbour (local S) if that is 0 and e1 >= 1
+        int e1[3], l1[3];
+        bool two[3];
+        const int lxyz[3] = {lx, ly, lz};
+        const int TT[3] = {TX, TY, TZ};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (d >= NSD) { e1[d] = 0; l1[d] = 0; two[d] = false; continue; }
+            e1[d] = min(lxyz[d] / S, TT[d] - 1);
+            l1[d] = lxyz[d] - e1[d] * S;
+            two[d] = l1[d] == 0 && e1[d] >= 1;
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < (1 << NSD); ++q) {          // bit = 0: lower neighbour (if any), 1: upper element; x fastest
+            const int cx = q & 1, cy = (q >> 1) & 1, cz = NSD > 2 ? (q >> 2) & 1 : 1;
+            const bool ok = (cx || two[0]) && (cy || two[1]) && (NSD == 2 || cz || two[2]);
+            const int exl = cx ? e1[0] : max(e1[0] - 1, 0), eyl = cy ? e1[1] : max(e1[1] - 1, 0), ezl = cz ? e1[2] : max(e1[2] - 1, 0);
+            const int ia = cx ? l1[0] : S, ja = cy ? l1[1] : S, ka = NSD == 2 ? 0 : (cz ? l1[2] : S);
+            const float v = contrib[((ka * NB + ja) * NB + ia) * TE + (ezl * TY + eyl) * TX + exl];
+            sum += ok ? v : 0.f;
+        }
+        dst[((size_t)z * g.n[1] + y) * g.n[0] + x] = sum;
+    }
+}
+
+// Standard-layout assembly: all candidate loads first, then added in ascending local id (upper element = local 0 first),
+// the order of the reference's sliced "+=" lines.
+template <int NSD, int NB>
+__global__ void __launch_bounds__(256) assemble_std_kernel(const float* __restrict__ rs, float* __restrict__ out, const GpeGeom g,
+                                                           const int accumulate) {
+    constexpr int NBT = NSD == 2 ? NB * NB : NB * NB * NB;
+    constexpr int NC = 1 << NSD;
+    const unsigned nel_s = (unsigned)(g.nel[0] * g.nel[1] * g.nel[2]);
+    const int64_t nps = (int64_t)g.n[0] * g.n[1] * g.n[2];
+    const int64_t total = nps * g.batch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / nps);
+        const unsigned nd = (unsigned)(idx - (int64_t)b * nps);
+        const int xyz[3] = {(int)(nd % (unsigned)g.n[0]), (int)((nd / (unsigned)g.n[0]) % (unsigned)g.n[1]),
+                            (int)(nd / ((unsigned)g.n[0] * (unsigned)g.n[1]))};
+        const NodeCand<NSD> c = node_candidates<NSD, NB>(xyz, g);
+        const float* src = rs + (int64_t)b * NBT * nel_s;
+        float v[NC];
+        bool ok[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            // ascending local id: local index 0 (slot 1 when the node is shared... i.e. the upper element) before local S
+            // (slot 0); per axis "first" = slot 1, "second" = slot 0; z is the slowest digit of the local id
+            const int fx = q & 1, fy = (q >> 1) & 1, fz = NSD > 2 ? (q >> 2) & 1 : 0;
+            const int cx = 1 - fx, cy = 1 - fy, cz = NSD > 2 ? 1 - fz : 1;
+            const unsigned e = ((unsigned)c.e[2][cz] * (unsigned)g.nel[1] + (unsigned)c.e[1][cy]) * (unsigned)g.nel[0] + (unsigned)c.e[0][cx];
+            const unsigned a = (unsigned)(NSD == 2 ? c.l[1][cy] * NB + c.l[0][cx] : (c.l[2][cz] * NB + c.l[1][cy]) * NB + c.l[0][cx]);
+            ok[q] = c.ok[0][cx] && c.ok[1][cy] && (NSD > 2 ? c.ok[2][cz] : true);
+            v[q] = src[(size_t)a * nel_s + e];
+        }
+        float s = accumulate ? out[idx] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) s += ok[q] ? v[q] : 0.f;
+        out[idx] = s;
     }
 }
 
@@ -218,9 +497,47 @@ extern "C" int dn_gauss_pt_eval_bwd(const float* grad_out, const float* tables, 
     if (lds > 64 * 1024) return DN_E_UNSUPPORTED;
     const int64_t total = (int64_t)g.n[0] * g.n[1] * g.n[2] * batch;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds_t = sizeof(float) * (size_t)nbt * ((G + 3) & ~3);
+    if (stride == nbf - 1 && lds_t <= 64 * 1024 && (int64_t)g.nel[0] * g.nel[1] * g.nel[2] * G < (1ll << 31) &&
+        (int64_t)g.n[0] * g.n[1] * g.n[2] < (1ll << 31)) {
+    {   // tiled element-centric adjoint where its LDS tile fits (all 2-D cases, 3-D Q1 / Q2)
+        const int S = nbf - 1;
+        const size_t tile_floats = (size_t)nbt * (nsd == 2 ? 1024 : 2048);       // contrib[NB^nsd][tile elements]
+        (void)S;
+        if (nsd >= 2 && tile_floats * sizeof(float) <= 96 * 1024 && getenv("DN_GPE_GATHER") == nullptr) {
+            const int tx_ = g.nel[0] <= 32 ? 1 : (g.nel[0] - 1 + 30) / 31;
+            const int ty_ = nsd == 2 ? (g.nel[1] <= 32 ? 1 : (g.nel[1] - 1 + 30) / 31) : (g.nel[1] <= 8 ? 1 : (g.nel[1] - 1 + 6) / 7);
+            const int tz_ = nsd == 2 ? 1 : (g.nel[2] <= 8 ? 1 : (g.nel[2] - 1 + 6) / 7);
+            const int64_t nblk = (int64_t)tx_ * ty_ * tz_ * batch;
+            if (nblk < (1ll << 31)) {
+#define K_BWDT(NSD, NB) hipLaunchKernelGGL((gpe_bwd_tiled_kernel<NSD, NB>), dim3((unsigned)nblk), dim3(256), tile_floats * sizeof(float), s, grad_out, tables, grad_in, g, tx_, ty_, tz_)
+                switch (nsd * 10 + nbf) {
+                    case 22: K_BWDT(2, 2); break;
+                    case 23: K_BWDT(2, 3); break;
+                    case 24: K_BWDT(2, 4); break;
+                    case 32: K_BWDT(3, 2); break;
+                    default: K_BWDT(3, 3); break;
+                }
+#undef K_BWDT
+                DN_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
+#define K_BWDS(NSD, NB, ...)                                                                                                                  \
+    do {                                                                                                                                      \
+        if (NSD == 3 && NB >= 3)                                                                                                              \
+            hipLaunchKernelGGL((gpe_bwd_std_scalar_kernel<NSD, NB>), dim3(grid_for(total)), dim3(256), lds, s, grad_out, tables, grad_in, g); \
+        else                                                                                                                                  \
+            hipLaunchKernelGGL((gpe_bwd_std_kernel<NSD, NB>), dim3(grid_for(total)), dim3(256), lds_t, s, grad_out, tables, grad_in, g);      \
+    } while (0)
+        DN_DISPATCH_NSD_NB(K_BWDS, nsd, nbf, 0)
+#undef K_BWDS
+    } else {
 #define K_BWD(NSD, NB, ...) hipLaunchKernelGGL((gpe_bwd_kernel<NSD, NB>), dim3(grid_for(total)), dim3(256), lds, s, grad_out, tables, grad_in, g)
-    DN_DISPATCH_NSD_NB(K_BWD, nsd, nbf, 0)
+        DN_DISPATCH_NSD_NB(K_BWD, nsd, nbf, 0)
 #undef K_BWD
+    }
     DN_LAUNCH_CHECK();
     return 0;
 }
@@ -233,7 +550,13 @@ extern "C" int dn_assemble(const float* r_split, float* out, int32_t batch, int3
     if (!r_split || !out || nsd < 2 || stride != nbf - 1) return DN_E_BADARG;
     const int64_t total = (int64_t)g.n[0] * g.n[1] * g.n[2] * batch;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define K_ASM(NSD, NB, ...) hipLaunchKernelGGL((assemble_kernel<NSD, NB>), dim3(grid_for(total)), dim3(256), 0, s, r_split, out, g, accumulate)
+    const bool small = (int64_t)g.nel[0] * g.nel[1] * g.nel[2] * nbf * nbf * (nsd == 3 ? nbf : 1) < (1ll << 31) &&
+                       (int64_t)g.n[0] * g.n[1] * g.n[2] < (1ll << 31);
+#define K_ASM(NSD, NB, ...)                                                                                                               \
+    do {                                                                                                                                  \
+        if (small) hipLaunchKernelGGL((assemble_std_kernel<NSD, NB>), dim3(grid_for(total)), dim3(256), 0, s, r_split, out, g, accumulate); \
+        else hipLaunchKernelGGL((assemble_kernel<NSD, NB>), dim3(grid_for(total)), dim3(256), 0, s, r_split, out, g, accumulate);          \
+    } while (0)
     switch (nsd * 10 + nbf) {
         case 22: K_ASM(2, 2); break;
         case 23: K_ASM(2, 3); break;
