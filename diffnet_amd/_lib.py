@@ -43,7 +43,8 @@ class DnFsdtArgs(C.Structure):
                 ("bc_field", C.c_void_p * 3), ("bc_field_batched", C.c_int32 * 3), ("bc_value", C.c_float * 3),
                 ("D11", C.c_float), ("D12", C.c_float), ("D22", C.c_float), ("D66", C.c_float), ("A44", C.c_float),
                 ("A55", C.c_float), ("q", C.c_float), ("wscale", C.c_float),
-                ("out", C.c_void_p * 3), ("sumsq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("out", C.c_void_p * 3), ("sumsq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("in_scale", C.c_void_p)]
 
 
 I32x3 = C.c_int32 * 3

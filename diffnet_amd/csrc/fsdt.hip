@@ -29,6 +29,7 @@ struct FsdtParams {
     float w2[4][4];                        // w[jg] * w[ig] * wscale
     float D11, D12, D22, D66, A44, A55, q;
     const float* fld[3];                   // w, phi_x, phi_y
+    const float* in_scale;                 // optional 3 device floats: field k is scaled as it is loaded
     const void* mask;
     int mask_is_u8, mask_batched;
     const float* bcf[3];
@@ -189,6 +190,9 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
     const uint8_t* m8 = (p.mask && p.mask_is_u8) ? reinterpret_cast<const uint8_t*>(p.mask) + mo : nullptr;
     const float* mf = (p.mask && !p.mask_is_u8) ? reinterpret_cast<const float*>(p.mask) + mo : nullptr;
 
+    float fscale[3] = {1.f, 1.f, 1.f};
+    if (p.in_scale) { fscale[0] = p.in_scale[0]; fscale[1] = p.in_scale[1]; fscale[2] = p.in_scale[2]; }
+
     __shared__ float xch[2][3][P][256];
     __shared__ double red[8];
     __shared__ int last_flag;
@@ -208,7 +212,11 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
     auto load_row = [&](int r, int yr) {
         const unsigned rowoff = (unsigned)yr * (unsigned)p.nx;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) load_seg<NW, false>(fb[k], rowoff, x0, p.nx, cu[k][r]);
+        for (int k = 0; k < 3; ++k) {
+            load_seg<NW, false>(fb[k], rowoff, x0, p.nx, cu[k][r]);
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) cu[k][r][n] *= fscale[k];
+        }
         unsigned bits = 0u;
         if (m8) {
             uint8_t t[NW + 1];
@@ -387,6 +395,7 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
         }
     pp.D11 = a->D11; pp.D12 = a->D12; pp.D22 = a->D22; pp.D66 = a->D66; pp.A44 = a->A44; pp.A55 = a->A55; pp.q = a->q;
     pp.fld[0] = a->w; pp.fld[1] = a->phi_x; pp.fld[2] = a->phi_y;
+    pp.in_scale = a->in_scale;
     pp.mask = a->bc_mask; pp.mask_is_u8 = a->mask_is_u8; pp.mask_batched = a->mask_batched;
     for (int k = 0; k < 3; ++k) {
         pp.bcf[k] = a->bc_field[k]; pp.bcf_batched[k] = a->bc_field_batched[k]; pp.bcv[k] = a->bc_value[k];

@@ -86,7 +86,8 @@ def fsdt_residuals_composed(fem, w, phi_x, phi_y, bc, w_bc=0.0, phi_x_bc=0.0, ph
 
 
 class _FsdtLoss(torch.autograd.Function):
-    """The three Frobenius norms from the launch that computes the residuals (in-kernel fixed-order fp64 sums)."""
+    """The three Frobenius norms (one (3,) tensor) from the launch that computes the residuals (in-kernel fixed-order
+    fp64 sums); the VJP is one more launch: the kernel scales the saved residuals by gout_k / ||R_k|| as it loads them."""
 
     @staticmethod
     def forward(ctx, w, phi_x, phi_y, fem, bc, bc_values, consts, q, wscale):
@@ -94,13 +95,14 @@ class _FsdtLoss(torch.autograd.Function):
         norms = sums.sqrt().float()
         ctx.save_for_backward(*outs, norms)
         ctx.fem, ctx.bc, ctx.consts, ctx.wscale = fem, bc, consts, wscale
-        return norms[0], norms[1], norms[2]
+        return norms
 
     @staticmethod
-    def backward(ctx, g1, g2, g3):
+    def backward(ctx, gnorms):
         *Rs, norms = ctx.saved_tensors
-        cots = [R * (g / n) for R, g, n in zip(Rs, (g1, g2, g3), norms)]           # d||R||/dR = R / ||R||
-        outs, _ = ops.fsdt_apply(ctx.fem.geom, *cots, ctx.bc, (0.0, 0.0, 0.0), q=0.0, wscale=ctx.wscale, want_sums=False, **ctx.consts)
+        scale = (gnorms / norms).contiguous()                                   # d||R_k||/dR_k = R_k / ||R_k||
+        outs, _ = ops.fsdt_apply(ctx.fem.geom, *Rs, ctx.bc, (0.0, 0.0, 0.0), q=0.0, wscale=ctx.wscale, want_sums=False, in_scale=scale,
+                                 **ctx.consts)
         return outs[0], outs[1], outs[2], None, None, None, None, None, None
 
 
@@ -108,4 +110,5 @@ def fsdt_loss(fem, w, phi_x, phi_y, bc, w_bc=0.0, phi_x_bc=0.0, phi_y_bc=0.0, E=
     """Frobenius norms of the three residuals (e1_plate_bending_fsdt.py:230-232); one launch forward, one backward."""
     hx = fem.h if hx is None else hx
     hy = fem.h if hy is None else hy
-    return _FsdtLoss.apply(w, phi_x, phi_y, fem, bc, (w_bc, phi_x_bc, phi_y_bc), _constants(E, v, h, K_s), q, (0.5 * hx) * (0.5 * hy))
+    norms = _FsdtLoss.apply(w, phi_x, phi_y, fem, bc, (w_bc, phi_x_bc, phi_y_bc), _constants(E, v, h, K_s), q, (0.5 * hx) * (0.5 * hy))
+    return norms.unbind(0)

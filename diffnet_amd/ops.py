@@ -343,11 +343,15 @@ def residual_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
     return _ResidualLoss.apply(u, geom, nu, f, f_gp, tuple(_norm_dirichlet(dirichlet)), float(jac))
 
 
+_FSDT_WS_BYTES = {}
+
+
 def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.0, D12=0.0, D22=1.0, D66=1.0, A44=1.0, A55=1.0,
-               q=0.0, wscale=1.0, want_out=True, want_sums=True):
+               q=0.0, wscale=1.0, want_out=True, want_sums=True, in_scale=None):
     """One launch of dn_fsdt_apply (include/diffnet_hip.h): the three assembled FSDT plate residuals of the fields
     (B,1,ny,nx) and / or the float64 device tensor of their three sums of squares.  `bc`: Dirichlet node mask (fp32,
-    `>= 0.5`, or bool/uint8), per sample or shared; `bc_values[k]`: float or tensor the k-th field / residual takes there."""
+    `>= 0.5`, or bool/uint8), per sample or shared; `bc_values[k]`: float or tensor the k-th field / residual takes there;
+    `in_scale`: optional float32 device tensor of 3 factors applied to the fields as they are loaded."""
     if geom.nsd != 2:
         raise DiffNetHipError("fsdt_apply: 2-D meshes only")
     flds = [_require(t, n, 4) for t, n in ((w, "w"), (phi_x, "phi_x"), (phi_y, "phi_y"))]
@@ -388,17 +392,28 @@ def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.
     args.D11, args.D12, args.D22, args.D66, args.A44, args.A55 = (float(x) for x in (D11, D12, D22, D66, A44, A55))
     args.q, args.wscale = float(q), float(wscale)
     mesh = geom.mesh_struct(B)
+    if in_scale is not None:
+        in_scale = _require(in_scale, "in_scale", 1)
+        if in_scale.numel() != 3:
+            raise ValueError("in_scale must hold 3 floats")
+        args.in_scale = in_scale.data_ptr()
+        keep.append(in_scale)
     outs = None
     if want_out:
-        outs = [torch.empty(shape, dtype=torch.float32, device=flds[0].device) for _ in range(3)]
+        o3 = torch.empty((3, *shape), dtype=torch.float32, device=flds[0].device)      # one allocation, three views
+        outs = [o3[0], o3[1], o3[2]]
         for k in range(3):
             args.out[k] = outs[k].data_ptr()
     sums = None
     if want_sums:
         sums = torch.empty(3, dtype=torch.float64, device=flds[0].device)
-        nbytes = _lib.lib().dn_fsdt_workspace_bytes(C.byref(mesh))
-        if nbytes < 0:
-            _lib.check(int(nbytes), "dn_fsdt_workspace_bytes")
+        key = (mesh.nx, mesh.ny, mesh.degree, mesh.ngp, B)
+        nbytes = _FSDT_WS_BYTES.get(key)
+        if nbytes is None:
+            nbytes = _lib.lib().dn_fsdt_workspace_bytes(C.byref(mesh))
+            if nbytes < 0:
+                _lib.check(int(nbytes), "dn_fsdt_workspace_bytes")
+            _FSDT_WS_BYTES[key] = nbytes
         ws = _workspace(flds[0].device, nbytes)
         keep.append(ws)
         args.sumsq = sums.data_ptr()

@@ -162,6 +162,8 @@ typedef struct dn_fsdt_args {
     double *sumsq;
     void *workspace;
     int64_t workspace_bytes;
+    const float *in_scale; /* optional: 3 device floats, field k is multiplied by in_scale[k] as it is loaded (before the
+                              Dirichlet substitution) -- lets the VJP of the three norms run without a scaling pass */
 } dn_fsdt_args;
 int64_t dn_fsdt_workspace_bytes(const dn_mesh *mesh);
 int dn_fsdt_apply(const dn_mesh *mesh, const dn_fsdt_args *args, void *stream);
