@@ -142,3 +142,47 @@ def test_fdm_module_surface_matches_reference(n):
     assert isinstance(m.pad, torch.nn.ReplicationPad2d) and m.nsd == 2 and m.stencil_len == 3
     with pytest.raises(AttributeError):
         m.calc_laplacian(None)
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
+    """Every entry point validates its arguments on the host and returns DN_E_* without launching anything (so this runs
+    without a GPU): null pointers, non-positive sizes, unsupported combinations, missing workspace."""
+    import ctypes as C
+    from diffnet_amd import _lib
+    L = _lib.lib()
+    null = None
+    i3 = _lib.I32x3(8, 8, 1)
+    BADARG, UNSUPPORTED, WORKSPACE = -1, -2, -3
+    assert L.dn_gauss_pt_eval_fwd(null, null, null, 1, 2, i3, 2, 1, 4, null) == BADARG
+    assert L.dn_gauss_pt_eval_bwd(null, null, null, 1, 2, i3, 2, 1, 4, null) == BADARG
+    assert L.dn_gauss_pt_eval_fwd(null, null, null, 1, 2, i3, 7, 1, 4, null) == BADARG          # nbf out of range
+    assert L.dn_assemble(null, null, 1, 2, i3, 2, 1, 0, null) == BADARG
+    assert L.dn_assemble_bwd(null, null, 1, 2, i3, 2, 1, null) == BADARG
+    assert L.dn_winding_nodes(null, null, null, null, 1, 10, 8, 8, null) == BADARG
+    assert L.dn_fdm_stencil_fwd(null, null, 1, 8, 8, null, 3, 1.0, 1.0, null) != 0
+    assert L.dn_instnorm_act_fwd(null, null, null, null, 4, 16, 1e-5, 0.2, null, 0, null) == BADARG
+    assert L.dn_instnorm_act_bwd(null, null, null, null, null, 4, 16, 0.2, null, 0, null) == BADARG
+    assert L.dn_instnorm_workspace_bytes(0, 16) == BADARG and L.dn_instnorm_workspace_bytes(4096, 64) == 0
+    assert L.dn_instnorm_workspace_bytes(4, 1 << 20) > 0                                      # few large instances: sliced path
+    assert L.dn_upconv_out_workspace_bytes(0, 64, 8, 8) == BADARG and L.dn_upconv_out_workspace_bytes(2, 64, 8, 8) > 0
+    assert L.dn_upconv_out_fwd(null, null, null, null, 2, 64, 8, 8, 1, null, 0, null) == WORKSPACE
+    assert L.dn_upconv_out_bwd(null, null, null, null, null, null, null, 2, 64, 8, 8, 1, null, 0, null) == BADARG
+    assert L.dn_upconv3d_out_workspace_bytes(1, 32, 0, 8, 8) == BADARG and L.dn_upconv3d_out_workspace_bytes(1, 32, 8, 8, 8) > 0
+    assert L.dn_upconv3d_out_fwd(null, null, null, null, 1, 32, 8, 8, 8, 1, null, 0, null) == BADARG
+    assert L.dn_upconv3d_out_bwd(null, null, null, null, null, null, null, 1, 32, 8, 8, 8, 1, null, 0, null) == BADARG
+    assert L.dn_conv3d_k4s2_wrw_workspace_bytes(1, 16, 200, 8, 8, 8) == UNSUPPORTED               # more than 128 coarse channels
+    assert L.dn_conv3d_k4s2_wrw_workspace_bytes(1, 16, 32, 2, 2, 2) == 0                         # single workgroup: no partials
+    assert L.dn_conv3d_k4s2_wrw(null, null, null, 1, 16, 32, 8, 8, 8, null, 0, null) == BADARG
+    m = _lib.DnMesh()
+    m.nsd, m.degree, m.ngp, m.batch, m.nx, m.ny, m.nz = 2, 1, 2, 1, 9, 9, 1
+    assert L.dn_poisson_workspace_bytes(C.byref(m)) > 0 and L.dn_fsdt_workspace_bytes(C.byref(m)) > 0
+    a = _lib.DnPoissonArgs()
+    assert L.dn_poisson_apply(C.byref(m), C.byref(a), null) == BADARG                          # no u
+    fa = _lib.DnFsdtArgs()
+    assert L.dn_fsdt_apply(C.byref(m), C.byref(fa), null) == BADARG
+    m.nsd = 3
+    m.nz = 9
+    assert L.dn_fsdt_workspace_bytes(C.byref(m)) == BADARG                                     # plate kernel is 2-D
+    m.degree = 2
+    a.u = 1; a.out = 1
+    assert L.dn_poisson_apply(C.byref(m), C.byref(a), null) == UNSUPPORTED                     # fused 3-D is Q1 only
