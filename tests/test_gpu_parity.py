@@ -658,3 +658,56 @@ def test_flagship_ibn3d_flow_trains_on_the_fused_kernels():
         model.dropin = True
         ref = float(model.loss(u, src, snk, f))
     np.testing.assert_allclose(fused, ref, rtol=2e-5)
+
+
+def _energy_by_operators(m, u, nu, f, masks, c):
+    """The reference formulation spelled with the drop-in HIP operators (pinned to the golden vectors above)."""
+    for mk, val in masks:
+        u = torch.where(mk > 0.5, torch.full_like(u, val), u)
+    terms = m.gauss_pt_evaluation_der_x(u) ** 2 + m.gauss_pt_evaluation_der_y(u) ** 2
+    if m.nsd == 3:
+        terms = terms + m.gauss_pt_evaluation_der_z(u) ** 2
+    w = m.gpw.to(u.device).reshape(1, -1, *([1] * m.nsd))
+    dens = w * (c * m.gauss_pt_evaluation(nu) * terms - m.gauss_pt_evaluation(u) * m.gauss_pt_evaluation(f))
+    return torch.mean(torch.sum(dens, 1))
+
+
+SWEEP_2D = [(nx, ny) for nx in (2, 4, 5, 8, 252, 255, 256, 257, 260, 511, 512, 513, 516, 1024, 1028) for ny in (2, 3, 18, 33)]
+
+
+@pytest.mark.parametrize("ngp", [2, 3])
+def test_fused_2d_kernel_at_chunk_and_strip_boundaries(ngp):
+    """Sizes around the vector width (4), the workgroup width (256 / 512 nodes), odd row counts (the two-row loop's tail)
+    and minimal meshes, uint8 and float masks: fused loss + gradient against the operator composition on the GPU."""
+    for k, (nx, ny) in enumerate(SWEEP_2D):
+        m = module(dict(domain_sizes=(nx, ny, 1), domain_lengths=(1.0, 0.5, 1.0), domain_size=nx, ngp_1d=ngp))
+        B = 1 + k % 3
+        shape = (B, 1, ny, nx)
+        u, nu, f = (seeded(shape, 300 + 3 * k + i, lo=0.5 if i == 1 else 0.0).to(dev()) for i in range(3))
+        bc = boundary_mask(shape).to(dev())
+        bc = bc.to(torch.uint8) if k % 2 else bc
+        blob = (seeded(shape, 900 + k) < 0.15).float().to(dev())
+        ur = u.clone().requires_grad_(True)
+        ref = _energy_by_operators(m, ur, nu, f, [(blob, 1.0), (bc.float(), 0.0)], 0.5)
+        (gref,) = torch.autograd.grad(ref, ur)
+        v, g = m.energy_loss_and_grad(u, nu, f, dirichlet=[(blob, 1.0), (bc, 0.0)], c=0.5)
+        np.testing.assert_allclose(float(v), float(ref), rtol=2e-5, atol=1e-7, err_msg=f"{nx}x{ny}")
+        close(g, gref.cpu().numpy(), rtol=1e-4, arel=1e-4, msg=f"{nx}x{ny}")
+
+
+@pytest.mark.parametrize("ngp", [2, 3])
+def test_fused_3d_kernel_at_tile_and_strip_boundaries(ngp):
+    for k, sizes in enumerate([(2, 2, 2), (3, 5, 4), (33, 17, 9), (64, 31, 18), (130, 9, 7), (31, 33, 40), (17, 16, 66)]):
+        nx, ny, nz = sizes
+        m = module(dict(domain_sizes=sizes, domain_lengths=(1.0, 0.7, 0.4), domain_size=nx, nsd=3, ngp_1d=ngp))
+        B = 1 + k % 2
+        shape = (B, 1, nz, ny, nx)
+        u, nu, f = (seeded(shape, 500 + 3 * k + i, lo=0.5 if i == 1 else 0.0).to(dev()) for i in range(3))
+        bc = boundary_mask(shape).to(dev())
+        bc = bc.to(torch.uint8) if k % 2 else bc
+        ur = u.clone().requires_grad_(True)
+        ref = _energy_by_operators(m, ur, nu, f, [(bc.float(), 0.0)], 1.0)
+        (gref,) = torch.autograd.grad(ref, ur)
+        v, g = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+        np.testing.assert_allclose(float(v), float(ref), rtol=2e-5, atol=1e-7, err_msg=str(sizes))
+        close(g, gref.cpu().numpy(), rtol=1e-4, arel=1e-4, msg=str(sizes))
