@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(256) upconv3d_fwd_kernel(const float* __restri
     float z8[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) z8[p] = bias;
+#pragma unroll 1                                   // unrolling over channels (2 / 4) was measured much slower (3-D: 350 -> 380 / 4940 us at 32 x 128^3)
     for (int c = 0; c < C; ++c) {
         const float* pc = ib + (size_t)c * vol;
         const float* kf = wf + c * 64;

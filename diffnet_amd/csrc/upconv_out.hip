@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(256) upconv_fwd_kernel(const float* __restrict
     const unsigned o00 = im * w + jm, o01 = im * w + j, o02 = im * w + jp, o10 = i * w + jm, o11 = i * w + j, o12 = i * w + jp,
                    o20 = ip * w + jm, o21 = ip * w + j, o22 = ip * w + jp;
     float z00 = bias, z01 = bias, z10 = bias, z11 = bias;
+#pragma unroll 1                                   // unrolling over channels (2 / 4) was measured much slower (2-D: 124 -> 481 / 610 us at B=16, 64 x 256^2)
     for (int c = 0; c < C; ++c) {
         const float* p = ib + (size_t)c * plane;
         const float* k = wf + c * 25;
