@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdiffnet_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE"}
 
