@@ -36,27 +36,23 @@ class PDE(_Base):
     batch_size, n_workers, learning_rate.  A second positional `dataset` is accepted (and stored) because
     64 legacy scripts of the reference still pass one ("ctor arity drift")."""
 
+    #: scalar keyword arguments and their defaults (DiffNet/base.py:16-22)
+    _SCALARS = (('nsd', 2), ('batch_size', 64), ('n_workers', 1), ('learning_rate', 3e-4), ('domain_length', 1.), ('domain_size', 64))
+
     def __init__(self, network, dataset=None, **kwargs):
         super().__init__()
-        self.kwargs = kwargs
-        self.network = network
+        self.kwargs, self.network = kwargs, network
         if dataset is not None:
             self.dataset = dataset
-        g = kwargs.get
-        self.nsd = g('nsd', 2)
-        self.batch_size = g('batch_size', 64)
-        self.n_workers = g('n_workers', 1)
-        self.learning_rate = g('learning_rate', 3e-4)
-        self.domain_length = g('domain_length', 1.)
-        self.domain_size = g('domain_size', 64)
-        self.domain_lengths_nd = g('domain_lengths', (self.domain_length,) * 3)
-        self.domain_sizes_nd = g('domain_sizes', (self.domain_size,) * 3)
+        for name, default in self._SCALARS:
+            setattr(self, name, kwargs.get(name, default))
+        # per-axis extents default to the isotropic value; the X / Y / Z aliases exist up to the problem's dimension
+        self.domain_lengths_nd = kwargs.get('domain_lengths', (self.domain_length,) * 3)
+        self.domain_sizes_nd = kwargs.get('domain_sizes', (self.domain_size,) * 3)
         if self.nsd >= 2:
-            self.domain_lengthX, self.domain_lengthY = self.domain_lengths_nd[0], self.domain_lengths_nd[1]
-            self.domain_sizeX, self.domain_sizeY = self.domain_sizes_nd[0], self.domain_sizes_nd[1]
-        if self.nsd >= 3:
-            self.domain_lengthZ = self.domain_lengths_nd[2]
-            self.domain_sizeZ = self.domain_sizes_nd[2]
+            for axis, letter in enumerate('XYZ'[:min(self.nsd, 3)]):
+                setattr(self, 'domain_length' + letter, self.domain_lengths_nd[axis])
+                setattr(self, 'domain_size' + letter, self.domain_sizes_nd[axis])
 
     def loss(self, u, inputs_tensor, forcing_tensor):
         raise NotImplementedError
@@ -66,11 +62,10 @@ class PDE(_Base):
         return self.network(inputs_tensor), inputs_tensor, forcing_tensor
 
     def training_step(self, batch, batch_idx):
-        u, inputs_tensor, forcing_tensor = self.forward(batch)
-        loss_val = self.loss(u, inputs_tensor, forcing_tensor).mean()
-        self.log('PDE_loss', loss_val.item())
-        self.log('loss', loss_val.item())
-        return loss_val
+        value = self.loss(*self.forward(batch)).mean()
+        for key in ('PDE_loss', 'loss'):                       # the two names the reference logs (base.py:45-46)
+            self.log(key, value.item())
+        return value
 
     def configure_optimizers(self):
         return [torch.optim.Adam(self.network.parameters(), lr=self.learning_rate)], []

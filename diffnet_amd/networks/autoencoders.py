@@ -8,16 +8,27 @@ from torch import nn
 from .fused import InstanceNormAct
 
 
+def _widths(dim, i):
+    """Channel widths around stride-2 stage i: 2 dim (i + 1) <-> 2 dim (i + 2) for i <= 3, 10 dim beyond."""
+    return (dim * 2 * (i + 1), dim * 2 * (i + 2)) if i <= 3 else (dim * 10, dim * 10)
+
+
+def _stage(conv, cout, slope):
+    # convolution -> fused InstanceNorm + activation (HIP); the Identity holds the index of the reference's activation module
+    return [conv, InstanceNormAct(cout, slope=slope), nn.Identity()]
+
+
 class Encoder(nn.Module):
     def __init__(self, in_channels=3, dim=64, n_downsample=3, encoder_type='convolutional'):
         super().__init__()
-        # the reference's first InstanceNorm is declared with `dim` features after a 2*dim-channel conv: harmless
-        # (affine=False) and kept so construction consumes the RNG identically
-        layers = [nn.ReflectionPad2d(3), nn.Conv2d(in_channels, dim * 2, 7), InstanceNormAct(dim, slope=0.2), nn.Identity()]
+        # the reference declares the first InstanceNorm with `dim` features after a 2*dim-channel conv: harmless
+        # (affine=False); the number is kept for the repr only
+        stem = [nn.ReflectionPad2d(3)] + _stage(nn.Conv2d(in_channels, dim * 2, 7), dim, 0.2)
+        downs = []
         for i in range(n_downsample):
-            cin, cout = (dim * 2 * (i + 1), dim * (i + 2) * 2) if i <= 3 else (dim * 10, dim * 10)
-            layers += [nn.Conv2d(cin, cout, 4, stride=2, padding=1), InstanceNormAct(cout, slope=0.0), nn.Identity()]
-        self.model_blocks = nn.Sequential(*layers, nn.Tanh())
+            cin, cout = _widths(dim, i)
+            downs += _stage(nn.Conv2d(cin, cout, 4, stride=2, padding=1), cout, 0.0)
+        self.model_blocks = nn.Sequential(*stem, *downs, nn.Tanh())
 
     def forward(self, x):
         return self.model_blocks(x)
@@ -26,13 +37,12 @@ class Encoder(nn.Module):
 class Decoder(nn.Module):
     def __init__(self, out_channels=3, dim=64, n_upsample=3, encoder_type='convolutional', activation='relu'):
         super().__init__()
-        layers = []
-        i = 0
+        ups, i = [], 0
         for i in reversed(range(n_upsample)):
-            cin, cout = (dim * 10, dim * 10) if i > 3 else (dim * (i + 2) * 2, dim * (i + 1) * 2)
-            layers += [nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1), InstanceNormAct(cout, slope=0.2), nn.Identity()]
-        layers += [nn.ReflectionPad2d(4), nn.Conv2d(dim * (i + 1) * 2, out_channels, 3), nn.Conv2d(out_channels, out_channels, 7)]
-        self.model_blocks = nn.Sequential(*layers)
+            cout, cin = _widths(dim, i)                   # mirrored: the decoder walks the widths backwards
+            ups += _stage(nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1), cout, 0.2)
+        head = [nn.ReflectionPad2d(4), nn.Conv2d(dim * (i + 1) * 2, out_channels, 3), nn.Conv2d(out_channels, out_channels, 7)]
+        self.model_blocks = nn.Sequential(*ups, *head)
         self.activation = nn.Sigmoid() if activation == 'sigmoid' else nn.ReLU()   # declared, not applied (as the reference)
 
     def forward(self, x):
