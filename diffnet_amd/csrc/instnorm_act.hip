@@ -180,11 +180,11 @@ __device__ __forceinline__ void bwd_apply(const float* xi, const float* gi, floa
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) in_bwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gy, float* __restrict__ gx,
-                                                        long S, float slope) {
+                                                        long S, float slope, long C, long gbs) {
     __shared__ double red[BLOCK / 64 + 1];
     __shared__ float stat[2];
     const long inst = blockIdx.x;
-    const float *xi = x + inst * S, *gi = gy + inst * S;
+    const float *xi = x + inst * S, *gi = gy + (inst / C) * gbs + (inst % C) * S;      // grad_y may be a channel slice of a wider tensor
     float* oi = gx + inst * S;
     const float m = mean[inst], r = rstd[inst];
     const Slice sl = slice_of(xi, gi, oi, S, 1);
@@ -199,10 +199,10 @@ __global__ void __launch_bounds__(BLOCK) in_bwd_kernel(const float* __restrict__
 
 __global__ void __launch_bounds__(256) in_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gy,
-                                                             double* __restrict__ part, long S, int nchunk, float slope) {
+                                                             double* __restrict__ part, long S, int nchunk, float slope, long C, long gbs) {
     __shared__ double red[5];
     const long inst = blockIdx.x;
-    const float *xi = x + inst * S, *gi = gy + inst * S;
+    const float *xi = x + inst * S, *gi = gy + (inst / C) * gbs + (inst % C) * S;
     double sg, sgx;
     bwd_sums<256>(xi, gi, slice_of(xi, gi, nullptr, S, nchunk), mean[inst], rstd[inst], slope, sg, sgx);
     sg = block_sum(sg, red, threadIdx.x, 256);
@@ -215,10 +215,10 @@ __global__ void __launch_bounds__(256) in_bwd_partial_kernel(const float* __rest
 
 __global__ void __launch_bounds__(256) in_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gy, float* __restrict__ gx,
-                                                           const double* __restrict__ part, long S, int nchunk, float slope) {
+                                                           const double* __restrict__ part, long S, int nchunk, float slope, long C, long gbs) {
     __shared__ float stat[2];
     const long inst = blockIdx.x;
-    const float *xi = x + inst * S, *gi = gy + inst * S;
+    const float *xi = x + inst * S, *gi = gy + (inst / C) * gbs + (inst % C) * S;
     float* oi = gx + inst * S;
     if (threadIdx.x == 0) {
         double sg = 0.0, sgx = 0.0;
@@ -278,23 +278,27 @@ extern "C" int dn_instnorm_act_fwd(const float* x, float* y, float* mean, float*
 }
 
 extern "C" int dn_instnorm_act_bwd(const float* x, const float* mean, const float* rstd, const float* grad_y, float* grad_x,
-                                   int64_t n_inst, int64_t spatial, float slope, void* workspace, int64_t workspace_bytes, void* stream) {
+                                   int64_t n_inst, int64_t spatial, float slope, int64_t channels, int64_t grad_y_batch_stride,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
     if (!x || !mean || !rstd || !grad_y || !grad_x) return DN_E_BADARG;
+    if (channels < 1 || n_inst % channels != 0) return DN_E_BADARG;
+    const long C = (long)channels, gbs = grad_y_batch_stride > 0 ? (long)grad_y_batch_stride : (long)(channels * spatial);
+    if (gbs < channels * spatial) return DN_E_BADARG;
     int nchunk;
     if (int rc = in_check(n_inst, spatial, workspace, workspace_bytes, nchunk)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long S = (long)spatial;
     if (nchunk == 1) {
         if (S <= 1024)
-            hipLaunchKernelGGL(dn::in_bwd_kernel<64>, dim3((unsigned)n_inst), dim3(64), 0, st, x, mean, rstd, grad_y, grad_x, S, slope);
+            hipLaunchKernelGGL(dn::in_bwd_kernel<64>, dim3((unsigned)n_inst), dim3(64), 0, st, x, mean, rstd, grad_y, grad_x, S, slope, C, gbs);
         else
-            hipLaunchKernelGGL(dn::in_bwd_kernel<256>, dim3((unsigned)n_inst), dim3(256), 0, st, x, mean, rstd, grad_y, grad_x, S, slope);
+            hipLaunchKernelGGL(dn::in_bwd_kernel<256>, dim3((unsigned)n_inst), dim3(256), 0, st, x, mean, rstd, grad_y, grad_x, S, slope, C, gbs);
     } else {
         double* part = static_cast<double*>(workspace);
         hipLaunchKernelGGL(dn::in_bwd_partial_kernel, dim3((unsigned)n_inst, nchunk), dim3(256), 0, st, x, mean, rstd, grad_y, part, S, nchunk,
-                           slope);
+                           slope, C, gbs);
         hipLaunchKernelGGL(dn::in_bwd_apply_kernel, dim3((unsigned)n_inst, nchunk), dim3(256), 0, st, x, mean, rstd, grad_y, grad_x, part, S,
-                           nchunk, slope);
+                           nchunk, slope, C, gbs);
     }
     DN_LAUNCH_CHECK();
     return 0;

@@ -36,10 +36,17 @@ class _InstNormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, mean, rstd = ctx.saved_tensors
-        gy = gy.contiguous()
+        Cn, S = x.shape[1], x[0, 0].numel()
+        # the gradient of a skip concatenation arrives as a channel slice of the wider tensor: contiguous per sample, with a
+        # larger batch stride -- read in place instead of copied
+        inner = x.stride()[1:]
+        if gy.stride()[1:] == inner and gy.stride(0) >= Cn * S:
+            gbs = gy.stride(0)
+        else:
+            gy, gbs = gy.contiguous(), 0
         gx = torch.empty_like(x)
-        ws, wsb = _workspace(x, mean.numel(), x[0, 0].numel())
-        rc = _lib.lib().dn_instnorm_act_bwd(_p(x), _p(mean), _p(rstd), _p(gy), _p(gx), mean.numel(), x[0, 0].numel(), ctx.slope,
+        ws, wsb = _workspace(x, mean.numel(), S)
+        rc = _lib.lib().dn_instnorm_act_bwd(_p(x), _p(mean), _p(rstd), _p(gy), _p(gx), mean.numel(), S, ctx.slope, Cn, gbs,
                                             _p(ws), wsb, _stream(x))
         _lib.check(rc, "dn_instnorm_act_bwd")
         return gx, None, None

@@ -207,12 +207,15 @@ int dn_conv3d_k4s2_wrw(const float *fine, const float *coarse, float *grad_weigh
  * n_inst = B*C; mean, rstd (n_inst) are written by fwd and consumed by bwd.  slope: 0 = ReLU, 0.2 = LeakyReLU(0.2),
  * 1 = no activation.  With few, large instances the work of one instance is sliced over several workgroups and the
  * fp64 partial sums go through `workspace` (dn_instnorm_workspace_bytes(n_inst, spatial) bytes, 0 when not needed;
- * no initialisation required).  Results are bitwise repeatable. */
+ * no initialisation required).  Results are bitwise repeatable.  bwd: grad_y may be a channel slice of a wider
+ * (B, C_total, spatial) tensor, e.g. the U-Net's skip concatenation: `channels` = C of this layer and
+ * grad_y_batch_stride = elements between samples (0 = contiguous). */
 int64_t dn_instnorm_workspace_bytes(int64_t n_inst, int64_t spatial);
 int dn_instnorm_act_fwd(const float *x, float *y, float *mean, float *rstd, int64_t n_inst, int64_t spatial, float eps,
                         float slope, void *workspace, int64_t workspace_bytes, void *stream);
 int dn_instnorm_act_bwd(const float *x, const float *mean, const float *rstd, const float *grad_y, float *grad_x,
-                        int64_t n_inst, int64_t spatial, float slope, void *workspace, int64_t workspace_bytes, void *stream);
+                        int64_t n_inst, int64_t spatial, float slope, int64_t channels, int64_t grad_y_batch_stride,
+                        void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -161,7 +161,7 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     assert L.dn_winding_nodes(null, null, null, null, 1, 10, 8, 8, null) == BADARG
     assert L.dn_fdm_stencil_fwd(null, null, 1, 8, 8, null, 3, 1.0, 1.0, null) != 0
     assert L.dn_instnorm_act_fwd(null, null, null, null, 4, 16, 1e-5, 0.2, null, 0, null) == BADARG
-    assert L.dn_instnorm_act_bwd(null, null, null, null, null, 4, 16, 0.2, null, 0, null) == BADARG
+    assert L.dn_instnorm_act_bwd(null, null, null, null, null, 4, 16, 0.2, 4, 0, null, 0, null) == BADARG
     assert L.dn_instnorm_workspace_bytes(0, 16) == BADARG and L.dn_instnorm_workspace_bytes(4096, 64) == 0
     assert L.dn_instnorm_workspace_bytes(4, 1 << 20) > 0                                      # few large instances: sliced path
     assert L.dn_upconv_out_workspace_bytes(0, 64, 8, 8) == BADARG and L.dn_upconv_out_workspace_bytes(2, 64, 8, 8) > 0

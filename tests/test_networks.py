@@ -214,3 +214,21 @@ def test_conv3d_k4s2_weight_gradient_matches_float64(B, cin, cout, n, transposed
     close(gw, gwd, 2e-5)
     gw2, = torch.autograd.grad(mod(xg), [mod.weight], cot.to(dev))
     assert torch.equal(gw, gw2)
+
+
+@pytest.mark.gpu
+def test_instnorm_act_backward_reads_channel_slices_in_place():
+    """The gradient reaching an up-block's InstanceNorm is a channel slice of the skip concatenation's gradient
+    (contiguous per sample, wider batch stride): same result as with a contiguous copy, for the one-pass and the
+    sliced (few large instances) kernels."""
+    from diffnet_amd.networks.fused import InstanceNormAct
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(23)
+    for shape in [(3, 5, 12, 12), (2, 4, 128, 128)]:
+        B, Cn, H, W = shape
+        x = torch.randn(shape, generator=g).to(dev).requires_grad_(True)
+        wide = torch.randn((B, Cn + 3, H, W), generator=g).to(dev)
+        y = InstanceNormAct(Cn, slope=0.0)(x)
+        g_slice, = torch.autograd.grad(y, x, wide[:, :Cn], retain_graph=True)
+        g_copy, = torch.autograd.grad(y, x, wide[:, :Cn].contiguous())
+        assert not wide[:, :Cn].is_contiguous() and torch.equal(g_slice, g_copy)
