@@ -97,6 +97,54 @@ def cpu_baseline(kw, c, budget_s=15.0):
                       f"torch {torch.__version__} CPU, {ncores} threads (os.cpu_count()={os.cpu_count()})"}
 
 
+def slab_main(args, rank, world, dev, dist):
+    """BASELINE configs[3]: one --size^3 Q1 mesh, 2x2x2 points, domain-decomposed over the ranks (strong scaling)."""
+    from diffnet_amd.slab import SlabPoisson
+    n, B = args.size, args.batch
+    sp = SlabPoisson(3, (n, n, n), (1.0, 1.0, 1.0), rank, world, ngp_1d=args.ngp, device=dev)
+    nzl = sp.dec.n1 - sp.dec.n0 + 1
+    shape = (B, 1, nzl, n, n)
+    g = torch.Generator().manual_seed(42 + rank)
+    u, nu, f = (torch.rand(shape, generator=g).to(dev) for _ in range(3))
+    nu += 0.5
+    bc = torch.zeros(shape, dtype=torch.uint8, device=dev)
+    bc[..., 0] = 1; bc[..., -1] = 1; bc[..., 0, :] = 1; bc[..., -1, :] = 1
+    if rank == 0:
+        bc[:, :, 0] = 1
+    if rank == world - 1:
+        bc[:, :, -1] = 1
+
+    def step():
+        return sp.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tmax = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    if rank == 0:
+        units = B * sp.dec.nel_global * args.ngp ** 3
+        print(json.dumps({
+            "metric": "elements*gauss_pts/sec (FEM loss+grad)", "value": units * args.steps / dt, "unit": "elements*gauss_pts/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3-D Poisson energy loss + gradient, Q1, ONE {n}^3 mesh x batch {B}, {args.ngp}^3 Gauss pts, z-slabs over "
+                                   f"{world} rank(s): 8-byte loss all-reduce + interface-layer exchange per step (BASELINE.json configs[3])",
+                       "nodes": [n, n, n], "parallelism": f"slab x{world}"}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +155,9 @@ def main():
     ap.add_argument("--ngp", type=int, default=3)
     ap.add_argument("--nsd", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--slab", action="store_true",
+                    help="strong-scaling variant (not the default metric run): ONE 3-D mesh of --size^3 nodes cut into z-slabs over "
+                         "the ranks (diffnet_amd/slab.py): per step one 8-byte all-reduce + one node-layer exchange per interior face")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,6 +178,9 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+
+    if args.slab:
+        return slab_main(args, rank, world, dev, dist)
 
     from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM
     kw = dict(domain_size=args.size, ngp_1d=args.ngp, nsd=args.nsd)
