@@ -486,16 +486,6 @@ def gen_winding(outdir):
         print("winding", tag, tuple(w.shape), float(w.abs().max()))
 
 
-if __name__ == "__main__":
-    if "--fdm" in sys.argv or "--datasets" in sys.argv:
-        pass
-    elif "--winding" in sys.argv:
-        install_shims()
-        gen_winding(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))
-    else:
-        main()
-
-
 def gen_fdm(outdir):
     import contextlib
     import io
@@ -516,11 +506,6 @@ def gen_fdm(outdir):
             out["par_" + k] = T(getattr(m, k))
         np.savez_compressed(os.path.join(outdir, f"fdm_n{n}.npz"), **out)
         print("fdm", n, float(np.abs(out["d_xx"]).max()))
-
-
-if __name__ == "__main__" and "--fdm" in sys.argv:
-    install_shims()
-    gen_fdm(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))
 
 
 def gen_datasets(outdir):
@@ -610,6 +595,14 @@ def gen_datasets(outdir):
     print("datasets", len(out), "arrays")
 
 
-if __name__ == "__main__" and "--datasets" in sys.argv:
-    install_shims()
-    gen_datasets(os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden")))
+if __name__ == "__main__":
+    # default: tables, operators, loss bodies and networks; the other fixture families are selected by flag
+    outdir = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    extra = {"--fdm": gen_fdm, "--winding": gen_winding, "--datasets": gen_datasets}
+    chosen = [fn for flag, fn in extra.items() if flag in sys.argv]
+    if chosen:
+        install_shims()
+        for fn in chosen:
+            fn(outdir)
+    else:
+        main()
