@@ -177,7 +177,7 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
         const int NW = E * P;
         if (P == 1 && E == 4 && (nx % 4 != 0 || !allow_e4)) continue;   // E = 4 exists only with aligned vector rows
         const int Q = (nx - 1) / NW + 1;                 // logical thread columns
-        for (int T = 64; T <= 256; T *= 2) {
+        for (int T = 64; T <= 256; T += 64) {            // whole waves: 64, 128, 192, 256 threads
             const int chunks = chunks_for(Q, T);
             const double util = (double)Q / ((double)chunks * T);
             // prefer wider per-thread work (fewer hand-overs, vector memory ops) at equal utilisation
