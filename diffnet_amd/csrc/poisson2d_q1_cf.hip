@@ -1,0 +1,258 @@
+// 2-D Q1 fused Poisson kernel, closed-form element (the default for nodal / absent forcing).
+//
+// With u, nu, f bilinear on the element,
+//     u(a, c) = U0 + a UX + c UY + a c UXY,   a, c in [0, 1] the lerp coordinates of the 1-D Gauss points,
+// every quadrature sum of the reference's loss bodies is a polynomial in (a_i, c_j) summed against the rule, i.e. a
+// combination of the rule's moments  M_r = sum_g w_g b_g^r  (r = 0..3; the x moments carry the Jacobian / user scale):
+//     sum_ij W_ij nu_ij (u_x)^2_j = hs0^2 (UX^2 A0 + 2 UX UXY A1 + UXY^2 A2),  A_k = P My_k + Q My_{k+1},
+//                                   P = Mx0 N0 + Mx1 NX,  Q = Mx0 NY + Mx1 NXY          (and likewise in y with B_k),
+//     sum_ij W_ij f_ij u_ij       = L0 U0 + LX UX + LY UY + LXY UXY                     (L.: moment combinations of f).
+// This is algebra, not a change of rule: the moments are computed from the rule's own points and weights (including the
+// reference's truncated 3- and 4-point literals), so the value equals the Gauss sum over any ngp x ngp points to rounding,
+// while the element costs ~75 VALU instructions whatever ngp is (115 for the per-point form at 3 x 3).
+//
+// Mapping as the other 2-D kernels: a thread owns E consecutive elements of a strip and marches over element rows; it
+// carries the lower node row (raw nodal values) and the layer-below contributions to that row's nodes; two rows per loop
+// trip with the two raw rows / carry sets swapping roles (no copies); node shared with the right neighbour through LDS.
+#include <cstdlib>
+
+#include "poisson_common.h"
+
+namespace dn {
+
+enum : int { CF_NU = 1, CF_F = 2, CF_BC = 8, CF_BC_U8C = 16 };
+
+template <int E>
+struct CfRow {
+    float u[E + 1], n[E + 1], f[E + 1];
+    float keep[E];
+    BcRaw<E> bc;
+    uint32_t m8[2][2];
+};
+
+#ifndef DN_Q1_2D_WAVES
+#define DN_Q1_2D_WAVES 2
+#endif
+#ifndef DN_PRIO_ROT
+#define DN_PRIO_ROT 3
+#endif
+
+template <int E, bool VEC, int FL>
+__global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(const PoissonParams p) {
+    constexpr int NW = E;
+    constexpr bool HAS_NU = (FL & CF_NU) != 0, HAS_F = (FL & CF_F) != 0;
+    constexpr bool BC_ANY = (FL & (CF_BC | CF_BC_U8C)) != 0, BC_U8C = (FL & CF_BC_U8C) != 0;
+    const int T = blockDim.x;
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+    const int q = chunk * (T - 1) + tid;  // logical thread column (chunks overlap by one thread)
+    const int ex0 = q * E;
+    const int x0 = ex0;
+    const bool col_owner = !(chunk > 0 && tid == 0);
+    const int64_t nps = (int64_t)p.nx * p.ny;
+    const SampleBases sb = sample_bases(p, b, nps);
+    const int R = p.rows_per_strip;
+    const int ey_own = strip * R;
+    const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;
+    const int ey_end = min(ey_own + R, p.nely);
+
+    __shared__ float xch[2][256];
+    __shared__ double red[8];
+    __shared__ int last_flag;
+
+    auto row_issue = [&](int yr, CfRow<E>& r) {
+        const unsigned rowoff = (unsigned)min(yr, p.ny - 1) * (unsigned)p.nx;
+        load_seg<NW, VEC>(sb.u, rowoff, x0, p.nx, r.u);
+        if constexpr (HAS_NU) load_seg<NW, VEC>(sb.nu, rowoff, x0, p.nx, r.n);
+        if constexpr (HAS_F) load_seg<NW, VEC>(sb.f, rowoff, x0, p.nx, r.f);
+        if constexpr (BC_U8C) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (sb.mask[k] != nullptr) {          // the second condition is optional (wave-uniform)
+                    uint8_t t[NW + 1];
+                    load_seg<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, t);
+                    uint32_t w = 0u;
+#pragma unroll
+                    for (int n = 0; n < NW; ++n) w |= (uint32_t)t[n] << (8 * n);
+                    r.m8[k][0] = w;
+                    r.m8[k][1] = t[NW];
+                }
+            }
+        } else if constexpr (BC_ANY) {
+            bc_issue<NW, VEC>(p, sb, rowoff, x0, r.bc);
+        }
+    };
+    // u <- where(mask, value, u) on a landed row, keep[] = 0 on its Dirichlet nodes
+    auto row_bc = [&](CfRow<E>& r) {
+#pragma unroll
+        for (int n = 0; n < NW; ++n) r.keep[n] = 1.f;
+        if constexpr (BC_U8C) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (sb.mask[k] != nullptr) {
+                    const float val = p.bc[k].value;
+#pragma unroll
+                    for (int n = 0; n <= NW; ++n) {
+                        const bool set = n < NW ? ((r.m8[k][0] >> (8 * n)) & 0xffu) != 0u : r.m8[k][1] != 0u;
+                        r.u[n] = set ? val : r.u[n];
+                        if (n < NW) r.keep[n] = set ? 0.f : r.keep[n];
+                    }
+                }
+            }
+        } else if constexpr (BC_ANY) {
+            bc_apply<NW>(p, sb, r.bc, r.u, r.keep);
+        }
+    };
+
+    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
+    int par = 0;
+
+    auto emit_row = [&](const float (&o)[NW + 1], const float (&keep)[NW], int yr, bool owned_row) {
+        xch[par][tid] = o[NW];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS-only barrier (loads stay in flight)
+        const float left = (tid > 0) ? xch[par][tid - 1] : 0.f;
+        par ^= 1;
+        if (owned_row && col_owner) {
+            float v[NW];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const float t = (o[n] + (n == 0 ? left : 0.f)) * keep[n];
+                sq_acc = fmaf(t, t, sq_acc);                 // nodes beyond the domain receive no contribution: t == 0
+                v[n] = t * p.out_scale;
+            }
+            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)yr * (unsigned)p.nx, x0, p.nx, v);
+        }
+    };
+
+    const float mx0 = p.T.mxs[0], mx1 = p.T.mxs[1], mx2 = p.T.mxs[2], mx3 = p.T.mxs[3];
+    const float my0 = p.T.m[0], my1 = p.T.m[1], my2 = p.T.m[2], my3 = p.T.m[3];
+    const float k0 = p.T.q1c[0], k1 = p.T.q1c[1], h0 = p.T.q1c[2], h1 = p.T.q1c[3], nb = -p.T.beta;
+
+    // one element layer between the lower row L (Dirichlet applied) and the freshly landed upper row U; cin holds the
+    // contributions of the layer below to L's nodes, cout receives this layer's contributions to U's nodes
+    auto layer = [&](int ey, const CfRow<E>& L, CfRow<E>& U, const float (&cin)[NW + 1], float (&cout)[NW + 1]) {
+        const bool own_layer = ey >= ey_own;
+        const float cnt = (own_layer && col_owner) ? 1.f : 0.f;
+        row_bc(U);
+        float o[NW + 1], le1 = 0.f, le2 = 0.f;
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) { o[n] = cin[n]; cout[n] = 0.f; }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (ex0 + e < p.nelx) {       // elements beyond the domain are skipped (and: scheduling fence between elements)
+                const float U0 = L.u[e], UX = L.u[e + 1] - L.u[e], UY = U.u[e] - L.u[e], UXY = (U.u[e + 1] - U.u[e]) - UX;
+                float P = mx0, Q = 0.f, Pp = my0, Qp = 0.f;
+                if constexpr (HAS_NU) {
+                    const float N0 = L.n[e], NX = L.n[e + 1] - N0, NY = U.n[e] - N0, NXY = (U.n[e + 1] - U.n[e]) - NX;
+                    P = fmaf(mx1, NX, mx0 * N0);
+                    Q = fmaf(mx1, NXY, mx0 * NY);
+                    Pp = fmaf(my1, NY, my0 * N0);
+                    Qp = fmaf(my1, NXY, my0 * NX);
+                }
+                const float A0 = fmaf(Q, my1, P * my0), A1 = fmaf(Q, my2, P * my1), A2 = fmaf(Q, my3, P * my2);
+                const float B0 = fmaf(Qp, mx1, Pp * mx0), B1 = fmaf(Qp, mx2, Pp * mx1), B2 = fmaf(Qp, mx3, Pp * mx2);
+                const float tX0 = fmaf(UXY, A1, UX * A0), tX1 = fmaf(UXY, A2, UX * A1);
+                const float tY0 = fmaf(UXY, B1, UY * B0), tY1 = fmaf(UXY, B2, UY * B1);
+                le1 += fmaf(h1, fmaf(UXY, tY1, UY * tY0), h0 * fmaf(UXY, tX1, UX * tX0));
+                float cU0 = 0.f, cUX = k0 * tX0, cUY = k1 * tY0, cUXY = fmaf(k0, tX1, k1 * tY1);
+                if constexpr (HAS_F) {
+                    const float F0 = L.f[e], FX = L.f[e + 1] - F0, FY = U.f[e] - F0, FXY = (U.f[e + 1] - U.f[e]) - FX;
+                    const float S0 = fmaf(mx1, FX, mx0 * F0), S1 = fmaf(mx1, FXY, mx0 * FY);
+                    const float T0 = fmaf(mx2, FX, mx1 * F0), T1 = fmaf(mx2, FXY, mx1 * FY);
+                    const float L0 = fmaf(my1, S1, my0 * S0), LX = fmaf(my1, T1, my0 * T0);
+                    const float LY = fmaf(my2, S1, my1 * S0), LXY = fmaf(my2, T1, my1 * T0);
+                    le2 += fmaf(LXY, UXY, fmaf(LY, UY, fmaf(LX, UX, L0 * U0)));
+                    cU0 = nb * L0;
+                    cUX = fmaf(nb, LX, cUX);
+                    cUY = fmaf(nb, LY, cUY);
+                    cUXY = fmaf(nb, LXY, cUXY);
+                }
+                const float g01 = cUX - cUXY, g10 = cUY - cUXY;
+                o[e] += (cU0 - cUX) - g10;
+                o[e + 1] += g01;
+                cout[e] += g10;
+                cout[e + 1] += cUXY;
+            }
+        }
+        e1_acc = fmaf(cnt, le1, e1_acc);
+        e2_acc = fmaf(cnt, le2, e2_acc);
+        emit_row(o, L.keep, ey, own_layer);
+    };
+
+    auto set_prio = [&](int e) {
+#if DN_PRIO_ROT
+        switch (((ey_end - e) >> 1) & 3) {          // progress-dependent wave priority (profiles/README.md)
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
+    };
+
+    CfRow<E> RA, RB;
+    float carryA[NW + 1], carryB[NW + 1];
+#pragma unroll
+    for (int n = 0; n <= NW; ++n) carryA[n] = carryB[n] = 0.f;
+    row_issue(ey_begin, RA);
+    row_bc(RA);
+    int ey = ey_begin;
+    for (; ey + 1 < ey_end; ey += 2) {
+        set_prio(ey);
+        row_issue(ey + 1, RB);
+        layer(ey, RA, RB, carryA, carryB);
+        row_issue(ey + 2, RA);
+        layer(ey + 1, RB, RA, carryB, carryA);
+    }
+    bool odd = false;
+    if (ey < ey_end) {
+        set_prio(ey);
+        row_issue(ey + 1, RB);
+        layer(ey, RA, RB, carryA, carryB);
+        odd = true;
+    }
+    if (ey_end == p.nely) {       // the last strip owns the top boundary row of the domain: only the layer below contributes
+        float o[NW + 1], keep[NW];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) o[n] = odd ? carryB[n] : carryA[n];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) keep[n] = odd ? RB.keep[n] : RA.keep[n];
+        emit_row(o, keep, p.ny - 1, true);
+    }
+
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);
+}
+
+template <int E, bool VEC, int FL>
+static void cf_launch_one(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
+    hipLaunchKernelGGL((poisson2d_q1_cf_kernel<E, VEC, FL>), dim3(g.chunks, g.strips, batch), dim3(g.T), 0, s, pp);
+}
+
+template <int E, bool VEC>
+static void cf_launch_flags(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
+    const bool any = pp.bc[0].mask || pp.bc[1].mask;
+    bool u8c = any;
+    for (int k = 0; k < 2; ++k)
+        if (pp.bc[k].mask && (!pp.bc[k].mask_is_u8 || pp.bc[k].field)) u8c = false;
+    const int nf = (pp.nu ? CF_NU : 0) | (pp.f ? CF_F : 0);
+#define DN_CF(FLAGS)                                                                         \
+    (!any ? cf_launch_one<E, VEC, (FLAGS)>(pp, g, batch, s)                                  \
+          : u8c ? cf_launch_one<E, VEC, (FLAGS) | CF_BC_U8C>(pp, g, batch, s)                \
+                : cf_launch_one<E, VEC, (FLAGS) | CF_BC>(pp, g, batch, s))
+    switch (nf) {
+        case 0: DN_CF(0); break;
+        case CF_NU: DN_CF(CF_NU); break;
+        case CF_F: DN_CF(CF_F); break;
+        default: DN_CF(CF_NU | CF_F); break;
+    }
+#undef DN_CF
+}
+
+int launch_poisson2d_q1_cf(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s) {
+    if (g.E == 4 && vec) { cf_launch_flags<4, true>(pp, g, batch, s); return 0; }
+    if (g.E == 2 && vec) { cf_launch_flags<2, true>(pp, g, batch, s); return 0; }
+    if (g.E == 2) { cf_launch_flags<2, false>(pp, g, batch, s); return 0; }
+    return DN_E_UNSUPPORTED;
+}
+
+}  // namespace dn

@@ -258,6 +258,8 @@ struct Geom3D { int TX, TY, E, chunks, tiles, strips, R; };
 int launch_poisson2d_q1_g2(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
 int launch_poisson2d_q1_g3(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
 int launch_poisson2d_q1_g4(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
+// closed-form 2-D Q1 kernel (poisson2d_q1_cf.hip): any rule, nodal forcing
+int launch_poisson2d_q1_cf(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
 // 3-D Q1 marching kernels likewise (poisson3d_q1_g{2,3,4}.hip)
 int launch_poisson3d_q1_g2(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);
 int launch_poisson3d_q1_g3(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);

@@ -36,7 +36,8 @@ struct ElemTab {
     float alpha, beta, c;
     // Q1 marching kernels: moments of the 1-D rule against the lerp weight b = phi_1(xi):
     //   m[r] = sum_g w[g] * b[g]^r  (r = 0,1,2);  kx[r][ig] = wx[ig] * m[r]
-    float m[3];
+    float m[4];          // m[r] = sum_g w[g] * b[g]^r, r = 0..3
+    float mxs[4];        // m[r] * wscale (the x axis carries the Jacobian / user scale): closed-form 2-D Q1 kernel
     float kx[3][4];
     float q1c[4];        // alpha*hs0^2, alpha*hs1^2, hs0^2, hs1^2  (2-D Q1 layer: derivative scales applied once per element)
 };

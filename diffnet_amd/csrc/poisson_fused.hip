@@ -310,6 +310,10 @@ static int launch2d_e(const PoissonParams& pp, const Geom2D& g, int batch, bool 
 }
 
 static int launch2d(const PoissonParams& pp, const Geom2D& g, int P, int ngp, int batch, bool vec, hipStream_t s) {
+    // Q1 with nodal (or absent) forcing: closed-form element kernel, cost independent of the number of Gauss points;
+    // forcing given at the Gauss points goes through the per-rule marching kernels
+    static const bool force_rule = getenv("DN_Q1_RULE_KERNEL") != nullptr;      // A/B switch
+    if (P == 1 && pp.fgp == nullptr && !force_rule) return launch_poisson2d_q1_cf(pp, g, batch, vec, s);
     switch (P * 10 + ngp) {
         case 12: return launch_poisson2d_q1_g2(pp, g, batch, vec, s);
         case 13: return launch_poisson2d_q1_g3(pp, g, batch, vec, s);
@@ -377,14 +381,16 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.T.q1c[0] = a->alpha * pp.T.hs[0] * pp.T.hs[0]; pp.T.q1c[1] = a->alpha * pp.T.hs[1] * pp.T.hs[1];
     pp.T.q1c[2] = pp.T.hs[0] * pp.T.hs[0];            pp.T.q1c[3] = pp.T.hs[1] * pp.T.hs[1];
     {   // moments of the 1-D rule against b = phi_1 (Q1 marching kernels), accumulated in double
-        double mm[3] = {0.0, 0.0, 0.0};
+        double mm[4] = {0.0, 0.0, 0.0, 0.0};
         for (int g = 0; g < m->ngp; ++g) {
             const double bb = m->basis[g][1];
-            mm[0] += m->gpw[g]; mm[1] += m->gpw[g] * bb; mm[2] += m->gpw[g] * bb * bb;
+            mm[0] += m->gpw[g]; mm[1] += m->gpw[g] * bb; mm[2] += m->gpw[g] * bb * bb; mm[3] += m->gpw[g] * bb * bb * bb;
         }
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < 4; ++r) {
             pp.T.m[r] = (float)mm[r];
-            for (int g = 0; g < 4; ++g) pp.T.kx[r][g] = (float)(mm[r] * (double)m->gpw[g] * (double)a->wscale);
+            pp.T.mxs[r] = (float)(mm[r] * (double)a->wscale);
+            if (r < 3)
+                for (int g = 0; g < 4; ++g) pp.T.kx[r][g] = (float)(mm[r] * (double)m->gpw[g] * (double)a->wscale);
         }
     }
     pp.T.alpha = a->alpha; pp.T.beta = a->beta; pp.T.c = a->c;
