@@ -5,7 +5,6 @@ for flags in "$@"; do
   tools/ab_build.sh "$flags" || exit 1
   echo "[$flags] 512^2 B=64 g3: $(b)"
   echo "[$flags] 512^2 B=64 g3: $(b)"
-  echo "[$flags] 512^2 B=64 g2: $(b --ngp 2)"
-  echo "[$flags] 1024^2 B=16 g2: $(b --size 1024 --batch 16 --ngp 2)"
+  echo "[$flags] 1024^2 B=16 g3: $(b --size 1024 --batch 16)"
 done
 tools/ab_build.sh "" || exit 1
