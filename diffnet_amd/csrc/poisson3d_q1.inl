@@ -92,139 +92,9 @@ __global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_
         }
     }
 
-#ifdef DN_3D_TILE
-    // In-plane node tile staged through LDS so that every node is loaded from memory once per workgroup: a thread
-    // loads only ITS row segment (E nodes, one vector load per field), applies the Dirichlet conditions, publishes it;
-    // the +1 node and the next row come from the neighbours.  The last thread column / row of the tile additionally
-    // load the column / row beyond the tile.  Row stride rs keeps 8-byte alignment of the E = 2 segments.
-    constexpr int NFLD = 1 + (HAS_NU ? 1 : 0) + (HAS_F ? 1 : 0);
-    __shared__ float ntile[NFLD][832];
-    const int rs = TX * E + 2;
-    struct OwnRow {
-        float u[NW], n[NW], f[NW], keep[NW];
-        uint32_t m[2][NW];     // raw Dirichlet masks (byte value or float bits) and value fields, applied at publish time
-        float fv[2][NW];
-    };
-    struct Plus1 { float u, n, f; uint32_t m[2]; float fv[2]; };
-    struct Pending { OwnRow own, nxt; Plus1 p0, p1; };     // loads of one node plane in flight (software prefetch)
-
-    auto row_off = [&](int z, int y) { return (unsigned)min(z, p.nz - 1) * npl + (unsigned)min(y, p.ny - 1) * (unsigned)p.nx; };
-    // issue the loads of this thread's E nodes of global row y (no use of the results: they stay in flight)
-    auto issue_row_nodes = [&](int z, int y, OwnRow& r) {
-        const unsigned rowoff = row_off(z, y);
-        load_own<NW, VEC>(sb.u, rowoff, x0, p.nx, r.u);
-        if constexpr (HAS_NU) load_own<NW, VEC>(sb.nu, rowoff, x0, p.nx, r.n);
-        if constexpr (HAS_F) load_own<NW, VEC>(sb.f, rowoff, x0, p.nx, r.f);
-        if constexpr (BC_ANY) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (sb.mask[k] != nullptr) {
-                    if (p.bc[k].mask_is_u8) {
-                        uint8_t t[NW];
-                        load_own<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, t);
-#pragma unroll
-                        for (int n = 0; n < NW; ++n) r.m[k][n] = t[n];
-                    } else {
-                        load_own<NW, VEC>(reinterpret_cast<const uint32_t*>(sb.mask[k]), rowoff, x0, p.nx, r.m[k]);
-                    }
-                    if (sb.field[k]) load_own<NW, VEC>(sb.field[k], rowoff, x0, p.nx, r.fv[k]);
-                }
-            }
-        }
-    };
-    auto issue_plus1 = [&](int z, int y, Plus1& q1) {
-        const unsigned o = row_off(z, y) + (unsigned)min(x0 + NW, p.nx - 1);
-        q1.u = sb.u[o];
-        if constexpr (HAS_NU) q1.n = sb.nu[o];
-        if constexpr (HAS_F) q1.f = sb.f[o];
-        if constexpr (BC_ANY) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (sb.mask[k] != nullptr) {
-                    q1.m[k] = p.bc[k].mask_is_u8 ? (uint32_t) reinterpret_cast<const uint8_t*>(sb.mask[k])[o]
-                                                 : reinterpret_cast<const uint32_t*>(sb.mask[k])[o];
-                    if (sb.field[k]) q1.fv[k] = sb.field[k][o];
-                }
-            }
-        }
-    };
-    auto issue_plane = [&](int z, Pending& pd) {
-        issue_row_nodes(z, ey, pd.own);
-        if (tx == TX - 1) issue_plus1(z, ey, pd.p0);
-        if (ty == TY - 1) {                      // the row beyond the tile
-            issue_row_nodes(z, ey + 1, pd.nxt);
-            if (tx == TX - 1) issue_plus1(z, ey + 1, pd.p1);
-        }
-    };
-    // u <- where(mask > 0.5, value, u) on one node; returns the keep factor
-    auto dirichlet1 = [&](float& u, const uint32_t (&m)[2], const float (&fv)[2]) {
-        float keep = 1.f;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (sb.mask[k] != nullptr) {
-                const bool set = p.bc[k].mask_is_u8 ? (m[k] != 0u) : (__uint_as_float(m[k]) > 0.5f);
-                u = set ? (sb.field[k] ? fv[k] : p.bc[k].value) : u;
-                keep = set ? 0.f : keep;
-            }
-        }
-        return keep;
-    };
-    auto apply_bc_row = [&](OwnRow& r) {
-#pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            if constexpr (BC_ANY) {
-                const uint32_t mm[2] = {r.m[0][n], r.m[1][n]};
-                const float ff[2] = {r.fv[0][n], r.fv[1][n]};
-                r.keep[n] = dirichlet1(r.u[n], mm, ff);
-            } else {
-                r.keep[n] = 1.f;
-            }
-        }
-    };
-    auto publish = [&](int lrow, int lcol, const OwnRow& r) {
-#pragma unroll
-        for (int n = 0; n < NW; ++n) {
-            ntile[0][lrow * rs + lcol + n] = r.u[n];
-            if constexpr (HAS_NU) ntile[1][lrow * rs + lcol + n] = r.n[n];
-            if constexpr (HAS_F) ntile[HAS_NU ? 2 : 1][lrow * rs + lcol + n] = r.f[n];
-        }
-    };
-    auto publish_plus1 = [&](int lrow, Plus1& q1) {
-        if constexpr (BC_ANY) (void)dirichlet1(q1.u, q1.m, q1.fv);
-        ntile[0][lrow * rs + TX * E] = q1.u;
-        if constexpr (HAS_NU) ntile[1][lrow * rs + TX * E] = q1.n;
-        if constexpr (HAS_F) ntile[HAS_NU ? 2 : 1][lrow * rs + TX * E] = q1.f;
-    };
-
-    // Dirichlet + publish the landed plane, then read rows ey, ey+1 of the tile and do the in-plane x- and y-stage
-    auto plane_stage = [&](Pending& pd, PlaneState3D<NGP, E>& S) {
-        float ru[2][NW + 1], rn[2][NW + 1], rf[2][NW + 1];
-        OwnRow& own = pd.own;
-        apply_bc_row(own);
-#pragma unroll
-        for (int n = 0; n < NW; ++n) S.keep[n] = own.keep[n];
-        publish(ty, tx * E, own);
-        if (tx == TX - 1) publish_plus1(ty, pd.p0);
-        if (ty == TY - 1) {
-            apply_bc_row(pd.nxt);
-            publish(TY, tx * E, pd.nxt);
-            if (tx == TX - 1) publish_plus1(TY, pd.p1);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-#pragma unroll
-            for (int n = 0; n <= NW; ++n) {
-                const int li = (ty + jb) * rs + tx * E + n;
-                ru[jb][n] = (jb == 0 && n < NW) ? own.u[n] : ntile[0][li];
-                if constexpr (HAS_NU) rn[jb][n] = (jb == 0 && n < NW) ? own.n[n] : ntile[1][li];
-                if constexpr (HAS_F) rf[jb][n] = (jb == 0 && n < NW) ? own.f[n] : ntile[HAS_NU ? 2 : 1][li];
-            }
-        }
-#else
-    // Direct form (default): every thread loads its two node rows itself (row ey+1 is also loaded by the next thread row;
-    // the duplicate is served by L1/L2).  Measured 8-15 % faster than the LDS-tile form above at 128^3 / 256^3
-    // (profiles/README.md): the tile adds a second barrier per plane and the kernel is not load-instruction bound.
+    // Every thread loads its two node rows itself (row ey+1 is also loaded by the next thread row; the duplicate is served
+    // by L1/L2).  Staging the in-plane node tile through LDS was measured 8-15 % slower at 128^3 / 256^3 (profiles/README.md:
+    // a second barrier per plane, and the kernel is not load-instruction bound) and is not in the tree any more.
     // Holding the next plane's loads in registers one layer ahead was measured too: 115 -> 156 VGPRs, 8-17 % slower.
     struct Pending { int z; };
     auto issue_plane = [&](int z, Pending& pd) { pd.z = z; };
@@ -275,7 +145,6 @@ __global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_
             bc_apply<NW>(p, sb, braw[0], ru[0], S.keep);
             bc_apply<NW>(p, sb, braw[1], ru[1], k1);
         }
-#endif
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const float dx0 = ru[0][e + 1] - ru[0][e], dx1 = ru[1][e + 1] - ru[1][e];
@@ -416,10 +285,7 @@ __global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_
     Pending pd;
     issue_plane(ez_begin, pd);
     plane_stage(pd, SA);
-    issue_plane(ez_begin + 1, pd);         // in flight; consumed at the top of the first iteration
-#ifdef DN_3D_TILE
-    __syncthreads();                       // every thread has read the first tile before it is overwritten
-#endif
+    issue_plane(ez_begin + 1, pd);
 #if DN_NGP == 2 && !defined(DN_NO_PINGPONG3D)
     // two layers per trip with the roles of the two plane states swapped: no state copy at the end of a layer
     // (-1..3 % at 2x2x2 points; the larger rules do not have the registers for the doubled loop body)
@@ -499,9 +365,6 @@ static void launch3_flags(const PoissonParams& pp, const Geom3D& g, int batch, h
     bool u8c = bc;
     for (int k = 0; k < 2; ++k)
         if (pp.bc[k].mask && (!pp.bc[k].mask_is_u8 || pp.bc[k].field)) u8c = false;
-#ifdef DN_3D_TILE
-    u8c = false;
-#endif
 #define DN_L3(FLAGS)                                                                   \
     (!bc ? launch3_one<NGP, E, VEC, (FLAGS)>(pp, g, batch, s)                          \
          : u8c ? launch3_one<NGP, E, VEC, (FLAGS) | FL3_BC_U8C>(pp, g, batch, s)       \
