@@ -165,7 +165,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
+    dist, backend = None, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -201,8 +201,12 @@ def main():
             # next evaluation's kernel does not queue behind the collective; waited PIPE steps later (a small-message
             # all-reduce over xGMI is latency-bound at tens of microseconds, comparable to one 75 us step) and drained
             # before the timed region closes, i.e. every step's loss IS reduced inside the timed region.
-            loss.div_(world)
-            pending.append((dist.all_reduce(loss, async_op=True), loss))
+            if backend == "nccl":                          # mean over ranks inside the collective: no extra launch per step
+                work = dist.all_reduce(loss, op=dist.ReduceOp.AVG, async_op=True)
+            else:
+                loss.div_(world)
+                work = dist.all_reduce(loss, async_op=True)
+            pending.append((work, loss))
             if len(pending) > PIPE:
                 pending.pop(0)[0].wait()
         return loss, grad
