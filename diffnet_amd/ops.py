@@ -156,6 +156,7 @@ def _norm_dirichlet(dirichlet):
 
 
 _WS = {}
+_POISSON_WS_BYTES = {}
 
 
 def _workspace(dev, nbytes):
@@ -242,9 +243,13 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
         args.out = out.data_ptr()
     if want_sums:
         sums = torch.empty(2, dtype=torch.float64, device=u.device)
-        nbytes = _lib.lib().dn_poisson_workspace_bytes(C.byref(mesh))
-        if nbytes < 0:
-            _lib.check(int(nbytes), "dn_poisson_workspace_bytes")
+        key = (mesh.nsd, mesh.degree, mesh.ngp, mesh.nx, mesh.ny, mesh.nz, B)
+        nbytes = _POISSON_WS_BYTES.get(key)
+        if nbytes is None:
+            nbytes = _lib.lib().dn_poisson_workspace_bytes(C.byref(mesh))
+            if nbytes < 0:
+                _lib.check(int(nbytes), "dn_poisson_workspace_bytes")
+            _POISSON_WS_BYTES[key] = nbytes
         ws = _workspace(u.device, nbytes)
         keep.append(ws)
         args.energy = sums.data_ptr()
