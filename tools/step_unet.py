@@ -12,10 +12,16 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--eval", action="store_true", help="eval mode (no dropout)")
+ap.add_argument("--benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen exhaustive find)")
+ap.add_argument("--channels-last", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
+if a.benchmark:
+    torch.backends.cudnn.benchmark = True
 net = UNet(2, 1).to(dev)
+if a.channels_last:
+    net = net.to(memory_format=torch.channels_last)
 if a.eval:
     net.eval()
 fem = DiffNet2DFEM(net, domain_size=a.size, ngp_1d=3).to(dev)
