@@ -150,8 +150,9 @@ constexpr int U3_CCH = 32, U3_TP = 128;
 __global__ void __launch_bounds__(256) upconv3d_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                                   const float* __restrict__ y, float* __restrict__ part, int B, int C, int d,
                                                                   int h, int w, int act, int tiles_per_wg) {
-    __shared__ __attribute__((aligned(16))) float S[U3_TP][28];      // taps 0..26 (+ 1 pad: float4 reads)
-    __shared__ float V[U3_CCH][U3_TP + 1];
+    // row strides 48 / 132 floats: the MFMA operand reads (16 lanes along a row, 4 lane groups along k) hit distinct banks
+    __shared__ float S[U3_TP][48];                                   // taps 0..26, 27..31 zero (two 16-column tiles)
+    __shared__ float V[U3_CCH][U3_TP + 4];
     __shared__ double red[8];
     const int tid = threadIdx.x;
     const int D2 = 2 * d, H2 = 2 * h, W2 = 2 * w;
@@ -159,13 +160,16 @@ __global__ void __launch_bounds__(256) upconv3d_bwd_weight_kernel(const float* _
     const long nvox = (long)B * vol;
     const int nc_pass = (C + U3_CCH - 1) / U3_CCH;
     const int pp = tid & (U3_TP - 1), half = tid >> 7;
-    const int cc = tid >> 3, t4 = (tid & 7) * 4;          // 32 channels x 8 tap quads (the 8th quad is unused: taps 28..31)
+    // accumulation on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): the 32 x 32 (channel x tap) block is four
+    // 16 x 16 tiles, one per wave: row tile rt (channels), column tile ct (taps); A[row li][k lk] = V, B[k lk][col li] = S
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4, rt = wv & 1, ct = wv >> 1;
     const size_t nwg = gridDim.x;
     float* pw = part + blockIdx.x;                        // partials are stored [output][workgroup]
     float bias_acc = 0.f;
     for (int pass = 0; pass < nc_pass; ++pass) {
         const int c0 = pass * U3_CCH;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < tiles_per_wg; ++t) {
             const long p = ((long)blockIdx.x * tiles_per_wg + t) * U3_TP + pp;
             const bool ok = p < nvox;
@@ -209,29 +213,23 @@ __global__ void __launch_bounds__(256) upconv3d_bwd_weight_kernel(const float* _
                     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) S[pp][(kz * 3 + ky) * 3 + kx] = Ys[2 - kz][2 - ky][2 - kx] + Ys[3 - kz][2 - ky][2 - kx];
-                S[pp][27] = 0.f;
+#pragma unroll
+                for (int z = 27; z < 32; ++z) S[pp][z] = 0.f;
                 if (pass == 0) bias_acc += Ys[1][1][1] + Ys[2][1][1];      // planes 2i, 2i+1 (patch 1, 2): every output voxel once
             }
             const float* ib = in + (size_t)b * C * vol + ((size_t)i * h + j) * w + k;
 #pragma unroll 8
             for (int c = half; c < U3_CCH; c += 2) V[c][pp] = (ok && c0 + c < C) ? ib[(size_t)(c0 + c) * vol] : 0.f;
             __syncthreads();
-            if (t4 < 28) {
 #pragma unroll 8
-                for (int q = 0; q < U3_TP; ++q) {
-                    const float v = V[cc][q];
-                    const float4 sv = *reinterpret_cast<const float4*>(&S[q][t4]);
-                    acc[0] = fmaf(v, sv.x, acc[0]);
-                    acc[1] = fmaf(v, sv.y, acc[1]);
-                    acc[2] = fmaf(v, sv.z, acc[2]);
-                    acc[3] = fmaf(v, sv.w, acc[3]);
-                }
-            }
+            for (int q0 = 0; q0 < U3_TP; q0 += 4)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(V[16 * rt + li][q0 + lk], S[q0 + lk][16 * ct + li], acc, 0, 0, 0);
         }
-        if (t4 < 28 && c0 + cc < C) {
+        // C/D layout of the 16 x 16 tile: column (tap) = lane & 15, row (channel) = 4 (lane >> 4) + register
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (t4 + q < 27) pw[(size_t)((c0 + cc) * 27 + t4 + q) * nwg] = acc[q];
+        for (int q = 0; q < 4; ++q) {
+            const int ch = c0 + 16 * rt + 4 * lk + q, tap = 16 * ct + li;
+            if (ch < C && tap < 27) pw[(size_t)(ch * 27 + tap) * nwg] = acc[q];
         }
     }
     const double bs = block_sum((double)bias_acc, red, tid, 256);

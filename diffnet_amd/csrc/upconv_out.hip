@@ -123,24 +123,26 @@ constexpr int UC_TP = 128;      // pixels per tile (44 KB of LDS per workgroup: 
 __global__ void __launch_bounds__(256) upconv_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                                 const float* __restrict__ y, float* __restrict__ part, int B, int C, int h,
                                                                 int w, int act, int tiles_per_wg) {
-    __shared__ __attribute__((aligned(16))) float S[UC_TP][20];      // [pixel][tap], rows padded to 80 B (float4 reads)
-    __shared__ float V[UC_CCH][UC_TP + 1];                            // [channel][pixel]
+    // row strides 16 / 132 floats: the MFMA operand reads (16 lanes along a row, 4 lane groups along k) hit distinct banks
+    __shared__ __attribute__((aligned(16))) float S[UC_TP][16];      // [pixel][tap]
+    __shared__ float V[UC_CCH][UC_TP + 4];                            // [channel][pixel]
     __shared__ double red[8];
     const int tid = threadIdx.x;
     const int H = 2 * h, W = 2 * w;
     const size_t plane = (size_t)h * w;
     const long npix = (long)B * h * w;
     const int nc_pass = (C + UC_CCH - 1) / UC_CCH;
-    // staging roles: pixel pp = tid % 128, channel parity half = tid / 128; accumulation roles: channel cc = tid / 4,
-    // taps 4 * (tid % 4) .. +3
+    // staging roles: pixel pp = tid % 128, channel parity half = tid / 128; accumulation on the matrix cores
+    // (v_mfma_f32_16x16x4_f32, exact fp32): wave wv owns channels 16 wv .. 16 wv + 15, A[row li][k lk] = V, B[k lk][col li] = S
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int pp = tid & (UC_TP - 1), half = tid >> 7;
-    const int cc = tid >> 2, t4 = (tid & 3) * 4;
+    const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     float bias_acc = 0.f;
     const size_t nwg = gridDim.x;
     float* pw = part + blockIdx.x;             // partials are stored [output][workgroup]
     for (int pass = 0; pass < nc_pass; ++pass) {
         const int c0 = pass * UC_CCH;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < tiles_per_wg; ++t) {
             const long p = ((long)blockIdx.x * tiles_per_wg + t) * UC_TP + pp;
             const bool ok = p < npix;
@@ -170,18 +172,14 @@ __global__ void __launch_bounds__(256) upconv_bwd_weight_kernel(const float* __r
             for (int c = half; c < UC_CCH; c += 2) V[c][pp] = (ok && c0 + c < C) ? ib[(size_t)(c0 + c) * plane] : 0.f;
             __syncthreads();
 #pragma unroll 8
-            for (int q = 0; q < UC_TP; ++q) {
-                const float v = V[cc][q];
-                const float4 sv = *reinterpret_cast<const float4*>(&S[q][t4]);
-                acc[0] = fmaf(v, sv.x, acc[0]);
-                acc[1] = fmaf(v, sv.y, acc[1]);
-                acc[2] = fmaf(v, sv.z, acc[2]);
-                acc[3] = fmaf(v, sv.w, acc[3]);
-            }
+            for (int q0 = 0; q0 < UC_TP; q0 += 4)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(V[16 * wv + li][q0 + lk], S[q0 + lk][li], acc, 0, 0, 0);
         }
-        if (c0 + cc < C) {
+        // C/D layout of the 16 x 16 tile: column (tap) = lane & 15, row (channel) = 4 (lane >> 4) + register
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pw[(size_t)((c0 + cc) * 16 + t4 + k) * nwg] = acc[k];
+        for (int k = 0; k < 4; ++k) {
+            const int ch = c0 + 16 * wv + 4 * lk + k;
+            if (ch < C) pw[(size_t)(ch * 16 + li) * nwg] = acc[k];
         }
     }
     const double bs = block_sum((double)bias_acc, red, tid, 256);
