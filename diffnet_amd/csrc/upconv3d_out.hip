@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(256) upconv3d_bwd_data_kernel(const float* __r
 
 // grad wrt the 27 x C weights and the bias: gW[c][tap] = sum_p in[c][p] * S[tap][p], S = 2 x 2 x 2 box sum of gz at
 // 2i+1-kz .. +1 (patch planes 2-kz, 3-kz).  Tiles of 128 voxels: 128 threads build the 27 box sums (+ the plain sum for
-// the bias) of one voxel each, all stage `in` for up to 32 channels, then thread (channel, tap quad) accumulates.
+// the bias) of one voxel each, all stage `in` for up to 32 channels, then the four waves accumulate the four 16 x 16 tiles
+// of the (32 channels x 32 padded taps) block on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
 constexpr int U3_CCH = 32, U3_TP = 128;
 __global__ void __launch_bounds__(256) upconv3d_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                                   const float* __restrict__ y, float* __restrict__ part, int B, int C, int d,

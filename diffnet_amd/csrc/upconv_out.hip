@@ -115,9 +115,10 @@ __global__ void __launch_bounds__(256) upconv_bwd_data_kernel(const float* __res
 }
 
 // grad wrt the 4 x 4 x C weights and the bias.  gW[c][ky][kx] = sum_p in[c][p] * S[ky][kx][p] with S the 2 x 2 box sum of gz at
-// rows 2i+2-ky .. +1, columns 2j+2-kx .. +1.  A workgroup walks its share of the pixels 256 at a time: every thread
-// computes the 16 box sums of its pixel into LDS and stages `in` for CCH channels, then thread (c, tap quad) accumulates
-// 4 outputs over the 256 pixels.  Per-workgroup partials are summed in index order by upconv_wsum_kernel.
+// rows 2i+2-ky .. +1, columns 2j+2-kx .. +1: a (C x pixels) x (pixels x 16) product.  A workgroup walks its share of the pixels
+// 128 at a time: 128 threads compute the 16 box sums of one pixel each into LDS, all stage `in` for 64 channels, then the four
+// waves accumulate one 16-channel x 16-tap tile each on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+// Per-workgroup partials are summed in index order by upconv_wsum_kernel.
 constexpr int UC_CCH = 64;      // channels staged per pass
 constexpr int UC_TP = 128;      // pixels per tile (44 KB of LDS per workgroup: three workgroups per CU)
 __global__ void __launch_bounds__(256) upconv_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ gout,
