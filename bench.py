@@ -267,7 +267,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.nsd}-D Poisson energy loss + gradient wrt u, Q1, {args.size}^{args.nsd} nodes, "
                                    f"{args.ngp}^{args.nsd} Gauss pts, batch {B}/GPU, nu+f nodal fields, u8 Dirichlet mask, "
-                                   "fused single pass (BASELINE.json configs[1] mesh)",
+                                   "fused single pass (BASELINE.json configs[1] mesh)"
+                                   + ("; 2-D Q1 element evaluated in closed form: the rule's sums as polynomials of its moments, same value "
+                                      "as the per-point sum (DN_Q1_RULE_KERNEL=1 runs the per-point kernel)" if args.nsd == 2 else ""),
                        "batch_per_gpu": B, "nodes": list(m.geom.node_shape), "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
