@@ -312,7 +312,7 @@ static int launch2d_e(const PoissonParams& pp, const Geom2D& g, int batch, bool 
 static int launch2d(const PoissonParams& pp, const Geom2D& g, int P, int ngp, int batch, bool vec, hipStream_t s) {
     // Q1 with nodal (or absent) forcing: closed-form element kernel, cost independent of the number of Gauss points;
     // forcing given at the Gauss points goes through the per-rule marching kernels
-    static const bool force_rule = getenv("DN_Q1_RULE_KERNEL") != nullptr;      // A/B switch
+    const bool force_rule = getenv("DN_Q1_RULE_KERNEL") != nullptr;             // A/B switch, read per call
     if (P == 1 && pp.fgp == nullptr && !force_rule) return launch_poisson2d_q1_cf(pp, g, batch, vec, s);
     switch (P * 10 + ngp) {
         case 12: return launch_poisson2d_q1_g2(pp, g, batch, vec, s);

@@ -735,3 +735,26 @@ def test_concurrent_streams_use_separate_workspaces_and_stay_bitwise_repeatable(
     torch.cuda.synchronize()
     for (la, ga), (lb, gb) in outs:
         assert torch.equal(la, la0) and torch.equal(ga, ga0) and torch.equal(lb, lb0) and torch.equal(gb, gb0)
+
+
+@pytest.mark.parametrize("ngp", [2, 3, 4])
+def test_closed_form_kernel_equals_the_per_point_kernel(ngp):
+    """The default 2-D Q1 kernel evaluates the Gauss sums as polynomials of the rule's moments; DN_Q1_RULE_KERNEL=1 selects
+    the kernel that visits every Gauss point.  Same inputs at the bench mesh: loss to 2e-6, gradient to 1e-5 of its scale
+    (fp32 re-association only), for the reference's exact 2-point and truncated 3- / 4-point rules alike."""
+    m = module(dict(domain_size=512, ngp_1d=ngp))
+    shape = (4, 1, 512, 512)
+    u, nu, f = (seeded(shape, 700 + i, lo=0.5 if i == 1 else 0.0).to(dev()) for i in range(3))
+    bc = boundary_mask(shape).to(dev()).to(torch.uint8)
+    v_cf, g_cf = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+    R_cf = m.residual(u, nu, f, dirichlet=[(bc, 0.0)], jac=0.25)
+    os.environ["DN_Q1_RULE_KERNEL"] = "1"
+    try:
+        v_pt, g_pt = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+        R_pt = m.residual(u, nu, f, dirichlet=[(bc, 0.0)], jac=0.25)
+    finally:
+        del os.environ["DN_Q1_RULE_KERNEL"]
+    np.testing.assert_allclose(float(v_cf), float(v_pt), rtol=2e-6)
+    assert float((g_cf - g_pt).abs().max()) <= 1e-5 * float(g_pt.abs().max())
+    assert float((R_cf - R_pt).abs().max()) <= 1e-5 * float(R_pt.abs().max())
+    assert not torch.equal(g_cf, g_pt)                       # two different kernels did run
