@@ -52,65 +52,57 @@ __device__ __forceinline__ void elem2d(const ElemTab& T, const float (&u)[P + 1]
     constexpr int NB = P + 1;
     float a1 = 0.f, a2 = 0.f;
     static_assert(P >= 2, "Q1 elements run through the marching kernels (q1_layer_2d / q1_layer_3d)");
-    {
-        // generic degree: table driven sum factorisation
-        float tv[NB][NGP], td[NB][NGP], tn[NB][NGP], tf[NB][NGP];
+    // Table-driven sum factorisation, one x-Gauss point at a time: x-stage of u / nu / f for that point (per node row),
+    // its NGP y-points (energy density, cotangents, y-transpose), then the x-transpose of that point straight into g.
+    // The live set is one point's stage values and cotangents instead of all points'.
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
+    for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-            for (int ig = 0; ig < NGP; ++ig) {
-                float a = 0.f, d = 0.f, n = 0.f, q = 0.f;
+        for (int ib = 0; ib < NB; ++ib) g[jb][ib] = 0.f;
 #pragma unroll
-                for (int ib = 0; ib < NB; ++ib) {
-                    a = fmaf(T.b[ig][ib], u[jb][ib], a);
-                    d = fmaf(T.dx[ig][ib], u[jb][ib], d);
-                    n = fmaf(T.b[ig][ib], nu[jb][ib], n);
-                    if constexpr (!FGP) q = fmaf(T.b[ig][ib], f[jb][ib], q);
-                }
-                tv[jb][ig] = a; td[jb][ig] = d; tn[jb][ig] = n; tf[jb][ig] = q;
+    for (int ig = 0; ig < NGP; ++ig) {
+        float tv[NB], td[NB], tn[NB], tf[NB], rv[NB], rd[NB];
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+            float a = 0.f, d = 0.f, n = 0.f, q = 0.f;
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                a = fmaf(T.b[ig][ib], u[jb][ib], a);
+                d = fmaf(T.dx[ig][ib], u[jb][ib], d);
+                n = fmaf(T.b[ig][ib], nu[jb][ib], n);
+                if constexpr (!FGP) q = fmaf(T.b[ig][ib], f[jb][ib], q);
             }
-        float rv[NB][NGP], rd[NB][NGP];
-#pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-            for (int ig = 0; ig < NGP; ++ig) rv[jb][ig] = rd[jb][ig] = 0.f;
+            tv[jb] = a; td[jb] = d; tn[jb] = n; tf[jb] = q; rv[jb] = 0.f; rd[jb] = 0.f;
+        }
 #pragma unroll
         for (int jg = 0; jg < NGP; ++jg) {
+            float val = 0.f, ux = 0.f, uy = 0.f, nuv = 0.f, fv = 0.f;
 #pragma unroll
-            for (int ig = 0; ig < NGP; ++ig) {
-                float val = 0.f, ux = 0.f, uy = 0.f, nuv = 0.f, fv = 0.f;
+            for (int jb = 0; jb < NB; ++jb) {
+                val = fmaf(T.b[jg][jb], tv[jb], val);
+                ux = fmaf(T.b[jg][jb], td[jb], ux);
+                uy = fmaf(T.dy[jg][jb], tv[jb], uy);
+                nuv = fmaf(T.b[jg][jb], tn[jb], nuv);
+                if constexpr (!FGP) fv = fmaf(T.b[jg][jb], tf[jb], fv);
+            }
+            if constexpr (FGP) fv = fg[jg * NGP + ig];
+            const float Wn = T.w2[jg][ig] * nuv, Wf = T.w2[jg][ig] * fv;
+            a1 = fmaf(Wn, ux * ux + uy * uy, a1);
+            a2 = fmaf(Wf, val, a2);
+            const float qx = T.alpha * Wn * ux, qy = T.alpha * Wn * uy, qv = -T.beta * Wf;
 #pragma unroll
-                for (int jb = 0; jb < NB; ++jb) {
-                    val = fmaf(T.b[jg][jb], tv[jb][ig], val);
-                    ux = fmaf(T.b[jg][jb], td[jb][ig], ux);
-                    uy = fmaf(T.dy[jg][jb], tv[jb][ig], uy);
-                    nuv = fmaf(T.b[jg][jb], tn[jb][ig], nuv);
-                    if constexpr (!FGP) fv = fmaf(T.b[jg][jb], tf[jb][ig], fv);
-                }
-                if constexpr (FGP) fv = fg[jg * NGP + ig];
-                const float Wn = T.w2[jg][ig] * nuv, Wf = T.w2[jg][ig] * fv;
-                a1 = fmaf(Wn, ux * ux + uy * uy, a1);
-                a2 = fmaf(Wf, val, a2);
-                const float qx = T.alpha * Wn * ux, qy = T.alpha * Wn * uy, qv = -T.beta * Wf;
-#pragma unroll
-                for (int jb = 0; jb < NB; ++jb) {
-                    rv[jb][ig] = fmaf(T.b[jg][jb], qv, rv[jb][ig]);
-                    rv[jb][ig] = fmaf(T.dy[jg][jb], qy, rv[jb][ig]);
-                    rd[jb][ig] = fmaf(T.b[jg][jb], qx, rd[jb][ig]);
-                }
+            for (int jb = 0; jb < NB; ++jb) {
+                rv[jb] = fmaf(T.b[jg][jb], qv, rv[jb]);
+                rv[jb] = fmaf(T.dy[jg][jb], qy, rv[jb]);
+                rd[jb] = fmaf(T.b[jg][jb], qx, rd[jb]);
             }
         }
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
             for (int ib = 0; ib < NB; ++ib) {
-                float a = 0.f;
-#pragma unroll
-                for (int ig = 0; ig < NGP; ++ig) {
-                    a = fmaf(T.b[ig][ib], rv[jb][ig], a);
-                    a = fmaf(T.dx[ig][ib], rd[jb][ig], a);
-                }
-                g[jb][ib] = a;
+                g[jb][ib] = fmaf(T.b[ig][ib], rv[jb], g[jb][ib]);
+                g[jb][ib] = fmaf(T.dx[ig][ib], rd[jb], g[jb][ib]);
             }
     }
     e1 = a1;
