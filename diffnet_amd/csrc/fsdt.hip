@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
     auto emit_row = [&](int r, int yr, bool owned_row) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) xch[par][k][r % P][tid] = acc[k][r][NW];
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier (loads stay in flight)
         if (owned_row && col_owner) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
     // Emit node row `yr` from acc[r] (adds the left neighbour's hand-over for n == 0).
     auto emit_row = [&](int r, int yr, bool owned_row) {
         xch[par][r % P][tid] = acc[r][NW];
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier: __syncthreads() would also drain the loads in flight
         const float left = (tid > 0) ? xch[par][r % P][tid - 1] : 0.f;
         if (owned_row && col_owner) {
             float o[NW];
