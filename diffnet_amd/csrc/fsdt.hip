@@ -85,19 +85,14 @@ __device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&
     }
 }
 
-// One element: nodal values F[k][jb][ib] of the three fields -> nodal residual contributions g[k][jb][ib].
+// One element: nodal values F[k][jb][ib] of the three fields; its nodal residual contributions are ADDED to g[k][jb][ib]
+// (the caller's partially assembled rows: no separate per-element result).
 // Sum-factorised one x-Gauss point at a time: x-stage of the three fields for that point (value / x-derivative per node
 // row), the NGP y-points with the constitutive law and the y-transpose, then the x-transpose of that point straight into
 // g -- the live set is one point's stage values and cotangents (36 registers at Q2) instead of all points' (108).
 template <int P, int NGP>
 __device__ __forceinline__ void fsdt_elem(const FsdtParams& p, const float (&F)[3][P + 1][P + 1], float (&g)[3][P + 1][P + 1]) {
     constexpr int NB = P + 1;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-            for (int ib = 0; ib < NB; ++ib) g[k][jb][ib] = 0.f;
 #pragma unroll
     for (int ig = 0; ig < NGP; ++ig) {
         float tv[3][NB], td[3][NB], rv[3][NB], rd[3][NB];
@@ -272,20 +267,8 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
         for (int r = 1; r <= P; ++r) load_row(r, ey * P + r);
         const bool own_layer = ey >= ey_own;
         if (ex0 < p.nelx) {
-            float F[3][NB][NB], g[3][NB][NB];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-                    for (int ib = 0; ib < NB; ++ib) F[k][jb][ib] = cu[k][jb][ib];
-            fsdt_elem<P, NGP>(p, F, g);
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-                    for (int ib = 0; ib < NB; ++ib) acc[k][jb][ib] += g[k][jb][ib];
+            static_assert(NW + 1 == NB, "one element per thread: the row state is the element's node block");
+            fsdt_elem<P, NGP>(p, cu, acc);
         }
 #pragma unroll
         for (int r = 0; r < P; ++r) emit_row(r, ey * P + r, own_layer);
