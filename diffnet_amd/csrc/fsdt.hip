@@ -301,15 +301,19 @@ static FsdtGeom fsdt_plan(const dn_mesh* m) {
     const int nely = (m->ny - 1) / P;
     double best = -1.0;
     g.T = 64; g.chunks = 1;
-    for (int T = 64; T <= 256; T *= 2) {
+    for (int T = 64; T <= 256; T += 64) {
         const int chunks = Q <= T ? 1 : fs_ceil_div(Q - 1, T - 1);
         const double util = (double)Q / ((double)chunks * T);
-        const double score = util + (T == 128 ? 0.005 : 0.0);
+        // at equal utilisation wider workgroups win (fewer recomputed chunk-seam columns, fewer workgroup dispatches:
+        // 1025^2 Q2 B = 8: 285 us with 192 threads x 8 rows, 324 us with 64 x 16 -- profiles/r1_configs.txt)
+        const double score = util + 0.0003 * T;
         if (score > best) { best = score; g.T = T; g.chunks = chunks; }
     }
-    const long long per_strip = (long long)g.chunks * m->batch;
+    // strip height: enough WAVES for ~4 per SIMD (the element is a long dependent chain), at the price of one recomputed
+    // layer per strip
+    const long long per_strip = (long long)g.chunks * m->batch * (g.T / 64);
     int R = 32;
-    while (R > 4 && per_strip * fs_ceil_div(nely, R) < 2048) R /= 2;
+    while (R > 4 && per_strip * fs_ceil_div(nely, R) < 4096) R /= 2;
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = fs_ceil_div(nely, g.R);
