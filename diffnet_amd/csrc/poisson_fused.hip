@@ -181,7 +181,7 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
             const int chunks = chunks_for(Q, T);
             const double util = (double)Q / ((double)chunks * T);
             // prefer wider per-thread work (fewer hand-overs, vector memory ops) at equal utilisation
-            const double score = util + 0.02 * NW + (T == 256 ? 0.005 : 0.0);
+            const double score = util + 0.02 * NW + 0.0003 * T;      // at equal utilisation: wider workgroups (fewer seam columns and dispatches)
             if (score > best) { best = score; g.T = T; g.E = E; g.chunks = chunks; }
         }
     }
