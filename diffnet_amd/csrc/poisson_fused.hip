@@ -185,10 +185,10 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
             if (score > best) { best = score; g.T = T; g.E = E; g.chunks = chunks; }
         }
     }
-    // strips: aim for >= 8 workgroups per CU in total, R in [4, 32]
-    const long long wg_per_strip = (long long)g.chunks * m->batch;
+    // strips: aim for >= 4 waves per SIMD in total (4096 waves), R in [4, 32]
+    const long long waves_per_strip = (long long)g.chunks * m->batch * (g.T / 64);
     int R = 32;
-    while (R > 4 && wg_per_strip * ceil_div(nely, R) < 2048) R /= 2;
+    while (R > 4 && waves_per_strip * ceil_div(nely, R) < 4096) R /= 2;
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = ceil_div(nely, g.R);
