@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdiffnet_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE"}
 
@@ -53,6 +53,8 @@ I32x3 = C.c_int32 * 3
 SYMBOLS = {
     "dn_abi_version": (C.c_int, []),
     "dn_build_info": (C.c_char_p, []),
+    "dn_config_set": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "dn_config_get": (C.c_char_p, [C.c_char_p]),
     "dn_poisson_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
     "dn_poisson_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnPoissonArgs), C.c_void_p]),
     "dn_gauss_pt_eval_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,
@@ -131,3 +133,17 @@ def check(rc, what):
     if rc < 0:
         raise DiffNetHipError(f"{what}: {DN_E.get(rc, rc)} (argument not supported by the HIP kernels)")
     raise DiffNetHipError(f"{what}: hipError_t {rc}")
+
+
+def config_set(key, value):
+    """Set a tuning / A-B switch of the library (include/diffnet_hip.h: dn_config_set); "" or None clears it."""
+    rc = lib().dn_config_set(key.encode(), (value or "").encode())
+    if rc != 0:
+        raise DiffNetHipError(f"dn_config_set: unknown switch {key!r} or value too long")
+
+
+def config_get(key):
+    v = lib().dn_config_get(key.encode())
+    if v is None:
+        raise DiffNetHipError(f"dn_config_get: unknown switch {key!r}")
+    return v.decode()

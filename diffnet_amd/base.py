@@ -63,8 +63,12 @@ class PDE(_Base):
 
     def training_step(self, batch, batch_idx):
         value = self.loss(*self.forward(batch)).mean()
-        for key in ('PDE_loss', 'loss'):                       # the two names the reference logs (base.py:45-46)
-            self.log(key, value.item())
+        # the two names the reference logs (base.py:45-46).  `.item()` is a host sync, illegal while the iteration is being
+        # captured into a HIP graph (Trainer(graph=True)): log the detached tensor then -- it is the graph's static output
+        # and reads the value of the latest replay
+        capturing = value.is_cuda and torch.cuda.is_current_stream_capturing()
+        for key in ('PDE_loss', 'loss'):
+            self.log(key, value.detach() if capturing else value.item())
         return value
 
     def configure_optimizers(self):

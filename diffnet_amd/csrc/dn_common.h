@@ -15,6 +15,11 @@
 
 namespace dn {
 
+// Tuning switches (dn_config_set / DN_<KEY> at load time, dn_api.hip): value of a switch, nullptr when unset.  A plain table
+// lookup -- nothing on the launch path touches the process environment.
+enum ConfigKey : int { CFG_PLAN2D = 0, CFG_PLAN3D, CFG_PLAN_FSDT, CFG_Q1_RULE_KERNEL, CFG_GPE_GATHER, CFG_COUNT };
+const char* config(ConfigKey k);
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = DN_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, DN_WAVE);

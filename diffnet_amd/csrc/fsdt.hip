@@ -317,7 +317,7 @@ static FsdtGeom fsdt_plan(const dn_mesh* m) {
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = fs_ceil_div(nely, g.R);
-    const char* e = getenv("DN_PLAN_FSDT");      // "T,R" (tuning experiments only)
+    const char* e = config(CFG_PLAN_FSDT);      // "T,R" (tuning experiments only)
     int T, RR;
     if (e && sscanf(e, "%d,%d", &T, &RR) == 2 && T >= 64 && T <= 256 && RR >= 1) {
         g.T = T; g.R = RR > nely ? nely : RR;

@@ -504,7 +504,7 @@ extern "C" int dn_gauss_pt_eval_bwd(const float* grad_out, const float* tables, 
         const int S = nbf - 1;
         const size_t tile_floats = (size_t)nbt * (nsd == 2 ? 1024 : 2048);       // contrib[NB^nsd][tile elements]
         (void)S;
-        if (nsd >= 2 && tile_floats * sizeof(float) <= 96 * 1024 && getenv("DN_GPE_GATHER") == nullptr) {
+        if (nsd >= 2 && tile_floats * sizeof(float) <= 96 * 1024 && config(CFG_GPE_GATHER) == nullptr) {
             const int tx_ = g.nel[0] <= 32 ? 1 : (g.nel[0] - 1 + 30) / 31;
             const int ty_ = nsd == 2 ? (g.nel[1] <= 32 ? 1 : (g.nel[1] - 1 + 30) / 31) : (g.nel[1] <= 8 ? 1 : (g.nel[1] - 1 + 6) / 7);
             const int tz_ = nsd == 2 ? 1 : (g.nel[2] <= 8 ? 1 : (g.nel[2] - 1 + 6) / 7);

@@ -345,16 +345,6 @@ __global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_
 template <int NGP, int E, bool VEC, int FL>
 static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
     const dim3 grid((unsigned)((long long)g.chunks * g.tiles * g.strips * batch)), block(g.TX, g.TY);
-    if constexpr (NGP == 2 && E == 2) {       // the big-workgroup builds exist where the register budget allows them
-        if (g.TX * g.TY > 512) {
-            hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL, 1024>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
-            return;
-        }
-        if (g.TX * g.TY > 256) {
-            hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL, 512>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
-            return;
-        }
-    }
     hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL, 256>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
 }
 

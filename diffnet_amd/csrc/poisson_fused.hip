@@ -229,10 +229,10 @@ static Geom3D plan3d(const dn_mesh* m) {
     return g;
 }
 
-// DN_PLAN2D="T,E,R" / DN_PLAN3D="TX,TY,E,R" override the launch geometry (tuning experiments only).
+// dn_config_set("PLAN2D", "T,E,R") / ("PLAN3D", "TX,TY,E,R") override the launch geometry (tuning experiments only).
 static Geom2D plan2d_env(const dn_mesh* m, int P, bool allow_e4 = true) {
     Geom2D g = plan2d(m, P, allow_e4);
-    const char* e = getenv("DN_PLAN2D");
+    const char* e = config(CFG_PLAN2D);
     int T, E, R;
     if (e && sscanf(e, "%d,%d,%d", &T, &E, &R) == 3 && T >= 64 && T <= 256 && (E == 1 || E == 2 || E == 4) && R >= 1 &&
         !(P == 1 && (E == 1 || (E == 4 && (m->nx % 4 != 0 || !allow_e4))))) {
@@ -246,10 +246,10 @@ static Geom2D plan2d_env(const dn_mesh* m, int P, bool allow_e4 = true) {
 
 static Geom3D plan3d_env(const dn_mesh* m) {
     Geom3D g = plan3d(m);
-    const char* e = getenv("DN_PLAN3D");
+    const char* e = config(CFG_PLAN3D);
     int TX, TY, E, R;
     if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY >= 64 && (E == 1 || (E == 2 && m->ngp == 2)) && R >= 1 &&
-        TX * TY <= ((E == 2 && m->ngp == 2) ? 1024 : 256)) {
+        TX * TY <= 256) {
         const int nelz = m->nz - 1;
         g.TX = TX; g.TY = TY; g.E = E; g.R = R > nelz ? nelz : R;
         g.chunks = chunks_for((m->nx - 1) / E + 1, TX);
@@ -312,7 +312,7 @@ static int launch2d_e(const PoissonParams& pp, const Geom2D& g, int batch, bool 
 static int launch2d(const PoissonParams& pp, const Geom2D& g, int P, int ngp, int batch, bool vec, hipStream_t s) {
     // Q1 with nodal (or absent) forcing: closed-form element kernel, cost independent of the number of Gauss points;
     // forcing given at the Gauss points goes through the per-rule marching kernels
-    const bool force_rule = getenv("DN_Q1_RULE_KERNEL") != nullptr;             // A/B switch, read per call
+    const bool force_rule = config(CFG_Q1_RULE_KERNEL) != nullptr;              // A/B switch (dn_config_set)
     if (P == 1 && pp.fgp == nullptr && !force_rule) return launch_poisson2d_q1_cf(pp, g, batch, vec, s);
     switch (P * 10 + ngp) {
         case 12: return launch_poisson2d_q1_g2(pp, g, batch, vec, s);

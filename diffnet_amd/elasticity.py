@@ -9,6 +9,7 @@ plate energy, so its VJP is the same kernel on the masked cotangents).  `fsdt_re
 computation spelled with the single-launch HIP operators (`gauss_pt_evaluation*`, `assemble`), kept as a second
 implementation for cross-checks."""
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import ops
 
@@ -29,6 +30,7 @@ class _FsdtResiduals(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g1, g2, g3):
         # J = M K M with K symmetric and M the projector onto the free nodes: J^T g = M K (M g).  Zero Dirichlet values
         # give both projections (inputs and result rows on Dirichlet nodes become 0), q = 0 drops the load term.
@@ -98,9 +100,12 @@ class _FsdtLoss(torch.autograd.Function):
         return norms
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gnorms):
         *Rs, norms = ctx.saved_tensors
-        scale = (gnorms / norms).contiguous()                                   # d||R_k||/dR_k = R_k / ||R_k||
+        # d||R_k||/dR_k = R_k / ||R_k||, with torch's norm_backward convention at ||R_k|| == 0 (zero subgradient): the
+        # reference script starts from all-zero fields, where R2 = R3 = 0 exactly (e1_plate_bending_fsdt.py:341-349)
+        scale = torch.where(norms > 0, gnorms / norms, torch.zeros_like(norms)).contiguous()
         outs, _ = ops.fsdt_apply(ctx.fem.geom, *Rs, ctx.bc, (0.0, 0.0, 0.0), q=0.0, wscale=ctx.wscale, want_sums=False, in_scale=scale,
                                  **ctx.consts)
         return outs[0], outs[1], outs[2], None, None, None, None, None, None

@@ -9,6 +9,7 @@ import ctypes as C
 
 import numpy as np
 import torch
+from torch.autograd.function import once_differentiable
 from torch import nn
 
 from . import _lib
@@ -56,6 +57,7 @@ class _Stencil(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, go):
         k9, axis, a, b, B, ny, nx = ctx.meta
         go = _require(go, "grad_output", 4)

@@ -222,16 +222,47 @@ class DiffNet2DFEM(DiffNetFEM):
     def calc_l2_err(self, u_sol):
         """L2 norms of error / solution / exact solution by Gauss quadrature (DiffNet/DiffNetFEM.py:348-379).
         Needs `self.exact_solution` and `self.u_exact` from the subclass; prints like the reference and
-        returns (eL2, uL2, u_exL2)."""
+        returns (eL2, uL2, u_exL2, vector_norm) -- the reference returns None."""
         eL2, uL2, u_exL2 = self._l2_terms(u_sol)
         u_ex = torch.as_tensor(np.asarray(self.u_exact), dtype=torch.float32).to(u_sol.device)
+        vec = torch.norm(u_ex - u_sol, 'fro') / np.sqrt(self.domain_sizeX * self.domain_sizeY)
         print("J = ", (0.5 * self.hx) * (0.5 * self.hy))
+        print("usol.shape =", u_sol.shape)
+        print("uex.shape =", u_ex.shape)
         print("||u_sol||, ||uex|| = ", uL2, u_exL2)
         print("||e||_{{L2}} = ", eL2)
-        print("||e|| (vector-norm) = ", torch.norm(u_ex - u_sol, 'fro') / np.sqrt(self.domain_sizeX * self.domain_sizeY))
-        return eL2, uL2, u_exL2
+        print("||e|| (vector-norm) = ", vec)
+        return eL2, uL2, u_exL2, vec
 
-    calc_l2_err_old = calc_l2_err
+    def calc_l2_err_old(self, u_sol):
+        """The reference's earlier host routine (DiffNet/DiffNetFEM.py:286-346): Q1, the exact 2-point rule with unit weights,
+        a unit square of `domain_size`^2 nodes, float64 numpy; `u_sol` a (N, N) numpy array, `self.u_exact` likewise.  Same
+        sums, evaluated for all elements at once instead of in a Python double loop; prints like the reference and returns
+        (eL2, uL2, u_exL2, vector_norm)."""
+        u = np.asarray(u_sol, dtype=np.float64)
+        n = self.domain_size
+        J = (0.5 / (n - 1)) ** 2
+        a = 0.577350269189626
+        x = np.linspace(0, 1, n)
+        lo, hi = x[:-1], x[1:]
+        sums = np.zeros(3)
+        for gx, gy in ((-a, -a), (a, -a), (-a, a), (a, a)):
+            N = 0.25 * np.array([(1 - gx) * (1 - gy), (1 + gx) * (1 - gy), (1 - gx) * (1 + gy), (1 + gx) * (1 + gy)])
+            u1 = N[0] * u[:-1, :-1] + N[1] * u[:-1, 1:] + N[2] * u[1:, :-1] + N[3] * u[1:, 1:]
+            xp = ((lo + hi) / 2. + (hi - lo) / 2. * gx)[None, :]
+            yp = ((lo + hi) / 2. + (hi - lo) / 2. * gy)[:, None]
+            u2 = np.asarray(self.exact_solution(xp, yp), dtype=np.float64)
+            sums += [np.sum((u1 - u2) ** 2) * J, np.sum(u1 ** 2) * J, np.sum(np.broadcast_to(u2, u1.shape) ** 2) * J]
+        eL2, uL2, u_exL2 = np.sqrt(sums)
+        u_ex = np.asarray(self.u_exact, dtype=np.float64)
+        vec = np.linalg.norm(u_ex - u, 'fro') / n
+        print("J = ", J)
+        print("usol.shape =", u.shape)
+        print("uex.shape =", u_ex.shape)
+        print("||u_sol||, ||uex|| = ", uL2, u_exL2)
+        print("||e||_{{L2}} = ", eL2)
+        print("||e|| (vector-norm) = ", vec)
+        return eL2, uL2, u_exL2, vec
 
 
 class DiffNet3DFEM(DiffNetFEM):
@@ -256,14 +287,48 @@ class DiffNet3DFEM(DiffNetFEM):
         return [torch.sqrt(torch.sum(v ** 2 * jxw)) for v in (u_gp - u_ex_gp, u_gp, u_ex_gp)]
 
     def calc_l2_err(self, u_sol):
-        """DiffNet/DiffNetFEM.py:560-591; returns (eL2, uL2, u_exL2)."""
+        """DiffNet/DiffNetFEM.py:560-591; returns (eL2, uL2, u_exL2, vector_norm) -- the reference returns None."""
         eL2, uL2, u_exL2 = self._l2_terms(u_sol)
         u_ex = torch.as_tensor(np.asarray(self.u_exact), dtype=torch.float32).to(u_sol.device)
+        vec = torch.norm(u_ex - u_sol, 'fro') / np.sqrt(self.domain_sizeX * self.domain_sizeY * self.domain_sizeZ)
         print("J = ", (0.5 * self.hx) * (0.5 * self.hy) * (0.5 * self.hz))
+        print("usol.shape =", u_sol.shape)
+        print("uex.shape =", u_ex.shape)
         print("||u_sol||, ||uex|| = ", uL2, u_exL2)
         print("||e||_{{L2}} = ", eL2)
-        print("||e|| (vector-norm) = ",
-              torch.norm(u_ex - u_sol, 'fro') / np.sqrt(self.domain_sizeX * self.domain_sizeY * self.domain_sizeZ))
-        return eL2, uL2, u_exL2
+        print("||e|| (vector-norm) = ", vec)
+        return eL2, uL2, u_exL2, vec
 
-    calc_l2_err_old = calc_l2_err
+    def calc_l2_err_old(self, u_sol):
+        """DiffNet/DiffNetFEM.py:482-558: the host routine in 3-D (Q1, the module's own 2-point rule with unit weights, unit
+        cube, float64 numpy); `u_sol` a (N, N, N) numpy array [k, j, i], `self.u_exact` a tensor or array."""
+        u = np.asarray(u_sol, dtype=np.float64)
+        n = self.domain_size
+        J = (0.5 / (n - 1)) ** 3
+        g1 = np.asarray(self.gpx_1d, dtype=np.float64)
+        x = np.linspace(0, 1, n)
+        lo, hi = x[:-1], x[1:]
+        mid, half = (lo + hi) / 2., (hi - lo) / 2.
+        sums = np.zeros(3)
+        for gz in g1[:2]:
+            for gy in g1[:2]:
+                for gx in g1[:2]:
+                    u1 = 0.0
+                    for kk, sz in ((0, 1 - gz), (1, 1 + gz)):
+                        for jj, sy in ((0, 1 - gy), (1, 1 + gy)):
+                            for ii, sx in ((0, 1 - gx), (1, 1 + gx)):
+                                u1 = u1 + 0.125 * sx * sy * sz * u[kk:n - 1 + kk, jj:n - 1 + jj, ii:n - 1 + ii]
+                    xp, yp, zp = (mid + half * gx)[None, None, :], (mid + half * gy)[None, :, None], (mid + half * gz)[:, None, None]
+                    u2 = np.asarray(self.exact_solution(xp, yp, zp), dtype=np.float64)
+                    sums += [np.sum((u1 - u2) ** 2) * J, np.sum(u1 ** 2) * J, np.sum(np.broadcast_to(u2, u1.shape) ** 2) * J]
+        eL2, uL2, u_exL2 = np.sqrt(sums)
+        ue = self.u_exact
+        u_ex = (ue.squeeze().detach().cpu().numpy() if isinstance(ue, torch.Tensor) else np.asarray(ue)).astype(np.float64)
+        vec = np.linalg.norm(u_ex.reshape(-1, 1) - u.reshape(-1, 1), 'fro') / (1. * n) ** 1.5
+        print("J = ", J)
+        print("usol.shape =", u.shape)
+        print("uex.shape =", u_ex.shape)
+        print("||u_sol||, ||uex|| = ", uL2, u_exL2)
+        print("||e||_{{L2}} = ", eL2)
+        print("||e|| (vector-norm) = ", vec)
+        return eL2, uL2, u_exL2, vec

@@ -2,6 +2,7 @@
 (one pass pair instead of torch's normalisation + activation kernels); on CPU tensors it evaluates the same formula
 with torch ops (the networks are plumbing around the convolutions, which stay MIOpen / oneDNN in this round)."""
 import torch
+from torch.autograd.function import once_differentiable
 from torch import nn
 import torch.nn.functional as F
 
@@ -34,6 +35,7 @@ class _InstNormAct(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         x, mean, rstd = ctx.saved_tensors
         Cn, S = x.shape[1], x[0, 0].numel()
@@ -91,6 +93,7 @@ class _UpConvOut(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
         x, weight, out = ctx.saved_tensors
         gout = gout.contiguous()
@@ -100,6 +103,8 @@ class _UpConvOut(torch.autograd.Function):
         gw = torch.empty_like(weight) if need_w else None
         gb = torch.empty(1, dtype=torch.float32, device=x.device) if (need_w and ctx.has_bias) else None
         nbytes = _lib.lib().dn_upconv_out_workspace_bytes(B, Cn, h, w)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "dn_upconv_out_workspace_bytes")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         rc = _lib.lib().dn_upconv_out_bwd(_p(x), _p(weight), _p(out), _p(gout), _p(gx), _p(gw), _p(gb), B, Cn, h, w, ctx.act, _p(ws), nbytes,
                                           _stream(x))
@@ -135,6 +140,7 @@ class _UpConv3dOut(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
         x, weight, out = ctx.saved_tensors
         gout = gout.contiguous()
@@ -144,6 +150,8 @@ class _UpConv3dOut(torch.autograd.Function):
         gw = torch.empty_like(weight) if need_w else None
         gb = torch.empty(1, dtype=torch.float32, device=x.device) if (need_w and ctx.has_bias) else None
         nbytes = _lib.lib().dn_upconv3d_out_workspace_bytes(B, Cn, d, h, w)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "dn_upconv3d_out_workspace_bytes")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         rc = _lib.lib().dn_upconv3d_out_bwd(_p(x), _p(weight), _p(out), _p(gout), _p(gx), _p(gw), _p(gb), B, Cn, d, h, w, ctx.act, _p(ws),
                                             nbytes, _stream(x))
@@ -187,6 +195,7 @@ class _Conv3dK4S2(torch.autograd.Function):
         return F.conv3d(x, weight, None, 2, 1)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
@@ -207,6 +216,7 @@ class _ConvT3dK4S2(torch.autograd.Function):
         return F.conv_transpose3d(x, weight, None, 2, 1)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()

@@ -8,6 +8,7 @@ import ctypes as C
 import math
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import DnDirichlet, DnFsdtArgs, DnMesh, DnPoissonArgs, I32x3, DiffNetHipError
@@ -42,20 +43,36 @@ def _sizes_xyz(t, nsd):
     return I32x3(*s)
 
 
+def _gpe_fwd(x, tables, nsd, nbf, stride):
+    x = _require(x, "tensor", nsd + 2)
+    if x.shape[1] != 1:
+        raise ValueError(f"gauss_pt_eval expects a single-channel field (B,1,...), got {tuple(x.shape)}")
+    G = tables.shape[0]
+    out_sp = [(n - nbf) // stride + 1 for n in x.shape[2:]]
+    if min(out_sp) < 1:
+        raise ValueError(f"field {tuple(x.shape)} smaller than the {nbf}-node element")
+    out = torch.empty((x.shape[0], G, *out_sp), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().dn_gauss_pt_eval_fwd(_p(x), _p(tables), _p(out), x.shape[0], nsd, _sizes_xyz(x, nsd), nbf, stride, G, _stream(x))
+    _lib.check(rc, "dn_gauss_pt_eval_fwd")
+    return out
+
+
+def _gpe_bwd(gout, tables, shape, nsd, nbf, stride):
+    gout = _require(gout, "grad_output")
+    gin = torch.empty(shape, dtype=torch.float32, device=gout.device)
+    sizes = I32x3(*(list(shape[2:])[::-1] + [1] * (3 - nsd)))
+    rc = _lib.lib().dn_gauss_pt_eval_bwd(_p(gout), _p(tables), _p(gin), shape[0], nsd, sizes, nbf, stride, tables.shape[0], _stream(gout))
+    _lib.check(rc, "dn_gauss_pt_eval_bwd")
+    return gin
+
+
 class _GaussPtEval(torch.autograd.Function):
+    """Linear in the field: the backward pass is the adjoint kernel wrapped in its own Function (`_GaussPtEvalT`), whose
+    backward is this one again, so the operator differentiates to any order like the reference's conv formulation."""
+
     @staticmethod
     def forward(ctx, x, tables, nsd, nbf, stride):
-        x = _require(x, "tensor", nsd + 2)
-        if x.shape[1] != 1:
-            raise ValueError(f"gauss_pt_eval expects a single-channel field (B,1,...), got {tuple(x.shape)}")
-        G = tables.shape[0]
-        out_sp = [(n - nbf) // stride + 1 for n in x.shape[2:]]
-        if min(out_sp) < 1:
-            raise ValueError(f"field {tuple(x.shape)} smaller than the {nbf}-node element")
-        out = torch.empty((x.shape[0], G, *out_sp), dtype=torch.float32, device=x.device)
-        rc = _lib.lib().dn_gauss_pt_eval_fwd(_p(x), _p(tables), _p(out), x.shape[0], nsd, _sizes_xyz(x, nsd), nbf, stride, G,
-                                             _stream(x))
-        _lib.check(rc, "dn_gauss_pt_eval_fwd")
+        out = _gpe_fwd(x, tables, nsd, nbf, stride)
         ctx.save_for_backward(tables)
         ctx.meta = (tuple(x.shape), nsd, nbf, stride)
         return out
@@ -64,13 +81,23 @@ class _GaussPtEval(torch.autograd.Function):
     def backward(ctx, gout):
         (tables,) = ctx.saved_tensors
         shape, nsd, nbf, stride = ctx.meta
-        gout = _require(gout, "grad_output")
-        gin = torch.empty(shape, dtype=torch.float32, device=gout.device)
-        sizes = I32x3(*(list(shape[2:])[::-1] + [1] * (3 - nsd)))
-        rc = _lib.lib().dn_gauss_pt_eval_bwd(_p(gout), _p(tables), _p(gin), shape[0], nsd, sizes, nbf, stride, tables.shape[0],
-                                             _stream(gout))
-        _lib.check(rc, "dn_gauss_pt_eval_bwd")
-        return gin, None, None, None, None
+        return _GaussPtEvalT.apply(gout, tables, shape, nsd, nbf, stride), None, None, None, None
+
+
+class _GaussPtEvalT(torch.autograd.Function):
+    """Adjoint of `_GaussPtEval` (element/Gauss-point cotangents -> nodal field)."""
+
+    @staticmethod
+    def forward(ctx, gout, tables, shape, nsd, nbf, stride):
+        ctx.save_for_backward(tables)
+        ctx.meta = (nsd, nbf, stride)
+        return _gpe_bwd(gout, tables, shape, nsd, nbf, stride)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (tables,) = ctx.saved_tensors
+        nsd, nbf, stride = ctx.meta
+        return _GaussPtEval.apply(gg, tables, nsd, nbf, stride), None, None, None, None, None
 
 
 def stack_tables(N, nsd):
@@ -96,6 +123,9 @@ def gauss_pt_eval(tensor, N, nsd=2, stride=1):
 
 
 class _Assemble(torch.autograd.Function):
+    """Element->node scatter-add (gather form).  Linear: its backward (`_AssembleT`, the per-element gather) is a Function
+    whose backward is the assembly again."""
+
     @staticmethod
     def forward(ctx, r_split, nsd, nbf, base):
         r_split = _require(r_split, "R_split", nsd + 2)
@@ -118,11 +148,25 @@ class _Assemble(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         shape, nsd, nbf, has_base = ctx.meta
+        return _AssembleT.apply(gout, shape, nsd, nbf), None, None, (gout if has_base else None)
+
+
+class _AssembleT(torch.autograd.Function):
+    """Adjoint of `_Assemble`: gathers the nodal cotangent to the local nodes of every element."""
+
+    @staticmethod
+    def forward(ctx, gout, shape, nsd, nbf):
         gout = _require(gout, "grad_output")
         gs = torch.empty(shape, dtype=torch.float32, device=gout.device)
         rc = _lib.lib().dn_assemble_bwd(_p(gout), _p(gs), shape[0], nsd, _sizes_xyz(gout, nsd), nbf, nbf - 1, _stream(gout))
         _lib.check(rc, "dn_assemble_bwd")
-        return gs, None, None, (gout if has_base else None)
+        ctx.meta = (nsd, nbf)
+        return gs
+
+    @staticmethod
+    def backward(ctx, gg):
+        nsd, nbf = ctx.meta
+        return _Assemble.apply(gg, nsd, nbf, None), None, None, None
 
 
 def assemble(r_split, nsd, nbf=2, out=None):
@@ -268,6 +312,88 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
     return out, sums
 
 
+# ---- composed (operator-level) forms: differentiable wrt EVERY tensor input ------------------------------------
+# The fused kernels return the gradient wrt u only.  When a coefficient (nu, f, f_gp) or a Dirichlet value field requires a
+# gradient -- inverse / parametric-coefficient problems, which the reference differentiates through plain autograd
+# (IBN_2D.py:116-134) -- the same loss is evaluated on the single-launch HIP operators (`_GaussPtEval` and its adjoint) plus
+# torch elementwise ops, so autograd covers all of them.  Slower (Gauss-point tensors are materialised), never silently wrong.
+def _wants_grad(*ts):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
+def _extra_grad_inputs(nu, f, f_gp, dirichlet):
+    return _wants_grad(nu, f, f_gp, *[d.value for d in dirichlet])
+
+
+def _dirichlet_cond(m):
+    return (m > 0.5) if m.is_floating_point() else (m != 0)
+
+
+def _apply_dirichlet(u, dirichlet):
+    for d in dirichlet:
+        v = d.value
+        if isinstance(v, torch.Tensor):
+            v = v[(None,) * (u.dim() - v.dim())] if v.dim() < u.dim() else v
+            v = v.to(u.device).expand_as(u)
+        else:
+            v = torch.full_like(u, float(v))
+        u = torch.where(_dirichlet_cond(d.mask), v, u)
+    return u
+
+
+def _geom_tables(geom, device):
+    """Stacked (G, nbf^nsd) N / dN_d tables and the nd weights of a FemGeometry on `device` (cached)."""
+    cache = geom.__dict__.setdefault("_dev_tables", {})
+    hit = cache.get(str(device))
+    if hit is None:
+        from .tables import nd_tables
+        K, _, w = nd_tables(geom.nsd, geom.deg, geom.gpx_1d, geom.gpw_1d, geom.hs)
+        names = ["N_gp"] + ["dN_%s_gp" % a for a in "xyz"[:geom.nsd]]
+        hit = ({n: torch.from_numpy(K[n].reshape(K[n].shape[0], -1).copy()).to(device) for n in names}, torch.from_numpy(w).to(device))
+        cache[str(device)] = hit
+    return hit
+
+
+def composed_energy(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0):
+    """Energy loss on the drop-in operators (the reference formulation, e.g. IBN_2D.py:116-134): differentiable wrt u, nu, f,
+    f_gp and Dirichlet value fields."""
+    T, w = _geom_tables(geom, u.device)
+    nsd, nbf = geom.nsd, geom.deg + 1
+    ev = lambda t, name: _GaussPtEval.apply(t, T[name], nsd, nbf, nbf - 1)
+    ub = _apply_dirichlet(u, _norm_dirichlet(dirichlet))
+    g2 = sum(ev(ub, "dN_%s_gp" % a) ** 2 for a in "xyz"[:nsd])
+    wg = (w * jac).reshape((1, -1) + (1,) * nsd)
+    dens = c * g2 if nu is None else c * ev(nu, "N_gp") * g2
+    if f is not None or f_gp is not None:
+        dens = dens - ev(ub, "N_gp") * (f_gp if f_gp is not None else ev(f, "N_gp"))
+    return torch.sum(wg * dens) / (u.shape[0] * geom.nelem_total)
+
+
+def composed_residual(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
+    """Assembled weak-form residual (zero on Dirichlet nodes) from the operator adjoints: R = sum_d gpe^T(W nu d_d u ; dN_d)
+    - gpe^T(W f ; N).  Differentiable wrt every tensor input."""
+    T, w = _geom_tables(geom, u.device)
+    nsd, nbf = geom.nsd, geom.deg + 1
+    dirichlet = _norm_dirichlet(dirichlet)
+    ev = lambda t, name: _GaussPtEval.apply(t, T[name], nsd, nbf, nbf - 1)
+    evT = lambda t, name: _GaussPtEvalT.apply(t.contiguous(), T[name], tuple(u.shape), nsd, nbf, nbf - 1)
+    ub = _apply_dirichlet(u, dirichlet)
+    wg = (w * jac).reshape((1, -1) + (1,) * nsd)
+    nug = None if nu is None else ev(nu, "N_gp")
+    R = None
+    for a in "xyz"[:nsd]:
+        q = wg * ev(ub, "dN_%s_gp" % a)
+        q = q if nug is None else q * nug
+        t = evT(q.expand(u.shape[0], *q.shape[1:]), "dN_%s_gp" % a)
+        R = t if R is None else R + t
+    if f is not None or f_gp is not None:
+        fg = f_gp if f_gp is not None else ev(f, "N_gp")
+        R = R - evT((wg * fg).expand(u.shape[0], -1, *fg.shape[2:]), "N_gp")
+    for d in dirichlet:
+        R = torch.where(_dirichlet_cond(d.mask), torch.zeros_like(R), R)
+    return R
+
+
 class _EnergyLoss(torch.autograd.Function):
     """Fused energy loss: forward and the gradient wrt u come out of the same single pass."""
 
@@ -281,14 +407,19 @@ class _EnergyLoss(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
         (grad,) = ctx.saved_tensors
         return grad * gout, None, None, None, None, None, None, None
 
 
 def energy_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0):
-    """mean_{b,e} sum_g gpw_g*jac*(c*nu_g*|grad u|_g^2 - u_g*f_g), differentiable wrt u (see _EnergyLoss)."""
-    return _EnergyLoss.apply(u, geom, nu, f, f_gp, tuple(_norm_dirichlet(dirichlet)), float(c), float(jac))
+    """mean_{b,e} sum_g gpw_g*jac*(c*nu_g*|grad u|_g^2 - u_g*f_g).  One fused launch, differentiable wrt u; when nu / f /
+    f_gp / a Dirichlet value field requires a gradient the composed operator form runs instead (see composed_energy)."""
+    dirichlet = tuple(_norm_dirichlet(dirichlet))
+    if _extra_grad_inputs(nu, f, f_gp, dirichlet):
+        return composed_energy(geom, u, nu, f, f_gp, dirichlet, float(c), float(jac))
+    return _EnergyLoss.apply(u, geom, nu, f, f_gp, dirichlet, float(c), float(jac))
 
 
 def energy_loss_and_grad(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0):
@@ -301,6 +432,14 @@ def energy_loss_and_grad(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.
     return loss, grad
 
 
+def _homogeneous(dirichlet):
+    return tuple(Dirichlet(d.mask, 0.0) for d in dirichlet)
+
+
+def _saved_masks(dirichlet):
+    return [d.mask for d in dirichlet]
+
+
 class _Residual(torch.autograd.Function):
     """Assembled weak-form residual R (zero on Dirichlet nodes).  The operator is symmetric in u, so the
     backward pass is the same kernel applied to the incoming cotangent with f dropped."""
@@ -309,19 +448,26 @@ class _Residual(torch.autograd.Function):
     def forward(ctx, u, geom, nu, f, f_gp, dirichlet, jac):
         R, _ = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=1.0, beta=1.0, c=0.0, wscale=jac, out_scale=1.0,
                              want_out=True, want_sums=False)
-        ctx.geom, ctx.nu, ctx.dirichlet, ctx.jac = geom, nu, dirichlet, jac
+        ctx.geom, ctx.jac, ctx.has_nu = geom, jac, nu is not None
+        ctx.save_for_backward(*([nu] if nu is not None else []), *_saved_masks(dirichlet))   # in-place edits are detected
         return R
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gR):
-        homog = tuple(Dirichlet(d.mask, 0.0) for d in ctx.dirichlet)
-        g, _ = poisson_apply(ctx.geom, gR.contiguous(), ctx.nu, None, None, homog, alpha=1.0, beta=0.0, c=0.0,
+        saved = list(ctx.saved_tensors)
+        nu = saved.pop(0) if ctx.has_nu else None
+        homog = tuple(Dirichlet(m, 0.0) for m in saved)
+        g, _ = poisson_apply(ctx.geom, gR.contiguous(), nu, None, None, homog, alpha=1.0, beta=0.0, c=0.0,
                              wscale=ctx.jac, out_scale=1.0, want_out=True, want_sums=False)
         return g, None, None, None, None, None, None
 
 
 def residual(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
-    return _Residual.apply(u, geom, nu, f, f_gp, tuple(_norm_dirichlet(dirichlet)), float(jac))
+    dirichlet = tuple(_norm_dirichlet(dirichlet))
+    if _extra_grad_inputs(nu, f, f_gp, dirichlet):
+        return composed_residual(geom, u, nu, f, f_gp, dirichlet, float(jac))
+    return _Residual.apply(u, geom, nu, f, f_gp, dirichlet, float(jac))
 
 
 class _ResidualLoss(torch.autograd.Function):
@@ -331,21 +477,27 @@ class _ResidualLoss(torch.autograd.Function):
     def forward(ctx, u, geom, nu, f, f_gp, dirichlet, jac):
         R, sums = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=1.0, beta=1.0, c=0.0, wscale=jac, out_scale=1.0,
                                 want_out=True, want_sums=True)
-        ctx.save_for_backward(R)
-        ctx.geom, ctx.nu, ctx.dirichlet, ctx.jac = geom, nu, dirichlet, jac
+        ctx.geom, ctx.jac, ctx.has_nu = geom, jac, nu is not None
+        ctx.save_for_backward(R, *([nu] if nu is not None else []), *_saved_masks(dirichlet))
         return sums[1].to(torch.float32)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gout):
-        (R,) = ctx.saved_tensors
-        homog = tuple(Dirichlet(d.mask, 0.0) for d in ctx.dirichlet)
-        g, _ = poisson_apply(ctx.geom, R, ctx.nu, None, None, homog, alpha=1.0, beta=0.0, c=0.0, wscale=ctx.jac,
+        saved = list(ctx.saved_tensors)
+        R = saved.pop(0)
+        nu = saved.pop(0) if ctx.has_nu else None
+        homog = tuple(Dirichlet(m, 0.0) for m in saved)
+        g, _ = poisson_apply(ctx.geom, R, nu, None, None, homog, alpha=1.0, beta=0.0, c=0.0, wscale=ctx.jac,
                              out_scale=2.0, want_out=True, want_sums=False)
         return g * gout, None, None, None, None, None, None
 
 
 def residual_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
-    return _ResidualLoss.apply(u, geom, nu, f, f_gp, tuple(_norm_dirichlet(dirichlet)), float(jac))
+    dirichlet = tuple(_norm_dirichlet(dirichlet))
+    if _extra_grad_inputs(nu, f, f_gp, dirichlet):
+        return torch.sum(composed_residual(geom, u, nu, f, f_gp, dirichlet, float(jac)) ** 2)
+    return _ResidualLoss.apply(u, geom, nu, f, f_gp, dirichlet, float(jac))
 
 
 _FSDT_WS_BYTES = {}

@@ -7,7 +7,22 @@ nothing else; checkpointing, loggers and DDP remain Lightning's job when it is a
 the whole iteration -- forward, fused loss kernel, backward, optimizer update -- is captured once into a HIP graph and
 replayed, so a step costs one graph launch instead of ~50 kernel launches from Python (the small meshes of
 BASELINE configs[0] are launch-bound: tools/bench_graph.py)."""
+import inspect
+
 import torch
+
+
+def _takes_optimizer_idx(module):
+    """Lightning 1.x passes `optimizer_idx` to `training_step` when several optimizers are configured and the method accepts
+    it (e1_plate_bending_fsdt.py: `training_step(self, batch, batch_idx, optimizer_idx)`)."""
+    try:
+        params = inspect.signature(module.training_step).parameters
+    except (TypeError, ValueError):
+        return False
+    if "optimizer_idx" in params:
+        return True
+    positional = [p for p in params.values() if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+    return len(positional) >= 3
 
 
 def _to(batch, device):
@@ -47,11 +62,13 @@ class Trainer:
                 if "capturable" in grp:
                     grp["capturable"] = True       # optimizer state (step counters) lives on the device
 
+        with_idx = len(opts) > 1 and _takes_optimizer_idx(module)
+
         def iteration():
             loss = None
-            for o in opts:
+            for k, o in enumerate(opts):
                 o.zero_grad(set_to_none=False)
-                loss = self._loss_of(module.training_step(batch, 0))
+                loss = self._loss_of(module.training_step(batch, 0, k) if with_idx else module.training_step(batch, 0))
                 loss.backward()
                 o.step()
             return loss
@@ -68,8 +85,13 @@ class Trainer:
         if self.global_step >= total:
             return self
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            static_loss = iteration()
+        try:
+            with torch.cuda.graph(g):
+                static_loss = iteration()
+        except RuntimeError as e:
+            raise RuntimeError("Trainer(graph=True): the training iteration could not be captured into a HIP graph -- most often a host "
+                               "synchronisation inside training_step (`.item()`, `.cpu()`, printing a tensor).  Log detached tensors "
+                               "(`self.log(name, value.detach())`) or use graph=False.  Original error: " + str(e)) from e
         # the capture itself does not execute; every replay is one full iteration
         while self.global_step < total:
             g.replay()
@@ -92,6 +114,18 @@ class Trainer:
         if dist.get_world_size() > 1 and any(p.requires_grad for p in module.network.parameters()):
             ids = [self.device.index] if self.device.type == "cuda" else None
             module.network = DDP(module.network, device_ids=ids)
+            # keep the reference's checkpoint keys ("network.<...>", no "module." level) in state_dict() / load_state_dict()
+            def strip(mod, sd, prefix, meta):
+                for k in [k for k in sd if k.startswith(prefix + "network.module.")]:
+                    sd[prefix + "network." + k[len(prefix + "network.module."):]] = sd.pop(k)
+                return sd
+
+            def add(sd, prefix, *unused):
+                for k in [k for k in sd if k.startswith(prefix + "network.") and not k.startswith(prefix + "network.module.")]:
+                    sd[prefix + "network.module." + k[len(prefix + "network."):]] = sd.pop(k)
+
+            module._register_state_dict_hook(strip)
+            module._register_load_state_dict_pre_hook(add)
         return module
 
     def fit(self, module, train_dataloaders, val_dataloaders=None):
@@ -108,15 +142,17 @@ class Trainer:
             if len(batches) != 1 or scheds or val_dataloaders is not None or self.callbacks:
                 raise ValueError("Trainer(graph=True) captures ONE static iteration: a single batch, no schedulers / validation / callbacks")
             return self._fit_graph(module, batches[0], opts)
+        with_idx = len(opts) > 1 and _takes_optimizer_idx(module)
         for epoch in range(self.max_epochs):
             self.current_epoch = module.current_epoch = epoch
             module.train()
             for idx, batch in enumerate(train_dataloaders):
                 batch = _to(batch, self.device)
-                for opt in opts:
+                for k, opt in enumerate(opts):
                     def closure():
                         opt.zero_grad(set_to_none=True)
-                        loss = self._loss_of(module.training_step(batch, idx))
+                        out = module.training_step(batch, idx, k) if with_idx else module.training_step(batch, idx)
+                        loss = self._loss_of(out)
                         loss.backward()
                         return loss
                     loss = opt.step(closure)

@@ -24,11 +24,23 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 3
+#define DN_ABI_VERSION 4
 
 #define DN_E_BADARG (-1)    /* null pointer / non-positive size / unsupported combination   */
 #define DN_E_UNSUPPORTED (-2) /* (nsd, degree, ngp) outside the compiled instantiations      */
 #define DN_E_WORKSPACE (-3)  /* workspace too small                                           */
+
+/* Process-wide tuning / A-B switches (launch geometry overrides, kernel-variant selection).  They are NOT part of the
+ * numerical contract: every setting yields the same results to rounding.  The table is initialised ONCE when the library
+ * is loaded, from the environment variables DN_<KEY>; afterwards the environment is never read again (no getenv on the
+ * launch path) and the only way to change a switch is this call.  Keys: "PLAN2D" ("T,E,R"), "PLAN3D" ("TX,TY,E,R"),
+ * "PLAN_FSDT" ("T,R"), "Q1_RULE_KERNEL" (non-empty: per-Gauss-point 2-D Q1 kernels instead of the closed form),
+ * "GPE_GATHER" (non-empty: per-node gather adjoint of gauss_pt_eval).  value NULL or "" clears the switch.
+ * Returns 0, or DN_E_BADARG for an unknown key / over-long value.  Not thread-safe against concurrent launches.
+ * No reference counterpart (the reference has no tuning surface). */
+int dn_config_set(const char *key, const char *value);
+/* Current value of a switch ("" when unset), NULL for an unknown key. */
+const char *dn_config_get(const char *key);
 
 /* Geometry + 1-D reference-element tables of one structured mesh.
  * Mirrors what DiffNetFEM.__init__ derives (DiffNet/DiffNetFEM.py:25-126):

@@ -320,6 +320,85 @@ class Oracle:
     def resmin(self, *a, **k):
         return torch.sum(self.residual(*a, **k) ** 2)
 
+    # -- assembly for any degree ------------------------------------------------------------------
+    def assemble(self, r_split):
+        """Element->node assembly for Q1/Q2/Q3.  The reference has the Q1 helper only (`assemble_q1` above); for higher
+        degrees assembly is DEFINED as the adjoint of `gauss_pt_eval` with one-hot tables: with
+        K_a = the nbf^nsd kernel that is 1 at local node a and 0 elsewhere, gauss_pt_eval(v, K)[b,a,e] = v at local node a
+        of element e, and assemble(r) = d<r, gauss_pt_eval(v, K)>/dv, evaluated by torch autograd on the reference's conv
+        formulation (DiffNetFEM.py:7-18).  For Q1 this equals `assemble_q1` (same scatter-add)."""
+        nb, nsd = self.spec.nbf_1d, self.nsd
+        onehot = torch.eye(nb ** nsd, dtype=r_split.dtype).reshape((nb ** nsd, 1, 1) + (nb,) * nsd)
+        node_sp = [n * (nb - 1) + 1 for n in r_split.shape[2:]]
+        v = torch.zeros((r_split.shape[0], 1, *node_sp), dtype=r_split.dtype, requires_grad=True)
+        gathered = gauss_pt_eval(v, onehot, nsd, self.stride)
+        (out,) = torch.autograd.grad(gathered, v, r_split, create_graph=r_split.requires_grad)
+        return out
+
+    def residual_any_degree(self, u, nu=None, f=None, dirichlet=(), jac=1.0, zero_masks=()):
+        """`residual` with the degree-independent assembly: the broadcast weak form of 12_klsum.py:96-122 on the module's
+        dense tables, then `assemble`."""
+        for mask, val in dirichlet:
+            u = torch.where(mask > 0.5, val + u * 0.0, u)
+        lhs = 0
+        for n in ["dN_x", "dN_y", "dN_z"][: self.nsd]:
+            lhs = lhs + self.t[n + "_values"].to(u.dtype) * self.ev(u, n + "_gp").unsqueeze(1)
+        if nu is not None:
+            lhs = self.ev(nu).unsqueeze(1) * lhs
+        if f is not None:
+            lhs = lhs - self.t["Nvalues"].to(u.dtype) * self.ev(f).unsqueeze(1)
+        R = self.assemble(torch.sum(lhs * (self._w(u, extra=1) * jac), 2))
+        for mask in zero_masks:
+            R = torch.where(mask > 0.5, R * 0.0, R)
+        return R
+
+    # -- 8(f) row 3 ------------------------------------------------------------------------------
+    def l2_err(self, u_sol, exact_fn, u_exact_nodes=None):
+        """calc_l2_err (DiffNet/DiffNetFEM.py:348-379 in 2-D, :560-591 in 3-D): Gauss-quadrature L2 norms of the error, the
+        solution and the exact solution, plus the nodal vector norm; `u_sol` (B,1,*N), `exact_fn(xgp, ygp[, zgp])`."""
+        u_gp = self.ev(u_sol)
+        u_ex_gp = exact_fn(*self.gp_coords()).type_as(u_sol)
+        jac = 1.0
+        for h in self.spec.hs:
+            jac = jac * (0.5 * h)
+        jxw = (self.gpw.type_as(u_sol) * jac).reshape((1, -1) + (1,) * self.nsd)
+        out = [torch.sqrt(torch.sum(torch.sum(v ** 2 * jxw, 1))) for v in (u_gp - u_ex_gp, u_gp, u_ex_gp)]
+        if u_exact_nodes is not None:
+            n_nodes = 1
+            for s_ in self.spec.sizes:
+                n_nodes *= s_
+            out.append(torch.norm(u_exact_nodes - u_sol, 'fro') / np.sqrt(n_nodes))
+        return out
+
+    def l2_err_old(self, u_sol, exact_fn, u_exact_nodes):
+        """calc_l2_err_old (DiffNet/DiffNetFEM.py:286-346, :482-558): the element / Gauss-point loops in float64 numpy on a unit
+        domain with the exact 2-point rule and unit weights.  Plain Python loops as in the reference (small meshes only)."""
+        n, nsd = self.spec.domain_size, self.nsd
+        a = 0.577350269189626 if nsd == 2 else float(self.spec.gpx_1d[1])
+        x = np.linspace(0, 1, n)
+        J = (0.5 / (n - 1)) ** nsd
+        tr = lambda lo, hi, g: (lo + hi) / 2. + (hi - lo) / 2. * g
+        u = np.asarray(u_sol, dtype=np.float64)
+        e2 = s2 = x2 = 0.0
+        import itertools
+        for el in itertools.product(range(n - 1), repeat=nsd):            # (j, i) or (k, j, i)
+            local = u[tuple(slice(c, c + 2) for c in el)]
+            for gp in itertools.product((-a, a), repeat=nsd):             # slowest axis first, like the local node order
+                basis = np.ones((2,) * nsd)
+                for ax, g in enumerate(gp):
+                    shp = [1] * nsd
+                    shp[ax] = 2
+                    basis = basis * (0.5 * np.array([1 - g, 1 + g])).reshape(shp)
+                u1 = float(np.sum(local * basis))
+                pts = [tr(x[c], x[c + 1], g) for c, g in zip(el, gp)][::-1]      # (x, y[, z])
+                u2 = float(exact_fn(*pts))
+                e2 += (u1 - u2) ** 2 * J
+                s2 += u1 ** 2 * J
+                x2 += u2 ** 2 * J
+        ue = np.asarray(u_exact_nodes, dtype=np.float64)
+        vec = np.linalg.norm(ue.reshape(-1, 1) - u.reshape(-1, 1), 'fro') / (1. * n) ** (nsd / 2.)
+        return np.sqrt(e2), np.sqrt(s2), np.sqrt(x2), vec
+
     # -- a14 -------------------------------------------------------------------------------------
     def fsdt_residuals(self, w, px, py, bc, E=1.0, v=0.25, th=0.1, Ks=1.0, q=1.0):
         """First-order shear-deformation plate residuals, e1_plate_bending_fsdt.py:128-228
@@ -340,13 +419,15 @@ class Oracle:
         Mxy = D66 * (pxy + pyx)
         N_, Nx, Ny = (self.t[n].to(w.dtype) for n in ["Nvalues", "dN_x_values", "dN_y_values"])
         jac = (0.5 * self.spec.h) ** 2
-        jxw = (self.gpw.to(w.dtype) * jac).reshape(1, -1, 1, 1)
+        jxw = (self.gpw.to(w.dtype) * jac).reshape(1, 1, -1, 1, 1)
+        Qx, Qy, Mxx, Myy, Mxy = (t_.unsqueeze(1) for t_ in (Qx, Qy, Mxx, Myy, Mxy))
         t1 = Nx * Qx + Ny * Qy - N_ * (q * torch.ones_like(Qx))
         t2 = Nx * Mxx + Ny * Mxy + N_ * Qx
         t3 = Nx * Mxy + Ny * Myy + N_ * Qy
         Rs = []
         for tt in (t1, t2, t3):
-            R = self.assemble_q1(torch.sum(tt * jxw, 2), torch.zeros_like(w))
+            rs = torch.sum(tt * jxw, 2)
+            R = self.assemble_q1(rs, torch.zeros_like(w)) if self.spec.deg == 1 else self.assemble(rs)
             Rs.append(torch.where(bc >= 0.5, zero, R))
         return Rs
 

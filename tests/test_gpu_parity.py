@@ -584,11 +584,12 @@ def test_fsdt_fused_full_size_q2_strips_and_chunks():
     assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), abs(rhs))
     for k in range(3):
         np.testing.assert_allclose(float(sums[k]), float((Kb[k].double() ** 2).sum()), rtol=1e-6)
-    os.environ["DN_PLAN_FSDT"] = "64,7"
+    from diffnet_amd import _lib
+    _lib.config_set("PLAN_FSDT", "64,7")
     try:
         Ka2, _ = ops.fsdt_apply(m.geom, *a3, bc, **kw)
     finally:
-        del os.environ["DN_PLAN_FSDT"]
+        _lib.config_set("PLAN_FSDT", "")
     for x, y in zip(Ka, Ka2):
         assert torch.equal(x, y)
 
@@ -739,7 +740,7 @@ def test_concurrent_streams_use_separate_workspaces_and_stay_bitwise_repeatable(
 
 @pytest.mark.parametrize("ngp", [2, 3, 4])
 def test_closed_form_kernel_equals_the_per_point_kernel(ngp):
-    """The default 2-D Q1 kernel evaluates the Gauss sums as polynomials of the rule's moments; DN_Q1_RULE_KERNEL=1 selects
+    """The default 2-D Q1 kernel evaluates the Gauss sums as polynomials of the rule's moments; dn_config_set("Q1_RULE_KERNEL") selects
     the kernel that visits every Gauss point.  Same inputs at the bench mesh: loss to 2e-6, gradient to 1e-5 of its scale
     (fp32 re-association only), for the reference's exact 2-point and truncated 3- / 4-point rules alike."""
     m = module(dict(domain_size=512, ngp_1d=ngp))
@@ -748,12 +749,13 @@ def test_closed_form_kernel_equals_the_per_point_kernel(ngp):
     bc = boundary_mask(shape).to(dev()).to(torch.uint8)
     v_cf, g_cf = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
     R_cf = m.residual(u, nu, f, dirichlet=[(bc, 0.0)], jac=0.25)
-    os.environ["DN_Q1_RULE_KERNEL"] = "1"
+    from diffnet_amd import _lib
+    _lib.config_set("Q1_RULE_KERNEL", "1")
     try:
         v_pt, g_pt = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
         R_pt = m.residual(u, nu, f, dirichlet=[(bc, 0.0)], jac=0.25)
     finally:
-        del os.environ["DN_Q1_RULE_KERNEL"]
+        _lib.config_set("Q1_RULE_KERNEL", "")
     np.testing.assert_allclose(float(v_cf), float(v_pt), rtol=2e-6)
     assert float((g_cf - g_pt).abs().max()) <= 1e-5 * float(g_pt.abs().max())
     assert float((R_cf - R_pt).abs().max()) <= 1e-5 * float(R_pt.abs().max())

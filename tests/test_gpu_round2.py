@@ -1,0 +1,344 @@
+"""GPU parity, round 2: the pins VERDICT r1 asked for.
+  * calc_l2_err against the numbers the imported reference printed (tests/golden/l2_*.npz);
+  * Q2/Q3 element->node assembly and the Q2/Q3 FSDT / Poisson residual kernels against the ORACLE (assembly defined as the
+    adjoint of the reference's conv formulation with one-hot tables, oracle/fem_oracle.py:Oracle.assemble), not against
+    other HIP kernels;
+  * BASELINE configs[3] (256^3) and configs[4] (1025^2 nodes = 512^2 Q2 elements) at their full size;
+  * gradients wrt nu / f / Dirichlet value fields (never silently zero), double backward of the linear operators;
+  * the FSDT loss at the reference's all-zero initial state; graph capture with the stock `training_step`.
+Tolerances as in test_gpu_parity.py (fp32): outputs rtol 1e-5 / atol 1e-6 max|ref| unless stated."""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from test_gpu_parity import boundary_mask, close, cu, dev, module, seeded
+from test_oracle_golden import exact_sines
+
+pytestmark = pytest.mark.gpu
+
+L2_FILES = sorted(glob.glob(os.path.join(GOLDEN, "l2_*.npz")))
+
+
+@pytest.mark.parametrize("path", L2_FILES, ids=[os.path.basename(p)[3:-4] for p in L2_FILES])
+def test_calc_l2_err_vs_reference_golden(path, capsys):
+    z = np.load(path)
+    m = module(eval(str(z["kwargs"])))
+    m.exact_solution, m.u_exact = exact_sines, z["u_exact"]
+    got = m.calc_l2_err(cu(z["u_sol"])[None, None])
+    np.testing.assert_allclose([float(v) for v in got], z["new"], rtol=5e-6)
+    out = capsys.readouterr().out
+    assert "||e||_{{L2}} = " in out and "||u_sol||, ||uex|| = " in out and "(vector-norm)" in out    # prints like the reference
+
+
+@pytest.mark.parametrize("nsd,deg,n,B", [(2, 2, 33, 2), (2, 3, 31, 2), (3, 2, 9, 2), (3, 3, 7, 1), (2, 2, 129, 1)])
+def test_assembly_any_degree_vs_oracle_adjoint(nsd, deg, n, B):
+    from oracle.fem_oracle import Oracle
+    m = module(dict(domain_size=n, nsd=nsd, fem_basis_deg=deg))
+    o = Oracle(domain_size=n, nsd=nsd, fem_basis_deg=deg)
+    nel = (n - 1) // deg
+    rs = seeded((B, (deg + 1) ** nsd) + (nel,) * nsd, 61) - 0.5
+    ref = o.assemble(rs)
+    got = m.assemble(rs.to(dev()))
+    close(got, ref.numpy(), rtol=1e-6, arel=1e-6)
+    # VJP (the gather) against autograd through the oracle
+    cot = seeded(ref.shape, 62)
+    rr = rs.clone().requires_grad_(True)
+    (gref,) = torch.autograd.grad(o.assemble(rr), rr, cot)
+    r = rs.to(dev()).requires_grad_(True)
+    (g,) = torch.autograd.grad(m.assemble(r), r, cot.to(dev()))
+    assert torch.equal(g.cpu(), gref)                        # a pure gather: exact
+
+
+@pytest.mark.parametrize("deg,ngp,n", [(2, 3, 17), (2, 4, 33), (3, 3, 19), (3, 4, 31), (2, 3, 65)])
+def test_fsdt_q2_q3_vs_oracle(deg, ngp, n):
+    """configs[4] shape class: three-field FSDT residuals on Q2/Q3 meshes, fused kernel vs the oracle's reference formulation
+    (per-Gauss-point convs, broadcast weak form, adjoint-defined assembly) and its autograd VJP."""
+    from diffnet_amd.elasticity import fsdt_loss, fsdt_residuals
+    from oracle.fem_oracle import Oracle
+    kw = dict(domain_size=n, fem_basis_deg=deg, ngp_1d=ngp)
+    m, o = module(kw), Oracle(**kw)
+    shape = (1, 1, n, n)
+    flds = [seeded(shape, 120 + i) for i in range(3)]
+    bc = boundary_mask(shape)
+    par = dict(E=2.0, v=0.3, q=1.5)
+    ref_in = [t.clone().requires_grad_(True) for t in flds]
+    Rref = o.fsdt_residuals(*ref_in, bc, th=0.2, Ks=5.0 / 6.0, **par)
+    gpu_in = [t.to(dev()).requires_grad_(True) for t in flds]
+    R = fsdt_residuals(m, *gpu_in, bc.to(dev()), h=0.2, K_s=5.0 / 6.0, **par)
+    for a, b in zip(R, Rref):
+        close(a, b.detach().numpy(), rtol=1e-4, arel=2e-5)
+    cots = [seeded(shape, 130 + i) for i in range(3)]
+    gref = torch.autograd.grad(Rref, ref_in, cots)
+    g = torch.autograd.grad(R, gpu_in, [c.to(dev()) for c in cots])
+    for a, b in zip(g, gref):
+        close(a, b.numpy(), rtol=1e-4, arel=1e-4)
+    norms = fsdt_loss(m, *gpu_in, bc.to(dev()), h=0.2, K_s=5.0 / 6.0, **par)
+    for nv, b in zip(norms, Rref):
+        np.testing.assert_allclose(float(nv), float(torch.linalg.vector_norm(b.double())), rtol=2e-5)
+
+
+@pytest.mark.parametrize("kw,B", [(dict(domain_size=33, fem_basis_deg=2), 2), (dict(domain_size=65, fem_basis_deg=2, ngp_1d=4), 1),
+                                  (dict(domain_size=31, fem_basis_deg=3), 2),
+                                  (dict(domain_sizes=(129, 37, 1), domain_lengths=(1.0, 1.0, 1.0), domain_size=129, fem_basis_deg=2), 1)])
+def test_fused_residual_q2_q3_vs_oracle(kw, B):
+    from oracle.fem_oracle import Oracle
+    m, o = module(kw), Oracle(**kw)
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = seeded(shape, 5), seeded(shape, 6, 0.5), seeded(shape, 7)
+    bc = boundary_mask(shape)
+    ubc = seeded(shape[2:], 8)
+    ur = u.clone().requires_grad_(True)
+    Rref = o.residual_any_degree(ur, nu, f, dirichlet=[(bc, ubc[None, None])], jac=0.25, zero_masks=[bc])
+    (gref,) = torch.autograd.grad(torch.sum(Rref ** 2), ur)
+    d = [(bc.to(dev()), ubc.to(dev()))]
+    R = m.residual(u.to(dev()), nu.to(dev()), f.to(dev()), dirichlet=d, jac=0.25)
+    close(R, Rref.detach().numpy(), rtol=1e-4, arel=2e-5)
+    ug = u.to(dev()).requires_grad_(True)
+    v = m.residual_loss(ug, nu.to(dev()), f.to(dev()), dirichlet=d, jac=0.25)
+    (g,) = torch.autograd.grad(v, ug)
+    np.testing.assert_allclose(float(v), float(torch.sum(Rref ** 2)), rtol=2e-5)
+    close(g, gref.numpy(), rtol=1e-4, arel=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[3] and configs[4] at their full size
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw,B", [("cfg4_3d_256_g2", dict(domain_size=256, nsd=3), 1), ("cfg5_2d_1025_q2", dict(domain_size=1025, fem_basis_deg=2), 1)])
+def test_full_size_properties_round2(name, kw, B):
+    from test_gpu_parity import test_full_size_properties
+    test_full_size_properties(name, kw, B)
+
+
+def test_full_size_3d_256_agrees_with_slab_partition_and_oracle_slab():
+    """256^3 (configs[3]): the global launch equals the sum of 8 z-slab launches (the 8-GPU decomposition run on one GPU), and one
+    thin slab of it equals the oracle on the same nodes (the oracle finishes 256 x 256 x 3 in seconds)."""
+    from diffnet_amd import DiffNet3DFEM, ops
+    from diffnet_amd.slab import SlabDecomposition
+    from oracle.fem_oracle import Oracle
+    n = 256
+    shape = (1, 1, n, n, n)
+    g = torch.Generator().manual_seed(4)
+    u, nu, f = torch.rand(shape, generator=g), 0.5 + torch.rand(shape, generator=g), torch.rand(shape, generator=g)
+    ud, nud, fd = u.to(dev()), nu.to(dev()), f.to(dev())
+    bc = boundary_mask(shape).to(torch.uint8).to(dev())
+    m = module(dict(domain_size=n, nsd=3))
+    lref, gref = m.energy_loss_and_grad(ud, nud, fd, dirichlet=[(bc, 0.0)], c=1.0)
+    esum, gfull = 0.0, torch.zeros_like(ud)
+    for r in range(8):
+        dec = SlabDecomposition(3, (n, n, n), (1.0, 1.0, 1.0), r, 8)
+        fem = DiffNet3DFEM(None, **dec.local_kwargs()).to(dev())
+        gl, sums = ops.poisson_apply(fem.geom, dec.take(ud), dec.take(nud), dec.take(fd), None, [(dec.take(bc), 0.0)], alpha=2.0, beta=1.0,
+                                     c=1.0, wscale=1.0, out_scale=1.0 / dec.nel_global)
+        esum += float(sums[0])
+        gfull[:, :, dec.n0:dec.n1 + 1] += gl
+    np.testing.assert_allclose(esum / m.geom.nelem_total, float(lref), rtol=1e-6)
+    close(gfull, gref.cpu().numpy(), rtol=1e-5, arel=1e-6)
+    # a 3-plane slab in the middle of the cube, no Dirichlet nodes inside it except the lateral faces
+    k0 = 100
+    sl = slice(k0, k0 + 3)
+    kw = dict(nsd=3, domain_sizes=(n, n, 3), domain_lengths=(1.0, 1.0, 2.0 / (n - 1)), domain_size=n, domain_length=1.0)
+    o, ms = Oracle(**kw), module(kw)
+    bcs = boundary_mask(shape)[:, :, sl].clone()
+    bcs[:, :, 0, 1:-1, 1:-1] = 0
+    bcs[:, :, -1, 1:-1, 1:-1] = 0
+    ur = u[:, :, sl].clone().requires_grad_(True)
+    ref = o.energy(ur, nu[:, :, sl], f[:, :, sl], dirichlet=[(bcs, 0.0)], c=1.0)
+    (gr,) = torch.autograd.grad(ref, ur)
+    v, gg = ms.energy_loss_and_grad(ud[:, :, sl].contiguous(), nud[:, :, sl].contiguous(), fd[:, :, sl].contiguous(),
+                                    dirichlet=[(bcs.to(dev()), 0.0)], c=1.0)
+    np.testing.assert_allclose(float(v), float(ref), rtol=1e-5)
+    close(gg, gr.numpy(), rtol=1e-4, arel=1e-4)
+
+
+def test_fsdt_full_size_1025_q2():
+    """configs[4] at its size (1025 x 1025 nodes = 512 x 512 Q2 elements, 3 x 3 points, three fields): symmetry of the
+    homogeneous operator, in-kernel norms, repartition invariance; and a 1025 x 9 strip of the same fields against the oracle."""
+    from diffnet_amd import _lib, ops
+    from diffnet_amd.elasticity import fsdt_residuals
+    from oracle.fem_oracle import Oracle
+    n = 1025
+    m = module(dict(domain_size=n, fem_basis_deg=2, ngp_1d=3))
+    shape = (1, 1, n, n)
+    a3 = [seeded(shape, 100 + i).to(dev()) for i in range(3)]
+    b3 = [seeded(shape, 110 + i).to(dev()) for i in range(3)]
+    bc = boundary_mask(shape).to(dev())
+    kw = dict(D11=1.0, D12=0.3, D22=1.0, D66=0.35, A44=40.0, A55=40.0, q=0.0, wscale=(0.5 * m.h) ** 2)
+    Ka, _ = ops.fsdt_apply(m.geom, *a3, bc, **kw)
+    Kb, sums = ops.fsdt_apply(m.geom, *b3, bc, **kw)
+    lhs = sum(float((x.double() * y.double() * (1 - bc.double())).sum()) for x, y in zip(Ka, b3))
+    rhs = sum(float((x.double() * y.double() * (1 - bc.double())).sum()) for x, y in zip(a3, Kb))
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), abs(rhs))
+    for k in range(3):
+        np.testing.assert_allclose(float(sums[k]), float((Kb[k].double() ** 2).sum()), rtol=1e-6)
+        assert float((Ka[k] * bc).abs().max()) == 0.0
+    _lib.config_set("PLAN_FSDT", "64,7")
+    try:
+        Ka2, _ = ops.fsdt_apply(m.geom, *a3, bc, **kw)
+    finally:
+        _lib.config_set("PLAN_FSDT", "")
+    for x, y in zip(Ka, Ka2):
+        assert torch.equal(x, y)
+    # oracle on a strip: a 1025 x 9 mesh (512 x 4 Q2 elements) with the same hx, hy
+    ny = 9
+    skw = dict(domain_sizes=(n, ny, 1), domain_lengths=(1.0, (ny - 1) / (n - 1), 1.0), domain_size=n, domain_length=1.0, fem_basis_deg=2)
+    ms, o = module(skw), Oracle(**skw)
+    flds = [seeded((1, 1, ny, n), 140 + i) for i in range(3)]
+    bcs = boundary_mask((1, 1, ny, n))
+    Rref = o.fsdt_residuals(*flds, bcs, E=2.0, v=0.3, th=0.2, Ks=5.0 / 6.0, q=1.0)
+    R = fsdt_residuals(ms, *[t.to(dev()) for t in flds], bcs.to(dev()), E=2.0, v=0.3, h=0.2, K_s=5.0 / 6.0, q=1.0)
+    for x, y in zip(R, Rref):
+        close(x, y.numpy(), rtol=1e-4, arel=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# every tensor input is differentiable (or the call raises): no silent zero gradients
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kw,B", [(dict(domain_size=33, ngp_1d=3), 2), (dict(domain_size=17, fem_basis_deg=2), 1), (dict(domain_size=12, nsd=3), 2)])
+def test_gradients_wrt_coefficients_and_dirichlet_values(kw, B):
+    from oracle.fem_oracle import Oracle
+    m, o = module(kw), Oracle(**kw)
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = seeded(shape, 1), seeded(shape, 2, 0.5), seeded(shape, 3)
+    bc, ubc = boundary_mask(shape), seeded(shape, 4)
+    cpu_in = [t.clone().requires_grad_(True) for t in (u, nu, f, ubc)]
+    ref = o.energy(cpu_in[0], cpu_in[1], cpu_in[2], dirichlet=[(bc, cpu_in[3])], c=0.5, jac=0.7)
+    gref = torch.autograd.grad(ref, cpu_in)
+    gpu_in = [t.to(dev()).requires_grad_(True) for t in (u, nu, f, ubc)]
+    val = m.energy_loss(gpu_in[0], gpu_in[1], gpu_in[2], dirichlet=[(bc.to(dev()), gpu_in[3])], c=0.5, jac=0.7)
+    g = torch.autograd.grad(val, gpu_in)
+    np.testing.assert_allclose(float(val), float(ref), rtol=1e-5)
+    for a, b, name in zip(g, gref, ("u", "nu", "f", "dirichlet value")):
+        assert float(b.abs().max()) > 0, name
+        close(a, b.numpy(), rtol=1e-4, arel=1e-4, msg=name)
+    # the fused single-launch form (coefficients detached) agrees on value and du
+    vf = m.energy_loss(gpu_in[0], gpu_in[1].detach(), gpu_in[2].detach(), dirichlet=[(bc.to(dev()), gpu_in[3].detach())], c=0.5, jac=0.7)
+    (gu,) = torch.autograd.grad(vf, gpu_in[0])
+    np.testing.assert_allclose(float(vf), float(val), rtol=2e-6)
+    close(gu, g[0].cpu().numpy(), rtol=1e-4, arel=1e-5)
+    if m.fem_basis_deg == 1:
+        cpu_in = [t.clone().requires_grad_(True) for t in (u, nu, f)]
+        Rr = o.residual(cpu_in[0], cpu_in[1], cpu_in[2], dirichlet=[(bc, 0.0 * u)], jac=0.25, zero_masks=[bc])
+        gref = torch.autograd.grad(torch.sum(Rr ** 2), cpu_in)
+        gpu_in = [t.to(dev()).requires_grad_(True) for t in (u, nu, f)]
+        v2 = m.residual_loss(gpu_in[0], gpu_in[1], gpu_in[2], dirichlet=[(bc.to(dev()), 0.0)], jac=0.25)
+        g = torch.autograd.grad(v2, gpu_in)
+        np.testing.assert_allclose(float(v2), float(torch.sum(Rr ** 2)), rtol=2e-5)
+        for a, b, name in zip(g, gref, ("u", "nu", "f")):
+            close(a, b.numpy(), rtol=2e-4, arel=1e-4, msg="resmin " + name)
+
+
+@pytest.mark.parametrize("kw", [dict(domain_size=17), dict(domain_size=9, nsd=3), dict(domain_size=17, fem_basis_deg=2)])
+def test_operators_differentiate_twice(kw):
+    """gauss_pt_evaluation* are linear maps; like the reference's convolutions they support create_graph=True (gradient
+    penalties, PINN-style terms): d/du of |d/du sum(phi(D u))|^2 against the oracle."""
+    from oracle.fem_oracle import Oracle
+    m, o = module(kw), Oracle(**kw)
+    shape = (2, 1, *m.geom.node_shape)
+    u = seeded(shape, 9)
+
+    def penalty(ev_dx, x):
+        y = ev_dx(x)
+        (g1,) = torch.autograd.grad(torch.sum(torch.sin(y)), x, create_graph=True)
+        return torch.sum(g1 ** 2)
+
+    ur = u.clone().requires_grad_(True)
+    pref = penalty(lambda x: o.ev(x, "dN_x_gp"), ur)
+    (gref,) = torch.autograd.grad(pref, ur)
+    ug = u.to(dev()).requires_grad_(True)
+    p = penalty(m.gauss_pt_evaluation_der_x, ug)
+    (g,) = torch.autograd.grad(p, ug)
+    np.testing.assert_allclose(float(p), float(pref), rtol=2e-5)
+    close(g, gref.numpy(), rtol=1e-4, arel=1e-4)
+    # fused losses are single-pass kernels: double backward raises instead of returning constants
+    v = m.energy_loss(ug)
+    (g1,) = torch.autograd.grad(v, ug, create_graph=True)
+    with pytest.raises(RuntimeError):
+        torch.autograd.grad(g1.sum(), ug)
+
+
+def test_fsdt_loss_is_finite_at_the_all_zero_initial_state():
+    """The reference FSDT script starts from w = phi_x = phi_y = 0 with zero Dirichlet values (e1_plate_bending_fsdt.py:341-349):
+    R2 = R3 = 0 exactly, ||R|| = 0, and torch's norm backward gives a zero subgradient there.  The fused VJP must do the
+    same (no 0/0), and match the composed torch path."""
+    from diffnet_amd.elasticity import fsdt_loss, fsdt_residuals_composed
+    n = 33
+    m = module(dict(domain_size=n))
+    shape = (1, 1, n, n)
+    bc = boundary_mask(shape).to(dev())
+    f1 = [torch.zeros(shape, device=dev(), requires_grad=True) for _ in range(3)]
+    f2 = [torch.zeros(shape, device=dev(), requires_grad=True) for _ in range(3)]
+    norms = fsdt_loss(m, *f1, bc, q=1.0)
+    assert float(norms[1]) == 0.0 and float(norms[2]) == 0.0 and float(norms[0]) > 0
+    comp = [torch.norm(R) for R in fsdt_residuals_composed(m, *f2, bc, q=1.0)]
+    for k in range(3):
+        gf = torch.autograd.grad(norms[k], f1, retain_graph=True, allow_unused=True)
+        gc = torch.autograd.grad(comp[k], f2, retain_graph=True, allow_unused=True)
+        for a, b in zip(gf, gc):
+            a = torch.zeros(shape, device=dev()) if a is None else a
+            b = torch.zeros(shape, device=dev()) if b is None else b
+            assert torch.isfinite(a).all()
+            close(a, b.cpu().numpy(), rtol=2e-4, arel=2e-5)
+    total = norms[0] + norms[1] + norms[2]
+    for gq in torch.autograd.grad(total, f1):
+        assert torch.isfinite(gq).all()
+
+
+def test_graph_capture_with_the_stock_training_step():
+    """Trainer(graph=True) on a module that keeps PDE.training_step (which logs the loss; `.item()` during capture would be a
+    host sync): same trajectory as the eager loop, and the logged value is the latest replay's loss."""
+    from torch import nn
+    from diffnet_amd import DiffNet2DFEM
+    from diffnet_amd.trainer import Trainer
+
+    class P(DiffNet2DFEM):
+        def forward(self, batch):
+            nu, f, bc = batch
+            return self.network[0], (nu, bc), f
+
+        def loss(self, u, inputs, f):
+            nu, bc = inputs
+            return self.energy_loss(u, nu, f, dirichlet=[(bc, 0.0)], c=0.5)
+
+        def configure_optimizers(self):
+            return [torch.optim.Adam(self.network.parameters(), lr=1e-3, capturable=True)], []
+
+    n, outs = 33, {}
+    for graph in (False, True):
+        net = nn.ParameterList([nn.Parameter(torch.zeros(1, 1, n, n))])
+        mod = P(net, domain_size=n, ngp_1d=2)
+        batch = (seeded((1, 1, n, n), 5, lo=0.5), seeded((1, 1, n, n), 6), boundary_mask((1, 1, n, n)))
+        tr = Trainer(max_epochs=25, graph=graph, device=dev()).fit(mod, [batch])
+        logged = mod.logged["loss"] if hasattr(mod, "logged") else None
+        outs[graph] = (mod.network[0].detach().clone(), tr.history, logged)
+    assert outs[True][1] == outs[False][1] and torch.equal(outs[True][0], outs[False][0])
+    if outs[True][2] is not None:
+        np.testing.assert_allclose(float(outs[True][2]), outs[True][1][-1], rtol=0, atol=0)
+
+
+def test_config_switches_are_explicit_calls_not_per_launch_getenv():
+    """Tuning / A-B switches are set through the C ABI (dn_config_set) and read once; changing the process environment after
+    the library is loaded has no effect on launches."""
+    from diffnet_amd import _lib
+    m = module(dict(domain_size=512, ngp_1d=3))
+    shape = (2, 1, 512, 512)
+    u, nu, f = (seeded(shape, 700 + i, lo=0.5 if i == 1 else 0.0).to(dev()) for i in range(3))
+    v0, g0 = m.energy_loss_and_grad(u, nu, f, c=1.0)
+    os.environ["DN_Q1_RULE_KERNEL"] = "1"
+    try:
+        v1, g1 = m.energy_loss_and_grad(u, nu, f, c=1.0)
+    finally:
+        del os.environ["DN_Q1_RULE_KERNEL"]
+    assert torch.equal(g0, g1)                                  # the environment is not consulted per launch
+    _lib.config_set("Q1_RULE_KERNEL", "1")
+    try:
+        v2, g2 = m.energy_loss_and_grad(u, nu, f, c=1.0)
+    finally:
+        _lib.config_set("Q1_RULE_KERNEL", "")
+    assert not torch.equal(g0, g2) and float((g0 - g2).abs().max()) <= 1e-5 * float(g0.abs().max())
+    with pytest.raises(_lib.DiffNetHipError):
+        _lib.config_set("NO_SUCH_SWITCH", "1")

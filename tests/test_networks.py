@@ -232,3 +232,30 @@ def test_instnorm_act_backward_reads_channel_slices_in_place():
         g_slice, = torch.autograd.grad(y, x, wide[:, :Cn], retain_graph=True)
         g_copy, = torch.autograd.grad(y, x, wide[:, :Cn].contiguous())
         assert not wide[:, :Cn].is_contiguous() and torch.equal(g_slice, g_copy)
+
+
+@pytest.mark.gpu
+def test_unet_at_the_baseline_mesh_512_matches_reference():
+    """BASELINE configs[1]'s network at its own size: U-Net(2 -> 1) on a 512 x 512 sample (eval mode), output and gradients
+    against the imported reference's CPU result (fixture keeps every 8th row / column; tools/gen_golden.py --net512)."""
+    z = np.load(os.path.join(GOLDEN, "net_unet_2_1_n512.npz"))
+    dev = torch.device("cuda:0")
+    net = build("unet_2_1_n64").to(dev)
+    sd = net.state_dict()
+    cs = np.array([float(sum(v.double().sum() for v in sd.values())), float(sum(v.double().abs().sum() for v in sd.values()))])
+    np.testing.assert_allclose(cs, z["checksum"], rtol=1e-12)
+    n, st = int(z["n"]), int(z["stride"])
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, n), torch.linspace(0, 1, n), indexing="ij")
+    x = torch.stack([0.5 + 0.4 * torch.sin(7 * xx + 3 * yy), (torch.cos(5 * xx * yy) > 0.3).float()], 0)[None].to(dev).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = net(x)
+    cot = torch.cos(11 * xx - 4 * yy)[None, None].to(dev)
+    gx, = torch.autograd.grad(y, x, cot, retain_graph=True)
+    gw, = torch.autograd.grad(y, list(net.parameters())[0], cot)
+    np.testing.assert_allclose(y.detach().cpu().numpy()[..., ::st, ::st], z["y"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(float(y.double().sum()), float(z["y_sum"]), rtol=1e-5)
+    gtol = 2e-3
+    np.testing.assert_allclose(gx.cpu().numpy()[..., ::st, ::st], z["grad_x"], rtol=gtol, atol=gtol * 0.1 * float(np.abs(z["grad_x"]).max()))
+    np.testing.assert_allclose(gw.cpu().numpy(), z["grad_w0"], rtol=gtol, atol=gtol * 0.1 * float(np.abs(z["grad_w0"]).max()))
+    np.testing.assert_allclose(float(gx.double().abs().sum()), float(z["gx_abs_sum"]), rtol=1e-3)

@@ -232,3 +232,63 @@ def test_winding_number_oracle(tag):
     z = load(f"winding_{tag}.npz")
     w = winding_nodes(tt(z["points"]), tt(z["normals"]), tt(z["nodes"]))
     np.testing.assert_allclose(w.numpy(), z["winding"], rtol=2e-4, atol=1e-5 * np.abs(z["winding"]).max())
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2: calc_l2_err and the degree-independent assembly
+# ---------------------------------------------------------------------------------------------
+def exact_sines(*xs):
+    if torch.is_tensor(xs[0]):
+        out = torch.sin(math.pi * xs[0])
+        for x in xs[1:]:
+            out = out * torch.sin(math.pi * x)
+        return out
+    out = np.sin(math.pi * xs[0])
+    for x in xs[1:]:
+        out = out * np.sin(math.pi * x)
+    return out
+
+
+L2_FILES = sorted(glob.glob(os.path.join(GOLDEN, "l2_*.npz")))
+
+
+@pytest.mark.parametrize("path", L2_FILES, ids=[os.path.basename(p)[3:-4] for p in L2_FILES])
+def test_l2_error_norms_vs_reference(path):
+    """calc_l2_err / calc_l2_err_old numbers the reference printed (tools/gen_golden.py --l2) vs the oracle restatement and
+    vs the product's host routine `calc_l2_err_old` (numpy, no GPU involved)."""
+    z = np.load(path)
+    kw = eval(str(z["kwargs"]))
+    o = Oracle(**kw)
+    u_sol, u_ex = tt(z["u_sol"]), tt(z["u_exact"])
+    got = o.l2_err(u_sol[None, None], exact_sines, u_ex)
+    np.testing.assert_allclose([float(v) for v in got], z["new"], rtol=2e-6)
+    if "old" in z.files:
+        old = o.l2_err_old(z["u_sol"].astype(np.float64), exact_sines, z["u_exact"])
+        np.testing.assert_allclose(old, z["old"], rtol=1e-12)
+        from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM
+        m = (DiffNet3DFEM if kw.get("nsd", 2) == 3 else DiffNet2DFEM)(None, **kw)
+        m.exact_solution, m.u_exact = exact_sines, (u_ex if kw.get("nsd", 2) == 3 else z["u_exact"])
+        mine = m.calc_l2_err_old(z["u_sol"].astype(np.float64))
+        np.testing.assert_allclose(mine, z["old"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("nsd,deg,n", [(2, 1, 9), (3, 1, 5), (2, 2, 9), (2, 3, 10), (3, 2, 5)])
+def test_assembly_as_adjoint_of_evaluation(nsd, deg, n):
+    """`Oracle.assemble` (autograd of the conv formulation with one-hot tables) equals the reference's Q1 slicing helper
+    bit for bit at degree 1, and is the exact adjoint of the one-hot evaluation at every degree."""
+    o = Oracle(domain_size=n, nsd=nsd, fem_basis_deg=deg)
+    g = torch.Generator().manual_seed(5)
+    nel = (n - 1) // deg
+    rs = torch.rand((2, (deg + 1) ** nsd) + (nel,) * nsd, generator=g) - 0.5
+    a = o.assemble(rs)
+    assert tuple(a.shape) == (2, 1) + (n,) * nsd
+    if deg == 1:
+        ref = o.assemble_q1(rs, torch.zeros_like(a))
+        np.testing.assert_allclose(a.numpy(), ref.numpy(), rtol=0, atol=1e-6)
+    v = torch.rand(a.shape, generator=g)
+    nb = deg + 1
+    onehot = torch.eye(nb ** nsd).reshape((nb ** nsd, 1, 1) + (nb,) * nsd)
+    lhs = float((a.double() * v.double()).sum())
+    rhs = float((rs.double() * gauss_pt_eval(v, onehot, nsd, deg).double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * abs(lhs)
+    np.testing.assert_allclose(float(a.double().sum()), float(rs.double().sum()), rtol=1e-6)   # every entry lands exactly once

@@ -38,7 +38,11 @@ def _worker(rank, world, port, out):
     ds = torch.utils.data.TensorDataset(x, y)
     loader = DeviceLoader(ds, batch_size=4, device="cpu", rank=rank, world=world)
     m = _module()
+    keys_before = sorted(m.state_dict().keys())
     Trainer(max_epochs=2, device="cpu", strategy="ddp").fit(m, loader)
+    # DistributedDataParallel adds a "module." level; the module keeps the reference's checkpoint keys and loads them back
+    assert sorted(m.state_dict().keys()) == keys_before, (sorted(m.state_dict().keys()), keys_before)
+    m.load_state_dict(m.state_dict())
     torch.save([p.detach().clone() for p in m.network.parameters()], os.path.join(out, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
@@ -60,3 +64,35 @@ def test_ddp_replicas_match_the_large_batch_step(tmp_path):
     Trainer(max_epochs=2, device="cpu").fit(m, batches)
     for a, b in zip(p0, m.network.parameters()):
         np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_multi_optimizer_loop_passes_optimizer_idx():
+    """Lightning 1.x semantics the reference's FSDT script relies on (e1_plate_bending_fsdt.py:
+    `training_step(self, batch, batch_idx, optimizer_idx)` returning `loss_vals[optimizer_idx]`, one optimizer per field)."""
+    from diffnet_amd.base import PDE
+    from diffnet_amd.trainer import Trainer
+    seen = []
+
+    class M(PDE):
+        def training_step(self, batch, batch_idx, optimizer_idx):
+            seen.append(optimizer_idx)
+            a, b = self.network[0], self.network[1]
+            return [(a - 1.0).pow(2).sum(), (b + 2.0).pow(2).sum()][optimizer_idx]
+
+        def configure_optimizers(self):
+            return [torch.optim.SGD([self.network[0]], lr=0.25), torch.optim.SGD([self.network[1]], lr=0.25)], []
+
+    m = M(nn.ParameterList([nn.Parameter(torch.zeros(3)), nn.Parameter(torch.zeros(3))]))
+    Trainer(max_epochs=3, device="cpu").fit(m, [(torch.zeros(1), torch.zeros(1))])
+    assert seen == [0, 1] * 3
+    # each optimizer descended its own loss: a -> 1 (factor 1/2 per step), b -> -2
+    np.testing.assert_allclose(m.network[0].detach().numpy(), 1.0 - 0.5 ** 3, rtol=1e-6)
+    np.testing.assert_allclose(m.network[1].detach().numpy(), -2.0 * (1.0 - 0.5 ** 3), rtol=1e-6)
+
+    class M2(M):                                   # a two-argument training_step keeps working with several optimizers
+        def training_step(self, batch, batch_idx):
+            return (self.network[0] - 1.0).pow(2).sum() + (self.network[1] + 2.0).pow(2).sum()
+
+    m2 = M2(nn.ParameterList([nn.Parameter(torch.zeros(3)), nn.Parameter(torch.zeros(3))]))
+    Trainer(max_epochs=1, device="cpu").fit(m2, [(torch.zeros(1), torch.zeros(1))])
+    assert torch.isfinite(m2.network[0]).all()

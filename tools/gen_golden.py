@@ -595,10 +595,88 @@ def gen_datasets(outdir):
     print("datasets", len(out), "arrays")
 
 
+def exact_sines(*xs):
+    """sin(pi x) sin(pi y) [sin(pi z)] for torch tensors (calc_l2_err) and numpy scalars (calc_l2_err_old) alike."""
+    if torch.is_tensor(xs[0]):
+        out = torch.sin(math.pi * xs[0])
+        for x in xs[1:]:
+            out = out * torch.sin(math.pi * x)
+        return out
+    out = np.sin(math.pi * xs[0])
+    for x in xs[1:]:
+        out = out * np.sin(math.pi * x)
+    return out
+
+
+def gen_l2(outdir):
+    """`calc_l2_err` / `calc_l2_err_old` of the reference (DiffNetFEM.py:286-379, 482-591).  They only print, so the
+    numbers are parsed from the captured stdout."""
+    import contextlib
+    import io
+    import re
+    from DiffNet.DiffNetFEM import DiffNet2DFEM, DiffNet3DFEM
+    num = r"(?:tensor\()?([-+0-9.eE]+)"
+
+    def parse(text):
+        a = re.search(r"\|\|u_sol\|\|, \|\|uex\|\| =\s+" + num + r"\)?\s+" + num, text)
+        e = re.search(r"\|\|e\|\|_\{\{L2\}\} =\s+" + num, text)   # the reference prints the doubled braces literally
+        v = re.search(r"\(vector-norm\) =\s+" + num, text)
+        return np.array([float(e.group(1)), float(a.group(1)), float(a.group(2)), float(v.group(1))])
+
+    for tag, nsd, kw in [("2d_n17_g2", 2, dict(domain_size=17)), ("2d_n33_g3", 2, dict(domain_size=33, ngp_1d=3)),
+                         ("2d_q2_n17", 2, dict(domain_size=17, fem_basis_deg=2)), ("3d_n9_g2", 3, dict(domain_size=9, nsd=3))]:
+        m = (DiffNet2DFEM if nsd == 2 else DiffNet3DFEM)(None, **kw)
+        m.exact_solution = exact_sines
+        coords = [m.xx, m.yy] + ([m.zz] if nsd == 3 else [])
+        u_ex = exact_sines(*coords)
+        g = rng(53)
+        u_sol = u_ex + 0.01 * (torch.rand(u_ex.shape, generator=g) - 0.5)
+        out = dict(kwargs=repr(kw), u_sol=T(u_sol), u_exact=T(u_ex))
+        torch.set_printoptions(precision=10)
+        m.u_exact = u_ex.numpy()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            m.calc_l2_err(u_sol[None, None])
+        out["new"] = parse(buf.getvalue())                       # eL2, uL2, u_exL2, vector norm
+        if kw.get("fem_basis_deg", 1) == 1 and kw.get("ngp_1d", 2) == 2:   # the old routine hard-codes Q1 / 2 points / unit square
+            if nsd == 3:
+                m.u_exact = u_ex                                 # the 3-D routine calls .squeeze().detach() on it
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                m.calc_l2_err_old(u_sol.numpy().astype(np.float64))
+            out["old"] = parse(buf.getvalue())
+        torch.set_printoptions(profile="default")
+        np.savez_compressed(os.path.join(outdir, f"l2_{tag}.npz"), **out)
+        print("l2", tag, out["new"], out.get("old"))
+
+
+def gen_networks_large(outdir):
+    """BASELINE configs[1]'s network at its mesh size: U-Net(2 -> 1) on one 512 x 512 sample, eval mode; outputs and
+    gradients are stored on a strided subset (the full tensors would be megabytes of fixture)."""
+    from DiffNet.networks.unets import UNet
+    torch.manual_seed(2024)
+    net = UNet(in_channels=2, out_channels=1).eval()
+    sd = net.state_dict()
+    checksum = np.array([float(sum(v.double().sum() for v in sd.values())), float(sum(v.double().abs().sum() for v in sd.values()))])
+    n = 512
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, n), torch.linspace(0, 1, n), indexing="ij")
+    x = torch.stack([0.5 + 0.4 * torch.sin(7 * xx + 3 * yy), (torch.cos(5 * xx * yy) > 0.3).float()], 0)[None].requires_grad_(True)
+    y = net(x)
+    cot = torch.cos(11 * xx - 4 * yy)[None, None]
+    gx, = torch.autograd.grad(y, x, cot, retain_graph=True)
+    first = list(net.parameters())[0]
+    gw, = torch.autograd.grad(y, first, cot)
+    st = 8
+    np.savez_compressed(os.path.join(outdir, "net_unet_2_1_n512.npz"), n=n, stride=st, y=T(y)[..., ::st, ::st], grad_x=T(gx)[..., ::st, ::st],
+                        grad_w0=T(gw), y_sum=float(y.double().sum()), gx_abs_sum=float(gx.double().abs().sum()),
+                        checksum=checksum, torch_version=torch.__version__)
+    print("net unet 512", float(y.mean()), float(gx.abs().max()))
+
+
 if __name__ == "__main__":
     # default: tables, operators, loss bodies and networks; the other fixture families are selected by flag
     outdir = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
-    extra = {"--fdm": gen_fdm, "--winding": gen_winding, "--datasets": gen_datasets}
+    extra = {"--fdm": gen_fdm, "--winding": gen_winding, "--datasets": gen_datasets, "--l2": gen_l2, "--net512": gen_networks_large}
     chosen = [fn for flag, fn in extra.items() if flag in sys.argv]
     if chosen:
         install_shims()
