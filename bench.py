@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the FEM hot path: fused energy loss + gradient (one pass) on BASELINE.json configs[1]'s mesh.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the driver's form:
+RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or run plainly -- then this process, which has not touched the GPU
+yet, starts that very launcher as a child process and exits with its code.
 
 One "step" = one evaluation of the Poisson energy loss AND its gradient wrt u (forward + backward of the
 reference's loss body IBN_2D.py:116-134 / e2_cib_neumann-style nu field) over one batch of synthetic nodal
@@ -97,11 +101,30 @@ def cpu_baseline(kw, c, budget_s=15.0):
                       f"torch {torch.__version__} CPU, {ncores} threads (os.cpu_count()={os.cpu_count()})"}
 
 
-def slab_main(args, rank, world, dev, dist):
-    """BASELINE configs[3]: one --size^3 Q1 mesh, 2x2x2 points, domain-decomposed over the ranks (strong scaling)."""
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) through torch.distributed.run
+    as a CHILD process.  Nothing in this process has initialised the GPU at this point (argparse + `import torch` only), and
+    the launcher is started as a subprocess, never exec'ed."""
+    import socket
+    import subprocess
+    ngpu = torch.cuda.device_count()                 # does not initialise the device
+    if os.environ.get("DN_DIST_BACKEND", "nccl") == "nccl" and ngpu < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ngpu} GPU(s) visible; the RCCL run needs one GPU per rank "
+                         "(DN_DIST_BACKEND=gloo rehearses the multi-rank logic on fewer GPUs)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def slab_leg(args, rank, world, dev, dist, n, B, ngp, steps, warmup):
+    """BASELINE configs[3]: ONE n^3 Q1 mesh, 2x2x2 points, domain-decomposed into z-slabs over the ranks (strong scaling).
+    Returns the result dict on rank 0 (None elsewhere)."""
     from diffnet_amd.slab import SlabPoisson
-    n, B = args.size, args.batch
-    sp = SlabPoisson(3, (n, n, n), (1.0, 1.0, 1.0), rank, world, ngp_1d=args.ngp, device=dev)
+    sp = SlabPoisson(3, (n, n, n), (1.0, 1.0, 1.0), rank, world, ngp_1d=ngp, device=dev)
     nzl = sp.dec.n1 - sp.dec.n0 + 1
     shape = (B, 1, nzl, n, n)
     g = torch.Generator().manual_seed(42 + rank)
@@ -117,13 +140,13 @@ def slab_main(args, rank, world, dev, dist):
     def step():
         return sp.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     if dist is not None:
         dist.barrier()
@@ -132,15 +155,25 @@ def slab_main(args, rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    if rank != 0:
+        return None
+    units = B * sp.dec.nel_global * ngp ** 3
+    alg = ALG_BYTES_PER_NODE * B * n ** 3
+    return {"metric": "elements*gauss_pts/sec (FEM loss+grad)", "value": units * steps / dt, "unit": "elements*gauss_pts/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "dtype": "f32", "data": "synthetic",
+            "hbm_frac_of_all_gpus": alg / (dt / steps) / 1e9 / (HBM_PEAK_GBS * world),
+            "config": {"workload": f"3-D Poisson energy loss + gradient, Q1, ONE {n}^3 mesh x batch {B}, {ngp}^3 Gauss pts, z-slabs over "
+                                   f"{world} rank(s): 8-byte loss all-reduce + interface-layer exchange per step, overlapped with the slab "
+                                   "kernel (BASELINE.json configs[3])",
+                       "nodes": [n, n, n], "parallelism": f"slab x{world}"}}
+
+
+def slab_main(args, rank, world, dev, dist):
+    out = slab_leg(args, rank, world, dev, dist, args.size, args.batch, args.ngp, args.steps, args.warmup)
     if rank == 0:
-        units = B * sp.dec.nel_global * args.ngp ** 3
-        print(json.dumps({
-            "metric": "elements*gauss_pts/sec (FEM loss+grad)", "value": units * args.steps / dt, "unit": "elements*gauss_pts/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"3-D Poisson energy loss + gradient, Q1, ONE {n}^3 mesh x batch {B}, {args.ngp}^3 Gauss pts, z-slabs over "
-                                   f"{world} rank(s): 8-byte loss all-reduce + interface-layer exchange per step (BASELINE.json configs[3])",
-                       "nodes": [n, n, n], "parallelism": f"slab x{world}"}}), flush=True)
+        out["vs_baseline"] = None
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -158,12 +191,16 @@ def main():
     ap.add_argument("--slab", action="store_true",
                     help="strong-scaling variant (not the default metric run): ONE 3-D mesh of --size^3 nodes cut into z-slabs over "
                          "the ranks (diffnet_amd/slab.py): per step one 8-byte all-reduce + one node-layer exchange per interior face")
+    ap.add_argument("--slab-size", type=int, default=256, help="mesh of the slab leg appended to the default run (0 = skip)")
+    ap.add_argument("--slab-steps", type=int, default=50)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                      # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist, backend = None, None
     if world > 1:
@@ -247,6 +284,7 @@ def main():
     torch.cuda.synchronize()
     kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    kern_med_ms = kern_ms[len(kern_ms) // 2]
     alg_bytes = ALG_BYTES_PER_NODE * B * m.geom.nnode_total
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
 
@@ -259,6 +297,11 @@ def main():
     except Exception:
         pass
 
+    # strong-scaling leg of BASELINE configs[3] in the same run (all ranks take part): one 256^3 mesh cut into z-slabs
+    slab = None
+    if args.slab_size and args.nsd == 2 and args.size == 512:
+        slab = slab_leg(args, rank, world, dev, dist, args.slab_size, 1, 2, args.slab_steps, 10)
+
     if rank == 0:
         value = units_per_step * world * args.steps / dt
         out = {
@@ -269,13 +312,16 @@ def main():
                                    f"{args.ngp}^{args.nsd} Gauss pts, batch {B}/GPU, nu+f nodal fields, u8 Dirichlet mask, "
                                    "fused single pass (BASELINE.json configs[1] mesh)"
                                    + ("; 2-D Q1 element evaluated in closed form: the rule's sums as polynomials of its moments, same value "
-                                      "as the per-point sum (DN_Q1_RULE_KERNEL=1 runs the per-point kernel)" if args.nsd == 2 else ""),
+                                      "as the per-point sum (dn_config_set(\"Q1_RULE_KERNEL\") runs the per-point kernel)" if args.nsd == 2 else ""),
                        "batch_per_gpu": B, "nodes": list(m.geom.node_shape), "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "poisson fused kernel (one launch per dn_poisson_apply)", "kernel_avg_ms": kern_avg_ms,
-                         "kernel_min_ms": kern_ms[0], "algorithmic_bytes": alg_bytes},
+                         "kernel_median_ms": kern_med_ms, "kernel_min_ms": kern_ms[0], "kernel_max_ms": kern_ms[-1],
+                         "frac_at_median": alg_bytes / (kern_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes},
         }
+        if slab is not None:
+            out["slab_3d"] = slab
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, c)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -9,11 +9,13 @@ neighbouring ranks (verified there against the oracle: p
 to the global module's because h is unchanged).
 
 Exchange steps per loss evaluation -- nothing else crosses GPUs:
-  * forward : one all-reduce(sum) of the local energy (8 bytes); the loss is sum / (B * nel_GLOBAL), not a
+  * forward : one all-reduce(sum) of the local energy (8 bytes), asynchronous; the loss is sum / (B * nel_GLOBAL), not a
     mean of per-rank means (slabs may differ by one layer);
   * backward: the gradient on an interface layer is the sum of both neighbours' contributions: one
     point-to-point exchange of a single node layer per interior face (256 KiB at 256^3), added in a fixed
-    order (lower rank's part first) so both replicas are bitwise identical.
+    order (lower rank's part first) so both replicas are bitwise identical.  Each rank's own part comes from a thin
+    launch over the one element layer under the face, so the transfers are in flight (side stream, pre-allocated
+    buffers) while the slab kernel runs.
 """
 import torch
 import torch.distributed as dist
@@ -72,66 +74,157 @@ class SlabDecomposition:
         return m.reshape((1, 1, -1) + (1,) * (self.nsd - 1))
 
 
+class InterfaceExchange:
+    """The backward exchange step: one node layer per interior face, point to point, with pre-allocated send / receive
+    buffers.  `start()` can be called as soon as this rank's partial gradients of its two interface layers exist -- before
+    the interior of the slab has been computed -- and runs the transfers on a side stream (GPU tensors), so they overlap the
+    slab kernel; `finish()` makes the current stream wait for them and writes lower-rank-part + upper-rank-part into the
+    interface layers, in that order on both sides, so the two replicas of a layer are bitwise identical."""
+
+    def __init__(self, dec, group=None):
+        self.dec, self.group = dec, group
+        self.buf, self.dev, self.host = None, None, False
+        self.side = None
+        self.reqs = []
+
+    def _buffers(self, like):
+        if self.buf is None or self.buf[0].shape != like.shape or self.dev != like.device or self.buf[0].dtype != like.dtype:
+            # gloo has no GPU point-to-point: a gloo group on GPU tensors (the one-GPU rehearsal of the N > 1 logic) stages the
+            # layers through host buffers; RCCL ("nccl") moves them GPU to GPU over xGMI
+            self.host = like.is_cuda and dist.get_backend(self.group) == "gloo"
+            self.dev = like.device
+            self.buf = [torch.empty_like(like, device="cpu" if self.host else like.device) for _ in range(4)]   # send_lo, recv_lo, send_hi, recv_hi
+            self.side = torch.cuda.Stream(like.device) if (like.is_cuda and not self.host) else None
+        return self.buf
+
+    def start(self, part_lo, part_hi):
+        """part_lo / part_hi: this rank's contribution to its first / last node layer, shape (B,1,[Ny,]Nx), either may be None
+        on the outermost ranks."""
+        dec = self.dec
+        ref = part_lo if part_lo is not None else part_hi
+        if dec.world == 1 or ref is None:
+            return
+        send_lo, recv_lo, send_hi, recv_hi = self._buffers(ref)
+        ops = []
+        if dec.rank > 0:
+            send_lo.copy_(part_lo)
+            ops += [dist.P2POp(dist.isend, send_lo, dec.rank - 1, self.group), dist.P2POp(dist.irecv, recv_lo, dec.rank - 1, self.group)]
+        if dec.rank + 1 < dec.world:
+            send_hi.copy_(part_hi)
+            ops += [dist.P2POp(dist.isend, send_hi, dec.rank + 1, self.group), dist.P2POp(dist.irecv, recv_hi, dec.rank + 1, self.group)]
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(ref.device))
+            with torch.cuda.stream(self.side):
+                self.reqs = dist.batch_isend_irecv(ops)
+        else:
+            self.reqs = dist.batch_isend_irecv(ops)
+
+    def finish(self, grad_local):
+        """Wait for the transfers and write both interface layers of `grad_local` (B,1,Nslow_local,...) in place."""
+        dec = self.dec
+        if dec.world == 1:
+            return grad_local
+        for req in self.reqs:
+            req.wait()
+        if self.side is not None:
+            torch.cuda.current_stream(grad_local.device).wait_stream(self.side)
+        self.reqs = []
+        send_lo, recv_lo, send_hi, recv_hi = (b.to(grad_local.device) for b in self.buf) if self.host else self.buf
+        if dec.rank > 0:
+            torch.add(recv_lo, send_lo, out=grad_local[:, :, 0])            # lower rank's contribution first
+        if dec.rank + 1 < dec.world:
+            torch.add(send_hi, recv_hi, out=grad_local[:, :, -1])
+        return grad_local
+
+
 def exchange_interfaces(grad_local, dec, group=None):
-    """Sum the two partial gradients of every interface node layer in place (lower rank's part first on both
-    sides => bitwise identical replicas).  One isend/irecv pair per interior face."""
+    """Sum the two partial gradients of every interface node layer in place (one-shot form of `InterfaceExchange`)."""
     if dec.world == 1:
         return grad_local
-    ops, recv_lo, recv_hi = [], None, None
-    lo, hi = dec.rank - 1, dec.rank + 1
-    if lo >= 0:
-        send_lo = grad_local[:, :, 0].contiguous()
-        recv_lo = torch.empty_like(send_lo)
-        ops += [dist.P2POp(dist.isend, send_lo, lo, group), dist.P2POp(dist.irecv, recv_lo, lo, group)]
-    if hi < dec.world:
-        send_hi = grad_local[:, :, -1].contiguous()
-        recv_hi = torch.empty_like(send_hi)
-        ops += [dist.P2POp(dist.isend, send_hi, hi, group), dist.P2POp(dist.irecv, recv_hi, hi, group)]
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    if recv_lo is not None:
-        grad_local[:, :, 0] = recv_lo + grad_local[:, :, 0]        # lower rank's contribution first
-    if recv_hi is not None:
-        grad_local[:, :, -1] = grad_local[:, :, -1] + recv_hi
-    return grad_local
+    ex = InterfaceExchange(dec, group)
+    ex.start(grad_local[:, :, 0] if dec.rank > 0 else None, grad_local[:, :, -1] if dec.rank + 1 < dec.world else None)
+    return ex.finish(grad_local)
 
 
-def slab_energy_loss_and_grad(dec, local_sum_and_grad, batch, group=None):
+def slab_energy_loss_and_grad(dec, local_sum_and_grad, batch, group=None, interface_parts=None, exchange=None):
     """Global energy loss and this rank's slab of its gradient.
 
     `local_sum_and_grad()` must return (energy_sum, grad) of the LOCAL slab where energy_sum is the un-normalised
     sum over local elements (0-dim tensor) and grad = d(energy_sum)/du_local * 1/(B*nel_global).  On the GPU that is
     `ops.poisson_apply(..., out_scale=1/(B*nel_global))` (HIP); the CPU tests inject the oracle.
+
+    `interface_parts()` (optional) returns this rank's partial gradients (part_lo, part_hi) of its first / last node layer,
+    computed from the ONE element layer next to each face -- cheap, and available before the slab kernel has run: the
+    layer exchange is then started first and overlaps the slab computation and the loss all-reduce.  Without it the
+    layers are taken from the finished slab gradient (no overlap).
     """
+    ex = exchange if exchange is not None else InterfaceExchange(dec, group)
+    started = False
+    if dec.world > 1 and interface_parts is not None:
+        ex.start(*interface_parts())
+        started = True
     esum, grad = local_sum_and_grad()
     esum = esum.clone().reshape(1)
     if dec.world > 1:
-        dist.all_reduce(esum, op=dist.ReduceOp.SUM, group=group)
-        exchange_interfaces(grad, dec, group)
+        work = dist.all_reduce(esum, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        if not started:
+            ex.start(grad[:, :, 0] if dec.rank > 0 else None, grad[:, :, -1] if dec.rank + 1 < dec.world else None)
+        ex.finish(grad)
+        work.wait()
     return (esum / (batch * dec.nel_global)).reshape(()), grad
 
 
 class SlabPoisson:
-    """Slab-parallel fused Poisson energy on the GPU: the per-rank FEM module + the two exchange steps."""
+    """Slab-parallel fused Poisson energy on the GPU: the per-rank FEM module + the two exchange steps.  Per evaluation:
+    two thin launches (the element layer under each interior face -> this rank's part of the interface-layer gradient), the
+    layer exchange started on a side stream, the slab kernel on the main stream, the 8-byte loss all-reduce (asynchronous),
+    then one small add per face."""
 
-    def __init__(self, nsd, sizes_xyz, lengths_xyz, rank, world, ngp_1d=2, group=None, device=None):
+    def __init__(self, nsd, sizes_xyz, lengths_xyz, rank, world, ngp_1d=2, group=None, device=None, overlap=True):
         from . import DiffNet2DFEM, DiffNet3DFEM
         self.dec = SlabDecomposition(nsd, sizes_xyz, lengths_xyz, rank, world)
         cls = DiffNet3DFEM if nsd == 3 else DiffNet2DFEM
         self.fem = cls(None, **self.dec.local_kwargs(ngp_1d=ngp_1d))
+        # one element layer: the module that evaluates the face-adjacent layer alone (same h => same tables)
+        slow = nsd - 1
+        h = self.dec.local_lengths[slow] / (self.dec.e1 - self.dec.e0)
+        thin = SlabDecomposition(nsd, sizes_xyz, lengths_xyz, rank, world)
+        thin.local_sizes = self.dec.local_sizes[:slow] + (2,)
+        thin.local_lengths = self.dec.local_lengths[:slow] + (h,)
+        self.fem_thin = cls(None, **thin.local_kwargs(ngp_1d=ngp_1d))
         if device is not None:
-            self.fem = self.fem.to(device)
+            self.fem, self.fem_thin = self.fem.to(device), self.fem_thin.to(device)
         self.group = group
+        self.overlap = overlap and world > 1
+        self.exchange = InterfaceExchange(self.dec, group)
+
+    @staticmethod
+    def _cut(t, sl):
+        return None if t is None else (t[:, :, sl].contiguous() if t.shape[2] > 2 else t)
+
+    def _thin_part(self, sl, keep, u, nu, f, dirichlet, c, jac, scale):
+        from . import ops
+        d = [ops.Dirichlet(self._cut(x.mask, sl), self._cut(x.value, sl) if isinstance(x.value, torch.Tensor) and x.value.dim() == u.dim()
+                           else x.value) for x in ops._norm_dirichlet(dirichlet)]
+        g, _ = ops.poisson_apply(self.fem_thin.geom, self._cut(u, sl), self._cut(nu, sl), self._cut(f, sl), None, d, alpha=2.0 * c, beta=1.0,
+                                 c=c, wscale=jac, out_scale=scale, want_out=True, want_sums=False)
+        return g[:, :, keep]
 
     def energy_loss_and_grad(self, u_local, nu=None, f=None, dirichlet=(), c=1.0, jac=1.0):
         from . import ops
         B = u_local.shape[0]
-        scale = 1.0 / (B * self.dec.nel_global)
+        dec = self.dec
+        scale = 1.0 / (B * dec.nel_global)
 
         def local():
             grad, sums = ops.poisson_apply(self.fem.geom, u_local, nu, f, None, dirichlet, alpha=2.0 * c, beta=1.0, c=c,
                                            wscale=jac, out_scale=scale, want_out=True, want_sums=True)
             return sums[0], grad
 
-        loss, grad = slab_energy_loss_and_grad(self.dec, local, B, self.group)
+        def parts():
+            lo = self._thin_part(slice(0, 2), 0, u_local, nu, f, dirichlet, c, jac, scale) if dec.rank > 0 else None
+            hi = self._thin_part(slice(-2, None), 1, u_local, nu, f, dirichlet, c, jac, scale) if dec.rank + 1 < dec.world else None
+            return lo, hi
+
+        loss, grad = slab_energy_loss_and_grad(dec, local, B, self.group, parts if self.overlap else None, self.exchange)
         return loss.to(torch.float32), grad

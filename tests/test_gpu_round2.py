@@ -342,3 +342,25 @@ def test_config_switches_are_explicit_calls_not_per_launch_getenv():
     assert not torch.equal(g0, g2) and float((g0 - g2).abs().max()) <= 1e-5 * float(g0.abs().max())
     with pytest.raises(_lib.DiffNetHipError):
         _lib.config_set("NO_SUCH_SWITCH", "1")
+
+
+def test_bench_spawns_its_own_ranks_world2_gloo_rehearsal():
+    """`python bench.py --gpus 2` with no launcher: the GPU-free parent starts torch.distributed.run as a child; both bench
+    modes (batch-sharded weak scaling + the z-slab strong-scaling leg with the overlapped layer exchange) run on 2 ranks.
+    On this one-GPU box the ranks share the card and talk over gloo (DN_DIST_BACKEND=gloo); on an 8-GPU node the same code
+    path runs over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DN_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "4",
+                        "--slab-size", "64", "--slab-steps", "3", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                             # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["slab_3d"]["n_gpus"] == 2 and out["slab_3d"]["scaling"] == "strong" and out["slab_3d"]["value"] > 0
+    assert out["roofline"]["kernel_median_ms"] >= out["roofline"]["kernel_min_ms"] > 0

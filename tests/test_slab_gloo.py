@@ -47,8 +47,25 @@ def _worker(rank, world, port, nsd, sizes, lengths, B, out_dir):
             (gl,) = torch.autograd.grad(esum * scale, ul)
             return esum.detach(), gl
 
+        def thin(sl, keep):                       # gradient part of one interface layer from the single element layer under it
+            kw = dec.local_kwargs()
+            sizes_l, lens_l = list(kw["domain_sizes"]), list(kw["domain_lengths"])
+            sizes_l[nsd - 1], lens_l[nsd - 1] = 2, lens_l[nsd - 1] / (dec.e1 - dec.e0)
+            kw.update(domain_sizes=tuple(sizes_l), domain_lengths=tuple(lens_l), domain_size=sizes_l[0], domain_length=lens_l[0])
+            ot = Oracle(**kw)
+            ul = dec.take(u)[:, :, sl].clone().requires_grad_(True)
+            mean = ot.energy(ul, dec.take(nu)[:, :, sl], dec.take(f)[:, :, sl], dirichlet=[(dec.take(bc)[:, :, sl], 0.0)], c=0.5)
+            (gl,) = torch.autograd.grad(mean * (B * int(np.prod(ot.spec.nel))) * scale, ul)
+            return gl[:, :, keep]
+
+        def parts():
+            return (thin(slice(0, 2), 0) if rank > 0 else None, thin(slice(-2, None), 1) if rank + 1 < world else None)
+
         loss, grad = slab_energy_loss_and_grad(dec, local, B)
-        torch.save({"loss": loss, "grad": grad, "n0": dec.n0, "n1": dec.n1, "own": dec.owned_mask(grad)},
+        loss2, grad2 = slab_energy_loss_and_grad(dec, local, B, interface_parts=parts)      # exchange started before the slab compute
+        assert torch.equal(loss, loss2)
+        np.testing.assert_allclose(grad2.numpy(), grad.numpy(), rtol=1e-5, atol=1e-7)
+        torch.save({"loss": loss2, "grad": grad2, "n0": dec.n0, "n1": dec.n1, "own": dec.owned_mask(grad)},
                    os.path.join(out_dir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
