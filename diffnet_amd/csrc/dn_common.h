@@ -17,7 +17,7 @@ namespace dn {
 
 // Tuning switches (dn_config_set / DN_<KEY> at load time, dn_api.hip): value of a switch, nullptr when unset.  A plain table
 // lookup -- nothing on the launch path touches the process environment.
-enum ConfigKey : int { CFG_PLAN2D = 0, CFG_PLAN3D, CFG_PLAN_FSDT, CFG_Q1_RULE_KERNEL, CFG_GPE_GATHER, CFG_COUNT };
+enum ConfigKey : int { CFG_PLAN2D = 0, CFG_PLAN3D, CFG_PLAN_FSDT, CFG_Q1_RULE_KERNEL, CFG_GPE_GATHER, CFG_Q1_3D_V1, CFG_COUNT };
 const char* config(ConfigKey k);
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -50,6 +50,19 @@ struct VecT<2> { using type = float2; };
 template <>
 struct VecT<4> { using type = float4; };
 
+// Typed access at a 32-bit BYTE offset from a wave-uniform base pointer.  Spelling the address as base + zext(u32 bytes)
+// lets the compiler pick `global_load/store ... v_off, s[base:base+1]` (SGPR base + 32-bit VGPR offset); indexing
+// `base[u32_index]` does not, because index * sizeof(T) may exceed 32 bits, and costs a 64-bit VALU add per access.
+// Callers guarantee in-sample byte offsets < 2^32 (dn_poisson_apply rejects samples of >= 2^30 nodes).
+template <typename V, typename T>
+__device__ __forceinline__ V ld_at(const T* __restrict__ base, unsigned index) {
+    return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (index * (unsigned)sizeof(T)));
+}
+template <typename V, typename T>
+__device__ __forceinline__ void st_at(T* __restrict__ base, unsigned index, const V& v) {
+    *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + (index * (unsigned)sizeof(T))) = v;
+}
+
 // Branch-free row-segment load: NW consecutive nodes starting at x0 plus the node x0+NW shared with the next
 // thread, from a per-sample base pointer (wave-uniform => SGPR) and a 32-bit in-sample offset (=> the
 // `global_load saddr + voffset` form, no 64-bit VALU address arithmetic).  Indices are clamped into [0, nx)
@@ -62,27 +75,27 @@ __device__ __forceinline__ void load_seg(const T* __restrict__ base, unsigned ro
         const unsigned xl = (unsigned)min(x0, nx - NW);
         if constexpr (sizeof(T) == 4) {
             using V = typename VecT<NW>::type;
-            const V v = *reinterpret_cast<const V*>(base + (rowoff + xl));
+            const V v = ld_at<V>(base, rowoff + xl);
             const T* vf = reinterpret_cast<const T*>(&v);
 #pragma unroll
             for (int k = 0; k < NW; ++k) dst[k] = vf[k];
         } else {
             static_assert(sizeof(T) == 1, "load_seg: 1- or 4-byte elements");
             if constexpr (NW == 4) {
-                const uint32_t w = *reinterpret_cast<const uint32_t*>(base + (rowoff + xl));
+                const uint32_t w = ld_at<uint32_t>(base, rowoff + xl);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) dst[k] = (T)((w >> (8 * k)) & 0xffu);
             } else {
-                const uint16_t w = *reinterpret_cast<const uint16_t*>(base + (rowoff + xl));
+                const uint16_t w = ld_at<uint16_t>(base, rowoff + xl);
                 dst[0] = (T)(w & 0xffu);
                 dst[1] = (T)(w >> 8);
             }
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < NW; ++k) dst[k] = base[rowoff + (unsigned)min(x0 + k, nx - 1)];
+        for (int k = 0; k < NW; ++k) dst[k] = ld_at<T>(base, rowoff + (unsigned)min(x0 + k, nx - 1));
     }
-    dst[NW] = base[rowoff + (unsigned)min(x0 + NW, nx - 1)];
+    dst[NW] = ld_at<T>(base, rowoff + (unsigned)min(x0 + NW, nx - 1));
 }
 
 // Exactly NW consecutive nodes starting at x0 (clamped like load_seg, no shared +1 node).
@@ -92,24 +105,24 @@ __device__ __forceinline__ void load_own(const T* __restrict__ base, unsigned ro
         const unsigned xl = (unsigned)min(x0, nx - NW);
         if constexpr (sizeof(T) == 4) {
             using V = typename VecT<NW>::type;
-            const V v = *reinterpret_cast<const V*>(base + (rowoff + xl));
+            const V v = ld_at<V>(base, rowoff + xl);
             const T* vf = reinterpret_cast<const T*>(&v);
 #pragma unroll
             for (int k = 0; k < NW; ++k) dst[k] = vf[k];
         } else {
             if constexpr (NW == 4) {
-                const uint32_t w = *reinterpret_cast<const uint32_t*>(base + (rowoff + xl));
+                const uint32_t w = ld_at<uint32_t>(base, rowoff + xl);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) dst[k] = (T)((w >> (8 * k)) & 0xffu);
             } else {
-                const uint16_t w = *reinterpret_cast<const uint16_t*>(base + (rowoff + xl));
+                const uint16_t w = ld_at<uint16_t>(base, rowoff + xl);
                 dst[0] = (T)(w & 0xffu);
                 dst[1] = (T)(w >> 8);
             }
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < NW; ++k) dst[k] = base[rowoff + (unsigned)min(x0 + k, nx - 1)];
+        for (int k = 0; k < NW; ++k) dst[k] = ld_at<T>(base, rowoff + (unsigned)min(x0 + k, nx - 1));
     }
 }
 
@@ -123,12 +136,12 @@ __device__ __forceinline__ void store_seg(float* __restrict__ base, unsigned row
             float* vf = reinterpret_cast<float*>(&v);
 #pragma unroll
             for (int k = 0; k < NW; ++k) vf[k] = src[k];
-            *reinterpret_cast<V*>(base + (rowoff + (unsigned)x0)) = v;
+            st_at<V>(base, rowoff + (unsigned)x0, v);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < NW; ++k)
-            if (x0 + k < nx) base[rowoff + (unsigned)(x0 + k)] = src[k];
+            if (x0 + k < nx) st_at<float>(base, rowoff + (unsigned)(x0 + k), src[k]);
     }
 }
 

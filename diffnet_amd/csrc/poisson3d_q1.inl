@@ -21,6 +21,18 @@ struct PlaneState3D {
     float keep[E];
 };
 
+// pure 1-D weight of Gauss point g (1 at compile time for the unit-weight rule)
+#define T_W(T, g, UW) ((UW) ? 1.f : (T).w[g])
+
+#ifndef DN_Q1W_WAVES_T16
+#define DN_Q1W_WAVES_T16 5        // 16-wide one-element form with the next plane's loads in flight: <= 96 VGPRs
+#endif
+#ifndef DN_Q1W_WAVES_E1
+#define DN_Q1W_WAVES_E1 6         // one element per thread at 2 x 2 x 2 points: <= 80 VGPRs (6 waves per SIMD)
+#endif
+#ifndef DN_Q1W_WAVES
+#define DN_Q1W_WAVES 4            // second-generation kernel: <= 128 VGPRs (4 waves per SIMD)
+#endif
 #ifndef DN_Q1_3D_WAVES
 #define DN_Q1_3D_WAVES 2
 #endif
@@ -341,11 +353,428 @@ __global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, TX * TY, red, &last_flag);
 }
 
+// =============================================================================================================
+// Second-generation kernel (default): same mapping, hand-over and reductions, ~1/3 fewer VALU instructions per element.
+//   * coefficient planes are staged WEIGHTED (w_j w_i nu, w_j w_i f) together with their in-plane sums A[j], B[i], once per
+//     plane; the layer arithmetic (q1_layer_3d_w) works on raw differences and applies 1/h^2, alpha and the user scale
+//     once per element; carried cotangents are folded into the layer's own fused multiply-adds;
+//   * UW (exact 2-point rule, all weights 1): every weight multiplication vanishes at compile time;
+//   * every global access is SGPR base + 32-bit byte offset (ld_at / st_at): no 64-bit VALU address arithmetic.
+// =============================================================================================================
+template <int NGP, int E>
+struct PlaneW {
+    float VU[E][NGP][NGP], VX[E][NGP], VY[E][NGP];
+    float VN[E][NGP][NGP];                            // weighted nu at the in-plane Gauss points
+    float VF[E][NGP][NGP];                            // weighted f
+    float keep[E];
+};
+
+// in-plane stage of u for one element: nodal values r0[e], r0[e+1] (row ey) and r1[e], r1[e+1] (row ey + 1)
+template <int NGP>
+__device__ __forceinline__ void stage_u3(const ElemTab& T, float a0, float a1, float b0, float b1, float (&VU)[NGP][NGP],
+                                         float (&VX)[NGP], float (&VY)[NGP]) {
+    const float dx0 = a1 - a0, dx1 = b1 - b0, ddx = dx1 - dx0;
+#pragma unroll
+    for (int j = 0; j < NGP; ++j) VX[j] = fmaf(T.b[j][1], ddx, dx0);
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) {
+        const float t0 = fmaf(T.b[i][1], dx0, a0);
+        VY[i] = fmaf(T.b[i][1], dx1, b0) - t0;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) VU[j][i] = fmaf(T.b[j][1], VY[i], t0);
+    }
+}
+
+// weighted in-plane stage of a coefficient field: V[j][i] = w_j w_i * c(gp j, i)
+template <int NGP, bool UW>
+__device__ __forceinline__ void stage_w3(const ElemTab& T, float a0, float a1, float b0, float b1, float (&V)[NGP][NGP]) {
+    const float dx0 = a1 - a0, dx1 = b1 - b0;
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) {
+        float t0, t1;
+        if constexpr (UW) {
+            t0 = fmaf(T.b[i][1], dx0, a0);
+            t1 = fmaf(T.b[i][1], dx1, b0);
+        } else {
+            t0 = fmaf(T.wb[i], dx0, T.w[i] * a0);
+            t1 = fmaf(T.wb[i], dx1, T.w[i] * b0);
+        }
+        const float dy = t1 - t0;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) V[j][i] = UW ? fmaf(T.b[j][1], dy, t0) : fmaf(T.wb[j], dy, T.w[j] * t0);
+    }
+}
+
+// T16: one element per thread in tiles exactly 16 threads wide.  A thread row is then a DPP row, so the hand-over to the right
+// neighbour is a `row_shr:1` move (zero fill at the tile's left edge) instead of an LDS slot, the up-right hand-over folds into
+// the up slot, and a thread's two nodes per row come from ONE (4-byte aligned) dwordx2 / ushort load.
+struct __attribute__((packed, aligned(4))) F2U { float a, b; };
+struct __attribute__((packed, aligned(1))) B2U { uint8_t a, b; };
+
+__device__ __forceinline__ float dpp_from_left(float v) {      // lane l <- lane l - 1 inside each row of 16 lanes, 0 for the first lane
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+
+template <int NGP, int E, bool VEC, int FL, bool UW, bool T16>
+__global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP == 2) ? DN_Q1W_WAVES_E1 : DN_Q1W_WAVES)) poisson3d_q1w_kernel(const PoissonParams p, const int chunks_x, const int tiles_y,
+                                                                            const int strips_z) {
+    static_assert(!T16 || E == 1, "T16 is the one-element-per-thread form");
+    constexpr int NW = E;
+    constexpr int G = NGP * NGP * NGP;
+    constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, FGP = (FL & FL3_FGP) != 0;
+    constexpr bool BC_U8C = (FL & FL3_BC_U8C) != 0, BC_ANY = (FL & (FL3_BC | FL3_BC_U8C)) != 0;
+    const int TX = blockDim.x, TY = blockDim.y;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * TX + tx;
+    unsigned lid = blockIdx.x;                    // XCD-aware decode, see poisson3d_q1m_kernel
+    {
+        const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
+        lid = xcd * base + min(xcd, rem) + idx;
+    }
+    const int chunk = (int)(lid % (unsigned)chunks_x);
+    lid /= (unsigned)chunks_x;
+    const int tile = (int)(lid % (unsigned)tiles_y);
+    lid /= (unsigned)tiles_y;
+    const int strip = (int)(lid % (unsigned)strips_z), b = (int)(lid / (unsigned)strips_z);
+    const int q = chunk * (TX - 1) + tx;
+    const int ex0 = q * E, x0 = ex0;
+    const int ey = tile * (TY - 1) + ty;
+    const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);
+    const unsigned npl = (unsigned)(p.nx * p.ny);
+    const int64_t nps = (int64_t)npl * p.nz;
+    const unsigned epl = (unsigned)(p.nelx * p.nely);
+    const unsigned eps = epl * (unsigned)p.nelz;
+    const SampleBases sb = sample_bases(p, b, nps);
+    const float* fgp = FGP ? p.fgp + (p.f_batched ? (int64_t)b * eps * G : 0) : nullptr;
+    const int R = p.rows_per_strip;
+    const int ez_own = strip * R;
+    const int ez_begin = ez_own > 0 ? ez_own - 1 : 0;
+    const int ez_end = min(ez_own + R, p.nelz);
+    const bool row_ok = ey < p.nely;
+    const bool noderow_ok = ey < p.ny;
+    // Elements beyond the mesh (ragged right / upper edge of the last chunk / tile) are computed like any other on clamped,
+    // finite node values and their results multiplied by 0: no per-element branches, no exec-masked regions in the loop.
+    float okf[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) okf[e] = (row_ok && (ex0 + e < p.nelx)) ? 1.f : 0.f;
+
+    __shared__ float xch[2][T16 ? 1 : NW + 2][256];
+    __shared__ double red[256 / 64 + 1];
+    __shared__ int last_flag;
+
+    PlaneW<NGP, E> SA, SB;
+    float cU[E][NGP][NGP], cX[E][NGP], cY[E][NGP];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        SA.keep[e] = SB.keep[e] = 1.f;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) {
+            cX[e][j] = cY[e][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NGP; ++i) {
+                cU[e][j][i] = 0.f;
+                SA.VN[e][j][i] = SB.VN[e][j][i] = T_W(p.T, j, UW) * T_W(p.T, i, UW);    // nu absent: the constant field 1
+                SA.VF[e][j][i] = SB.VF[e][j][i] = 0.f;
+            }
+        }
+    }
+
+    // byte offsets of this thread's two node rows inside a plane; the plane offset is added per plane (one VALU add each)
+    const int y0c = min(ey, p.ny - 1), y1c = min(ey + 1, p.ny - 1);
+    const unsigned row0 = (unsigned)y0c * (unsigned)p.nx, row1 = (unsigned)y1c * (unsigned)p.nx;
+    const unsigned x0c = (unsigned)min(x0, p.nx - 2);         // T16: in-bounds start of the thread's node pair
+    const bool pair_shifted = x0 == p.nx - 1;                  // T16: owner of the last node column (no element of its own)
+
+    // Raw node values of one plane (this thread's two rows), as loaded: `plane_issue` only issues the loads, `plane_consume`
+    // applies the Dirichlet conditions and stages.  PF (T16 form): the loads of plane k + 2 are issued BEFORE the arithmetic of
+    // layer k and consumed after it, so a wave does not sit on its memory latency once per layer (rocprofv3: 64 % of the wave
+    // cycles were s_waitcnt / barrier waits without it); 14 more live VGPRs at one element per thread.
+    // uint8 masks with constant values: both mask slots are always loaded (see plane_issue)
+    const bool has_mask[2] = {sb.mask[0] != nullptr, sb.mask[1] != nullptr};
+    const uint8_t* mask8[2];
+    mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);
+    mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);
+    struct RawPlane {
+        float ru[2][NW + 1], rn[2][NW + 1], rf[2][NW + 1];
+        BcRaw<NW> braw[2];
+        uint8_t m8[2][2][NW + 1];
+    };
+    auto plane_issue = [&](int zreq, RawPlane& W) {
+        const unsigned zoff = (unsigned)min(zreq, p.nz - 1) * npl;
+        const unsigned rowoff[2] = {zoff + row0, zoff + row1};
+        float (&ru)[2][NW + 1] = W.ru;
+        float (&rn)[2][NW + 1] = W.rn;
+        float (&rf)[2][NW + 1] = W.rf;
+        BcRaw<NW> (&braw)[2] = W.braw;
+        uint8_t (&m8)[2][2][NW + 1] = W.m8;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            if constexpr (T16) {
+                // both nodes of the row in one load; threads right of the mesh read the last valid pair (their element is masked)
+                const unsigned o2 = rowoff[jb] + x0c;
+                const F2U a = ld_at<F2U>(sb.u, o2);
+                ru[jb][0] = a.a; ru[jb][1] = a.b;
+                if constexpr (HAS_NU) { const F2U t = ld_at<F2U>(sb.nu, o2); rn[jb][0] = t.a; rn[jb][1] = t.b; }
+                if constexpr (HAS_F) { const F2U t = ld_at<F2U>(sb.f, o2); rf[jb][0] = t.a; rf[jb][1] = t.b; }
+                if constexpr (BC_U8C) {
+                    // unconditional loads (an absent mask reads the other one and is ignored): a load inside a uniform branch makes
+                    // the compiler wait vmcnt(0) at the end of the branch, which serialises every load of the plane behind it
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const B2U t = ld_at<B2U>(mask8[k], o2);
+                        m8[jb][k][0] = t.a; m8[jb][k][1] = t.b;
+                    }
+                } else if constexpr (BC_ANY) {
+                    bc_issue<NW, false>(p, sb, rowoff[jb], (int)x0c, braw[jb]);
+                }
+            } else {
+                load_seg<NW, VEC>(sb.u, rowoff[jb], x0, p.nx, ru[jb]);
+                if constexpr (HAS_NU) load_seg<NW, VEC>(sb.nu, rowoff[jb], x0, p.nx, rn[jb]);
+                if constexpr (HAS_F) load_seg<NW, VEC>(sb.f, rowoff[jb], x0, p.nx, rf[jb]);
+                if constexpr (BC_U8C) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) load_seg<NW, VEC>(mask8[k], rowoff[jb], x0, p.nx, m8[jb][k]);
+                } else if constexpr (BC_ANY) {
+                    bc_issue<NW, VEC>(p, sb, rowoff[jb], x0, braw[jb]);
+                }
+            }
+        }
+    };
+    auto plane_consume = [&](RawPlane& W, PlaneW<NGP, E>& S) {
+        float (&ru)[2][NW + 1] = W.ru;
+        float (&rn)[2][NW + 1] = W.rn;
+        float (&rf)[2][NW + 1] = W.rf;
+        BcRaw<NW> (&braw)[2] = W.braw;
+        uint8_t (&m8)[2][2][NW + 1] = W.m8;
+        float kall[NW + 1];                   // 0 on Dirichlet nodes of row ey (all NW + 1 loaded nodes)
+        if constexpr (BC_U8C) {
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) kall[n] = 1.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float val = p.bc[k].value;
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int n = 0; n <= NW; ++n) {
+                        const bool set = has_mask[k] && m8[jb][k][n] != 0;
+                        ru[jb][n] = set ? val : ru[jb][n];
+                        if (jb == 0) kall[n] = set ? 0.f : kall[n];
+                    }
+            }
+        } else if constexpr (BC_ANY) {
+            float k1[NW + 1];
+            bc_apply_all<NW>(p, sb, braw[0], ru[0], kall);
+            bc_apply_all<NW>(p, sb, braw[1], ru[1], k1);
+        } else {
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) kall[n] = 1.f;
+        }
+        // T16: the thread of the last node column loads the pair (nx-2, nx-1); the node it owns is the second one
+#pragma unroll
+        for (int n = 0; n < NW; ++n) S.keep[n] = (T16 && pair_shifted) ? kall[n + 1] : kall[n];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            stage_u3<NGP>(p.T, ru[0][e], ru[0][e + 1], ru[1][e], ru[1][e + 1], S.VU[e], S.VX[e], S.VY[e]);
+            if constexpr (HAS_NU) stage_w3<NGP, UW>(p.T, rn[0][e], rn[0][e + 1], rn[1][e], rn[1][e + 1], S.VN[e]);
+            if constexpr (HAS_F) stage_w3<NGP, UW>(p.T, rf[0][e], rf[0][e + 1], rf[1][e], rf[1][e + 1], S.VF[e]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    auto plane_stage = [&](int zreq, PlaneW<NGP, E>& S) {
+        RawPlane W;
+        plane_issue(zreq, W);
+        plane_consume(W, S);
+    };
+
+    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
+    int par = 0;
+
+    // adjoint of stage_u3: cotangents of one plane's stage values -> contributions to the element's 2 x 2 nodes
+    auto plane_transpose = [&](int e, const float (&tU)[NGP][NGP], const float (&tX)[NGP], const float (&tY)[NGP], float (&o)[2][NW + 1]) {
+        float s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) {
+            float s = 0.f, t = 0.f;
+#pragma unroll
+            for (int j = 0; j < NGP; ++j) { s += tU[j][i]; t = fmaf(p.T.b[j][1], tU[j][i], t); }
+            const float c1 = t + tY[i], c0 = s - c1;
+            s0 += c0; t0 = fmaf(p.T.b[i][1], c0, t0);
+            s1 += c1; t1 = fmaf(p.T.b[i][1], c1, t1);
+        }
+        float sX = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) { sX += tX[j]; d1 = fmaf(p.T.b[j][1], tX[j], d1); }
+        const float g01 = t0 + (sX - d1), g11 = t1 + d1;
+        o[0][e + 1] = fmaf(okf[e], g01, o[0][e + 1]); o[0][e] = fmaf(okf[e], s0 - g01, o[0][e]);
+        o[1][e + 1] = fmaf(okf[e], g11, o[1][e + 1]); o[1][e] = fmaf(okf[e], s1 - g11, o[1][e]);
+    };
+
+    const unsigned out_row = (unsigned)ey * (unsigned)p.nx;
+    float pend_v = 0.f;                       // T16: output of the last emitted plane, not yet stored
+    unsigned pend_off = 0u;
+    bool pend_st = false;
+    auto flush_store = [&]() {
+        if (pend_st) st_at<float>(sb.out, pend_off, pend_v);
+        pend_st = false;
+    };
+    auto emit_plane = [&](const float (&o)[2][NW + 1], const float (&keep)[NW], int z, bool owned_plane) {
+        if constexpr (T16) {
+            const float left = dpp_from_left(o[0][1]);                  // right-hand contribution of the thread to the left
+            xch[par][0][tid] = o[1][0] + dpp_from_left(o[1][1]);        // up slot with the up-right part of the left thread folded in
+#ifndef DN_ABLATE_BAR3D                    // timing experiment only: results are wrong without the barrier
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+            // the value is stored by flush_store(), AFTER the next plane has been consumed and the one after it requested: a
+            // store issued here would be younger than those loads' consumer wait, which the compiler turns into vmcnt(0)
+            float t = o[0][0] + left;
+            if (ty > 0) t += xch[par][0][tid - 16];
+            t *= keep[0];
+            const bool st = owned_plane && owner && noderow_ok;
+            sq_acc = st ? fmaf(t, t, sq_acc) : sq_acc;
+            pend_v = t * p.out_scale;
+            pend_off = (unsigned)z * npl + out_row + (unsigned)x0;
+            pend_st = st && sb.out != nullptr && x0 < p.nx;
+            par ^= 1;
+            return;
+        }
+        xch[par][0][tid] = o[0][NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) xch[par][(T16 ? 0 : 1 + n)][tid] = o[1][n];
+        xch[par][T16 ? 0 : NW + 1][tid] = o[1][NW];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (owned_plane && owner && noderow_ok) {
+            float v[NW];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                float t = o[0][n];
+                if (ty > 0) t += xch[par][T16 ? 0 : 1 + n][tid - TX];
+                if (n == 0) {
+                    if (tx > 0) t += xch[par][0][tid - 1];
+                    if (tx > 0 && ty > 0) t += xch[par][T16 ? 0 : NW + 1][tid - TX - 1];
+                }
+                t *= keep[n];
+                sq_acc = fmaf(t, t, sq_acc);
+                v[n] = t * p.out_scale;
+            }
+            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)z * npl + out_row, x0, p.nx, v);
+        }
+        par ^= 1;
+    };
+
+    auto layer = [&](int ez, const PlaneW<NGP, E>& L, const PlaneW<NGP, E>& U) {
+        const bool own_layer = ez >= ez_own;
+        const float cnt = (own_layer && owner) ? 1.f : 0.f;
+        float o[2][NW + 1], le1 = 0.f, le2 = 0.f;
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) o[0][n] = o[1][n] = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float fg[G];
+            if constexpr (FGP) {
+                const unsigned eo = (unsigned)ez * epl + (unsigned)min(ey, p.nely - 1) * (unsigned)p.nelx + (unsigned)min(ex0 + e, p.nelx - 1);
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) fg[gi] = ld_at<float>(fgp, eo + (unsigned)gi * eps);
+            }
+            float tU[NGP][NGP], tX[NGP], tY[NGP], e1, e2;
+            q1_layer_3d_w<NGP, FGP, HAS_F, UW>(p.T, L.VU[e], U.VU[e], L.VX[e], U.VX[e], L.VY[e], U.VY[e], L.VN[e], U.VN[e], L.VF[e], U.VF[e],
+                                               fg, cU[e], cX[e], cY[e], tU, tX, tY, e1, e2);
+            // pin the element's energy sums here: left alone, the compiler sinks their fused multiply-adds to the end of the loop
+            // body and keeps every Gauss-point factor alive until then (232 VGPRs instead of ~110)
+            asm volatile("" : "+v"(e1), "+v"(e2));
+            le1 = fmaf(okf[e], e1, le1);
+            le2 = fmaf(okf[e], e2, le2);
+            plane_transpose(e, tU, tX, tY, o);
+            __builtin_amdgcn_sched_barrier(0);      // keep the element streams apart: interleaving them doubles the live set
+        }
+        e1_acc = fmaf(cnt, le1, e1_acc);
+        e2_acc = fmaf(cnt, le2, e2_acc);
+        emit_plane(o, L.keep, ez, own_layer);
+    };
+
+    plane_stage(ez_begin, SA);
+    if constexpr (T16) {
+        // software pipeline: plane k + 2 is in flight while layer k is computed (planes beyond the mesh re-read the last one)
+        RawPlane W;
+        plane_issue(ez_begin + 1, W);
+        int ez = ez_begin;
+#pragma nounroll
+        for (; ez + 1 < ez_end; ez += 2) {
+            plane_consume(W, SB);
+            plane_issue(ez + 2, W);
+            flush_store();
+            layer(ez, SA, SB);
+            plane_consume(W, SA);
+            plane_issue(ez + 3, W);
+            flush_store();
+            layer(ez + 1, SB, SA);
+        }
+        if (ez < ez_end) {
+            plane_consume(W, SB);
+            flush_store();
+            layer(ez, SA, SB);
+            SA = SB;
+        }
+        flush_store();
+    } else {
+        // two layers per trip with the roles of the two plane states swapped: no state copy at the end of a layer
+        int ez = ez_begin;
+#pragma nounroll
+        for (; ez + 1 < ez_end; ez += 2) {
+            plane_stage(ez + 1, SB);
+            layer(ez, SA, SB);
+            plane_stage(ez + 2, SA);
+            layer(ez + 1, SB, SA);
+        }
+        if (ez < ez_end) {
+            plane_stage(ez + 1, SB);
+            layer(ez, SA, SB);
+            SA = SB;
+        }
+    }
+    if (ez_end == p.nelz) {       // the last strip owns the top boundary plane: only the layer below contributes
+        float o[2][NW + 1];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) o[0][n] = o[1][n] = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) plane_transpose(e, cU[e], cX[e], cY[e], o);
+        emit_plane(o, SA.keep, p.nz - 1, true);
+        if constexpr (T16) flush_store();
+    }
+
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, TX * TY, red, &last_flag, (double)p.T.esc);
+}
+
 // ---- dispatch ---------------------------------------------------------------------------------------------
 template <int NGP, int E, bool VEC, int FL>
 static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
     const dim3 grid((unsigned)((long long)g.chunks * g.tiles * g.strips * batch)), block(g.TX, g.TY);
-    hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL, 256>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+    if (config(CFG_Q1_3D_V1) != nullptr) {             // first-generation kernel, kept for A/B runs
+        hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL, 256>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+        return;
+    }
+    bool unit = true;                                   // the exact 2-point rule: all weights 1
+    for (int i = 0; i < NGP; ++i) unit = unit && pp.T.w[i] == 1.0f;
+    if constexpr (E == 1) {
+        if (g.TX == 16 && pp.nx >= 2) {                // 16-wide tiles, one element per thread: DPP hand-over, paired loads
+            if constexpr (NGP == 2) {
+                if (unit) {
+                    hipLaunchKernelGGL((poisson3d_q1w_kernel<NGP, 1, false, FL, true, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((poisson3d_q1w_kernel<NGP, 1, false, FL, false, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+            return;
+        }
+    }
+    if constexpr (NGP == 2) {
+        if (unit) {
+            hipLaunchKernelGGL((poisson3d_q1w_kernel<NGP, E, VEC, FL, true, false>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((poisson3d_q1w_kernel<NGP, E, VEC, FL, false, false>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
 }
 
 template <int NGP, int E, bool VEC>

@@ -115,10 +115,10 @@ __device__ __forceinline__ unsigned load_apply_bc(const PoissonParams& p, const 
 // acquire and reads the partials with sc1 loads.
 #define DN_NSHARD 64
 __device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, float e2, float sq, int tid, int nthreads,
-                                            double* red, int* flag) {
+                                            double* red, int* flag, double escale = 1.0) {
     const int nblocks = gridDim.x * gridDim.y * gridDim.z;
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const double es = block_sum((double)p.T.c * (double)e1 - (double)e2, red, tid, nthreads);
+    const double es = block_sum(escale * ((double)p.T.c * (double)e1 - (double)e2), red, tid, nthreads);
     const double ss = block_sum((double)sq, red, tid, nthreads);
     if (tid == 0) {
         // write-through (sc1) 8-byte stores + drain instead of an agent-scope release fence: a release is a
@@ -189,12 +189,12 @@ __device__ __forceinline__ void bc_issue(const PoissonParams& p, const SampleBas
     }
 }
 
-// u <- where(mask > 0.5, value, u) for both conditions in order; keep[n] = 0 on Dirichlet nodes, 1 elsewhere.
+// u <- where(mask > 0.5, value, u) for both conditions in order; keep[n] = 0 on Dirichlet nodes, 1 elsewhere (all NW + 1 nodes).
 template <int NW>
-__device__ __forceinline__ void bc_apply(const PoissonParams& p, const SampleBases& sb, const BcRaw<NW>& r, float (&u)[NW + 1],
-                                         float (&keep)[NW]) {
+__device__ __forceinline__ void bc_apply_all(const PoissonParams& p, const SampleBases& sb, const BcRaw<NW>& r, float (&u)[NW + 1],
+                                             float (&keep)[NW + 1]) {
 #pragma unroll
-    for (int n = 0; n < NW; ++n) keep[n] = 1.f;
+    for (int n = 0; n <= NW; ++n) keep[n] = 1.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (sb.mask[k] != nullptr) {
@@ -205,12 +205,21 @@ __device__ __forceinline__ void bc_apply(const PoissonParams& p, const SampleBas
             for (int n = 0; n <= NW; ++n) {
                 const bool set = u8 ? (r.m[k][n] != 0u) : (__uint_as_float(r.m[k][n]) > 0.5f);
                 u[n] = set ? (hasf ? r.fv[k][n] : val) : u[n];
-                if (n < NW) keep[n] = set ? 0.f : keep[n];
+                keep[n] = set ? 0.f : keep[n];
             }
         }
     }
 }
 
+// same, keep[] for the NW nodes a thread owns
+template <int NW>
+__device__ __forceinline__ void bc_apply(const PoissonParams& p, const SampleBases& sb, const BcRaw<NW>& r, float (&u)[NW + 1],
+                                         float (&keep)[NW]) {
+    float k[NW + 1];
+    bc_apply_all<NW>(p, sb, r, u, k);
+#pragma unroll
+    for (int n = 0; n < NW; ++n) keep[n] = k[n];
+}
 
 // Dirichlet conditions on exactly N nodes starting at x0 of one row (loads issued first, then selects).
 // u <- where(mask > 0.5, value, u) for both conditions in order; keep[n] = 0 on Dirichlet nodes, 1 elsewhere.

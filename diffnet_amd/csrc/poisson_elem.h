@@ -40,6 +40,14 @@ struct ElemTab {
     float mxs[4];        // m[r] * wscale (the x axis carries the Jacobian / user scale): closed-form 2-D Q1 kernel
     float kx[3][4];
     float q1c[4];        // alpha*hs0^2, alpha*hs1^2, hs0^2, hs1^2  (2-D Q1 layer: derivative scales applied once per element)
+    // 3-D Q1 marching kernel, second form (q1_layer_3d_w): the in-plane weights live in the staged coefficient planes, the
+    // user scale (wscale) in kap[] and in the final energy scale, the 1/h factors are applied once per element.
+    float wb[4];         // w[g] * b[g]           (pure 1-D weights: no wscale)
+    float kap[3];        // alpha * wscale * hs[d]^2   cotangent scale of direction d
+    float hs2[3];        // hs[d]^2                    energy scale of direction d (wscale is applied in finish_sums)
+    float m01, m12;      // m[0] - m[1], m[1] - m[2]
+    float esc;           // wscale: factor of both energy sums of the second-form kernel (1 for the other kernels)
+    float nbw;           // -beta * wscale
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -271,6 +279,106 @@ __device__ __forceinline__ void q1_layer_3d(const ElemTab& T, const float (&LU)[
         cYL[ig] = sy - ty;
     }
     e1 = a1;
+    e2 = a2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3-D Q1, marching form, second version (fewer instructions).  Differences to q1_layer_3d:
+//   * the coefficient planes arrive WEIGHTED: VNw = w_j w_i nu, VFw = w_j w_i f at the in-plane Gauss points (weights applied
+//     once per plane instead of once per layer, plane and term);
+//   * raw differences are used throughout; 1/h^2, alpha and the user scale are applied once per element (T.kap, T.hs2);
+//   * the cotangents of the lower plane are returned already summed with the carried cotangents of the layer below.
+// UW: all weights of the rule are 1 (the exact 2-point rule): weight multiplications vanish at compile time.
+// Outputs: tU/tX/tY = complete cotangents of the LOWER plane's stage values (carry included), cU/cX/cY (in/out) = carried
+// cotangents: in = from the layer below, out = this layer's contribution to the UPPER plane.  e1, e2 without wscale.
+// ---------------------------------------------------------------------------------------------
+template <int NGP, bool FGP, bool HAS_F, bool UW>
+__device__ __forceinline__ void q1_layer_3d_w(const ElemTab& T, const float (&LU)[NGP][NGP], const float (&UU)[NGP][NGP],
+                                              const float (&LX)[NGP], const float (&UX)[NGP], const float (&LY)[NGP],
+                                              const float (&UY)[NGP], const float (&LN)[NGP][NGP], const float (&UN)[NGP][NGP],
+                                              const float (&LF)[NGP][NGP], const float (&UF)[NGP][NGP],
+                                              const float* fg, float (&cU)[NGP][NGP], float (&cX)[NGP], float (&cY)[NGP],
+                                              float (&tU)[NGP][NGP], float (&tX)[NGP], float (&tY)[NGP], float& e1, float& e2) {
+    float a1z = 0.f, a1x = 0.f, a1y = 0.f, a2 = 0.f;
+    const float nb = T.nbw;
+    // row / column sums of the weighted nu planes (x- and y-moments of nu at the y- / x-Gauss points)
+    float LA[NGP], UA[NGP], LB[NGP], UB[NGP];
+#pragma unroll
+    for (int j = 0; j < NGP; ++j) {
+        float la = 0.f, ua = 0.f, lb = 0.f, ub = 0.f;
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) { la += LN[j][i]; ua += UN[j][i]; lb += LN[i][j]; ub += UN[i][j]; }
+        LA[j] = la; UA[j] = ua; LB[j] = lb; UB[j] = ub;
+    }
+#pragma unroll
+    for (int j = 0; j < NGP; ++j) {
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) {
+            const float dzu = UU[j][i] - LU[j][i];
+            const float Qz = fmaf(T.m[1], UN[j][i], T.m01 * LN[j][i]);          // sum_k w_k nu(i,j,k), in-plane weights inside
+            const float qz = Qz * dzu;
+            a1z = fmaf(qz, dzu, a1z);
+            float up = T.kap[2] * qz;                                            // cotangent of UU from the z-derivative term
+            float lo = cU[j][i] - up;
+            if constexpr (FGP) {
+                float cs = 0.f, c1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < NGP; ++k) {
+                    const float wf = T.w[k] * T.w[j] * T.w[i] * fg[(k * NGP + j) * NGP + i];
+                    cs += wf;
+                    c1 = fmaf(T.b[k][1], wf, c1);
+                }
+                a2 = fmaf(cs, LU[j][i], a2);
+                a2 = fmaf(c1, dzu, a2);
+                up = fmaf(nb, c1, up);
+                lo = fmaf(nb, cs - c1, lo);
+            } else if constexpr (HAS_F) {
+                const float cs = fmaf(T.m[1], UF[j][i], T.m01 * LF[j][i]);       // m0 FL + m1 (FU - FL)
+                const float c1 = fmaf(T.m[2], UF[j][i], T.m12 * LF[j][i]);       // m1 FL + m2 (FU - FL)
+                a2 = fmaf(cs, LU[j][i], a2);
+                a2 = fmaf(c1, dzu, a2);
+                up = fmaf(nb, c1, up);
+                lo = fmaf(nb, cs - c1, lo);
+            }
+            tU[j][i] = lo;
+            cU[j][i] = up;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NGP; ++j) {
+        const float dX = UX[j] - LX[j], dA = UA[j] - LA[j];
+        float sx = 0.f, tx = 0.f;
+#pragma unroll
+        for (int k = 0; k < NGP; ++k) {
+            const float ux = fmaf(T.b[k][1], dX, LX[j]);
+            const float Qx = fmaf(T.b[k][1], dA, LA[j]);
+            const float qx = UW ? Qx * ux : (T.w[k] * Qx) * ux;
+            a1x = fmaf(qx, ux, a1x);
+            sx += qx;
+            tx = fmaf(T.b[k][1], qx, tx);
+        }
+        const float up = T.kap[0] * tx;
+        tX[j] = fmaf(T.kap[0], sx, cX[j] - up);
+        cX[j] = up;
+    }
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) {
+        const float dY = UY[i] - LY[i], dB = UB[i] - LB[i];
+        float sy = 0.f, ty = 0.f;
+#pragma unroll
+        for (int k = 0; k < NGP; ++k) {
+            const float uy = fmaf(T.b[k][1], dY, LY[i]);
+            const float Qy = fmaf(T.b[k][1], dB, LB[i]);
+            const float qy = UW ? Qy * uy : (T.w[k] * Qy) * uy;
+            a1y = fmaf(qy, uy, a1y);
+            sy += qy;
+            ty = fmaf(T.b[k][1], qy, ty);
+        }
+        const float up = T.kap[1] * ty;
+        tY[i] = fmaf(T.kap[1], sy, cY[i] - up);
+        cY[i] = up;
+    }
+    e1 = fmaf(T.hs2[2], a1z, fmaf(T.hs2[0], a1x, T.hs2[1] * a1y));
     e2 = a2;
 }
 

@@ -16,6 +16,7 @@
 // HBM traffic is the algorithmic minimum: each nodal field is read once (+ halo re-reads that hit
 // L2), the output is written once.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -198,12 +199,41 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
 static Geom3D plan3d(const dn_mesh* m) {
     Geom3D g;
     const int nx = m->nx, ny = m->ny, nelz = m->nz - 1;
-    const int maxE = m->ngp == 2 ? 2 : 1;              // register budget of the marching kernel: E = 2 only at 2x2x2 points
+    if (m->ngp == 2) {
+        // 2 x 2 x 2 points: one element per thread in tiles 16 threads wide (the T16 form of poisson3d_q1w_kernel: DPP hand-over
+        // along x, paired loads, next plane's loads in flight).  Tile height: the multiple of 4 rows (whole waves) that wastes
+        // the fewest thread rows; strip height: fewest (half-)rounds of resident workgroups x layers per workgroup -- a
+        // workgroup costs its R layers + 1 recomputed seam layer + ~1.5 layers of start-up, and 256 CUs hold 5 workgroups each.
+        g.TX = 16; g.E = 1;
+        g.chunks = chunks_for(nx, 16);
+        double best = -1.0;
+        g.TY = 16;
+        for (int TY = 4; TY <= 16; TY += 4) {
+            const int tiles = chunks_for(ny, TY);
+            const double util = (double)ny / ((double)tiles * TY) + 0.002 * TY;
+            if (util > best) { best = util; g.TY = TY; g.tiles = tiles; }
+        }
+        const double cap = 256.0 * 5.0 * (256.0 / (16.0 * g.TY)) ;          // resident workgroups (waves per SIMD bound)
+        const long long wg_per_strip = (long long)g.chunks * g.tiles * m->batch;
+        double bestc = 1e300;
+        g.R = nelz < 1 ? 1 : nelz;
+        for (int R = 4; R <= 64 && R <= (nelz < 4 ? 4 : nelz); ++R) {
+            const int strips = ceil_div(nelz, R);
+            const double rounds = std::max(1.0, std::ceil(2.0 * (double)(wg_per_strip * strips) / cap) / 2.0);
+            const double layers = (strips == 1 ? nelz : R + 1) + 1.5;
+            const double cost = rounds * layers * (1.0 + 0.002 * R);              // ties: shorter strips (smaller tail)
+            if (cost < bestc) { bestc = cost; g.R = R; }
+        }
+        if (g.R > nelz) g.R = nelz < 1 ? 1 : nelz;
+        g.strips = ceil_div(nelz, g.R);
+        return g;
+    }
+    const int maxE = 1;                                  // larger rules: one element per thread (register budget)
     double best = -1.0;
     g.TX = 16; g.TY = 16; g.E = 1; g.chunks = 1; g.tiles = 1;
-    // Tile shape: the kernel is VALU bound, so what counts is the fraction of thread slots doing useful work -- chunks and
-    // tiles overlap by one thread column / row and the last ones are partly empty.  Any TX is legal (a wave may span rows);
-    // powers of two get a small bonus (measured: equal utilisation runs a few per cent faster with aligned rows).
+    // Tile shape: what counts is the fraction of thread slots doing useful work -- chunks and tiles overlap by one thread
+    // column / row and the last ones are partly empty.  Any TX is legal (a wave may span rows); powers of two get a small
+    // bonus (measured: equal utilisation runs a few per cent faster with aligned rows).
     for (int E = 1; E <= maxE; E *= 2) {
         const int Q = (nx - 1) / E + 1;
         for (int TX = 8; TX <= 128; ++TX) {
@@ -218,8 +248,7 @@ static Geom3D plan3d(const dn_mesh* m) {
         }
     }
     // Strip height: >= 2048 workgroups when the mesh allows it, but never fewer than 8 layers per strip (one layer is
-    // recomputed per strip, and a workgroup's start-up costs about as much as a layer: 128^3 B = 1 runs 8 % faster with
-    // 688 workgroups of 8 layers than with 1376 of 4).
+    // recomputed per strip, and a workgroup's start-up costs about as much as a layer).
     const long long wg_per_strip = (long long)g.chunks * g.tiles * m->batch;
     int R = 32;
     while (R > 8 && wg_per_strip * ceil_div(nelz, R) < 2048) R /= 2;
@@ -393,6 +422,13 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
                 for (int g = 0; g < 4; ++g) pp.T.kx[r][g] = (float)(mm[r] * (double)m->gpw[g] * (double)a->wscale);
         }
     }
+    for (int g = 0; g < 4; ++g) pp.T.wb[g] = m->gpw[g] * m->basis[g][1];
+    for (int d = 0; d < 3; ++d) {
+        pp.T.hs2[d] = pp.T.hs[d] * pp.T.hs[d];
+        pp.T.kap[d] = a->alpha * a->wscale * pp.T.hs2[d];
+    }
+    pp.T.m01 = pp.T.m[0] - pp.T.m[1]; pp.T.m12 = pp.T.m[1] - pp.T.m[2];
+    pp.T.esc = a->wscale; pp.T.nbw = -a->beta * a->wscale;
     pp.T.alpha = a->alpha; pp.T.beta = a->beta; pp.T.c = a->c;
     pp.u = a->u; pp.nu = a->nu; pp.f = a->f; pp.fgp = a->f_gp;
     pp.nu_batched = a->nu_batched; pp.f_batched = a->f_batched;

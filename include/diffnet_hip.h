@@ -35,7 +35,7 @@ extern "C" {
  * is loaded, from the environment variables DN_<KEY>; afterwards the environment is never read again (no getenv on the
  * launch path) and the only way to change a switch is this call.  Keys: "PLAN2D" ("T,E,R"), "PLAN3D" ("TX,TY,E,R"),
  * "PLAN_FSDT" ("T,R"), "Q1_RULE_KERNEL" (non-empty: per-Gauss-point 2-D Q1 kernels instead of the closed form),
- * "GPE_GATHER" (non-empty: per-node gather adjoint of gauss_pt_eval).  value NULL or "" clears the switch.
+ * "GPE_GATHER" (non-empty: per-node gather adjoint of gauss_pt_eval), "Q1_3D_V1" (non-empty: first-generation 3-D Q1 kernel).  value NULL or "" clears the switch.
  * Returns 0, or DN_E_BADARG for an unknown key / over-long value.  Not thread-safe against concurrent launches.
  * No reference counterpart (the reference has no tuning surface). */
 int dn_config_set(const char *key, const char *value);

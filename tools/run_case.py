@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""One fused energy loss + gradient case launched N times (for rocprofv3): python tools/run_case.py nsd n B ngp [PLAN] [reps]"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM, _lib   # noqa: E402
+
+nsd, n, B, ngp = (int(v) for v in sys.argv[1:5])
+plan = sys.argv[5] if len(sys.argv) > 5 else ""
+reps = int(sys.argv[6]) if len(sys.argv) > 6 else 20
+dev = torch.device("cuda:0")
+m = (DiffNet3DFEM if nsd == 3 else DiffNet2DFEM)(None, domain_size=n, nsd=nsd, ngp_1d=ngp).to(dev)
+shape = (B, 1, *m.geom.node_shape)
+g = torch.Generator().manual_seed(1)
+u, nu, f = (torch.rand(shape, generator=g).to(dev) for _ in range(3))
+nu += 0.5
+bc = torch.zeros(shape, dtype=torch.uint8, device=dev)
+for d in range(2, len(shape)):
+    idx = [slice(None)] * len(shape); idx[d] = 0; bc[tuple(idx)] = 1; idx[d] = -1; bc[tuple(idx)] = 1
+if plan:
+    _lib.config_set("PLAN3D" if nsd == 3 else "PLAN2D", plan)
+for _ in range(reps):
+    m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+torch.cuda.synchronize()
+print("done")
