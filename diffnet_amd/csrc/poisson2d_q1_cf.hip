@@ -37,6 +37,10 @@ struct CfRow {
 #define DN_PRIO_ROT 3
 #endif
 
+#ifndef DN_CF_PF
+#define DN_CF_PF 1                // software-pipelined rows (row k + 2 in flight while layer k is computed)
+#endif
+
 template <int E, bool VEC, int FL>
 __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(const PoissonParams p) {
     constexpr int NW = E;
@@ -60,23 +64,28 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     __shared__ double red[8];
     __shared__ int last_flag;
 
+    const bool has_mask[2] = {sb.mask[0] != nullptr, sb.mask[1] != nullptr};
+    const uint8_t* mask8[2];
+    mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);
+    mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);
+
     auto row_issue = [&](int yr, CfRow<E>& r) {
         const unsigned rowoff = (unsigned)min(yr, p.ny - 1) * (unsigned)p.nx;
         load_seg<NW, VEC>(sb.u, rowoff, x0, p.nx, r.u);
         if constexpr (HAS_NU) load_seg<NW, VEC>(sb.nu, rowoff, x0, p.nx, r.n);
         if constexpr (HAS_F) load_seg<NW, VEC>(sb.f, rowoff, x0, p.nx, r.f);
         if constexpr (BC_U8C) {
+            // both mask slots are loaded unconditionally (an absent one re-reads the other and is ignored): a load inside a
+            // wave-uniform branch makes the compiler wait vmcnt(0) where the branch joins, which would drain the pipelined rows
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                if (sb.mask[k] != nullptr) {          // the second condition is optional (wave-uniform)
-                    uint8_t t[NW + 1];
-                    load_seg<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, t);
-                    uint32_t w = 0u;
+                uint8_t t[NW + 1];
+                load_seg<NW, VEC>(mask8[k], rowoff, x0, p.nx, t);
+                uint32_t w = 0u;
 #pragma unroll
-                    for (int n = 0; n < NW; ++n) w |= (uint32_t)t[n] << (8 * n);
-                    r.m8[k][0] = w;
-                    r.m8[k][1] = t[NW];
-                }
+                for (int n = 0; n < NW; ++n) w |= (uint32_t)t[n] << (8 * n);
+                r.m8[k][0] = w;
+                r.m8[k][1] = t[NW];
             }
         } else if constexpr (BC_ANY) {
             bc_issue<NW, VEC>(p, sb, rowoff, x0, r.bc);
@@ -89,14 +98,12 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         if constexpr (BC_U8C) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                if (sb.mask[k] != nullptr) {
-                    const float val = p.bc[k].value;
+                const float val = p.bc[k].value;
 #pragma unroll
-                    for (int n = 0; n <= NW; ++n) {
-                        const bool set = n < NW ? ((r.m8[k][0] >> (8 * n)) & 0xffu) != 0u : r.m8[k][1] != 0u;
-                        r.u[n] = set ? val : r.u[n];
-                        if (n < NW) r.keep[n] = set ? 0.f : r.keep[n];
-                    }
+                for (int n = 0; n <= NW; ++n) {
+                    const bool set = has_mask[k] && (n < NW ? ((r.m8[k][0] >> (8 * n)) & 0xffu) != 0u : r.m8[k][1] != 0u);
+                    r.u[n] = set ? val : r.u[n];
+                    if (n < NW) r.keep[n] = set ? 0.f : r.keep[n];
                 }
             }
         } else if constexpr (BC_ANY) {
@@ -107,21 +114,31 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
     int par = 0;
 
+    // The finished row is stored by flush_store(), after the next row has been consumed and the one after it requested: a store
+    // issued here would be younger than the loads the next consumer waits for, and because it sits in a divergent branch the
+    // compiler turns that wait into vmcnt(0), i.e. into a wait for the store itself.
+    float pend_v[NW];
+    unsigned pend_row = 0u;
+    bool pend_st = false;
+    auto flush_store = [&]() {
+        if (pend_st) store_seg<NW, VEC>(sb.out, pend_row, x0, p.nx, pend_v);
+        pend_st = false;
+    };
     auto emit_row = [&](const float (&o)[NW + 1], const float (&keep)[NW], int yr, bool owned_row) {
         xch[par][tid] = o[NW];
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS-only barrier (loads stay in flight)
         const float left = (tid > 0) ? xch[par][tid - 1] : 0.f;
         par ^= 1;
-        if (owned_row && col_owner) {
-            float v[NW];
+        const bool st = owned_row && col_owner;
 #pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                const float t = (o[n] + (n == 0 ? left : 0.f)) * keep[n];
-                sq_acc = fmaf(t, t, sq_acc);                 // nodes beyond the domain receive no contribution: t == 0
-                v[n] = t * p.out_scale;
-            }
-            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)yr * (unsigned)p.nx, x0, p.nx, v);
+        for (int n = 0; n < NW; ++n) {
+            const float t = (o[n] + (n == 0 ? left : 0.f)) * keep[n];
+            sq_acc = st ? fmaf(t, t, sq_acc) : sq_acc;       // nodes beyond the domain receive no contribution: t == 0
+            pend_v[n] = t * p.out_scale;
         }
+        pend_row = (unsigned)yr * (unsigned)p.nx;
+        pend_st = st && sb.out != nullptr;
+        if (!DN_CF_PF) flush_store();
     };
 
     const float mx0 = p.T.mxs[0], mx1 = p.T.mxs[1], mx2 = p.T.mxs[2], mx3 = p.T.mxs[3];
@@ -133,7 +150,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     auto layer = [&](int ey, const CfRow<E>& L, CfRow<E>& U, const float (&cin)[NW + 1], float (&cout)[NW + 1]) {
         const bool own_layer = ey >= ey_own;
         const float cnt = (own_layer && col_owner) ? 1.f : 0.f;
-        row_bc(U);
+        if (!DN_CF_PF) row_bc(U);
         float o[NW + 1], le1 = 0.f, le2 = 0.f;
 #pragma unroll
         for (int n = 0; n <= NW; ++n) { o[n] = cin[n]; cout[n] = 0.f; }
@@ -197,6 +214,37 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     row_issue(ey_begin, RA);
     row_bc(RA);
     int ey = ey_begin;
+    bool odd = false;
+#if DN_CF_PF
+    {
+        // software pipeline: W holds the raw row k + 2 while layer k runs; consume = Dirichlet select + copy into the row state
+        CfRow<E> W;
+        auto consume = [&](CfRow<E>& r) {
+            r = W;
+            row_bc(r);
+        };
+        row_issue(ey_begin + 1, W);
+        for (; ey + 1 < ey_end; ey += 2) {
+            set_prio(ey);
+            consume(RB);
+            row_issue(ey + 2, W);
+            flush_store();
+            layer(ey, RA, RB, carryA, carryB);
+            consume(RA);
+            row_issue(ey + 3, W);
+            flush_store();
+            layer(ey + 1, RB, RA, carryB, carryA);
+        }
+        if (ey < ey_end) {
+            set_prio(ey);
+            consume(RB);
+            flush_store();
+            layer(ey, RA, RB, carryA, carryB);
+            odd = true;
+        }
+        flush_store();
+    }
+#else
     for (; ey + 1 < ey_end; ey += 2) {
         set_prio(ey);
         row_issue(ey + 1, RB);
@@ -204,13 +252,13 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         row_issue(ey + 2, RA);
         layer(ey + 1, RB, RA, carryB, carryA);
     }
-    bool odd = false;
     if (ey < ey_end) {
         set_prio(ey);
         row_issue(ey + 1, RB);
         layer(ey, RA, RB, carryA, carryB);
         odd = true;
     }
+#endif
     if (ey_end == p.nely) {       // the last strip owns the top boundary row of the domain: only the layer below contributes
         float o[NW + 1], keep[NW];
 #pragma unroll
@@ -218,6 +266,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
 #pragma unroll
         for (int n = 0; n < NW; ++n) keep[n] = odd ? RB.keep[n] : RA.keep[n];
         emit_row(o, keep, p.ny - 1, true);
+        flush_store();
     }
 
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);

@@ -127,6 +127,8 @@ class DiffNetFEM(PDE):
     # -- operator level (DiffNet/DiffNetFEM.py:143-174); the `stride` argument is ignored as in the reference
     def _stacked(self, name, device):
         plist = getattr(self, name)
+        if torch.compiler.is_compiling():      # traced: stack in-graph (the version-keyed cache below is host logic dynamo cannot guard on)
+            return torch.stack([p.detach().reshape(-1) for p in plist], 0).to(device=device, dtype=torch.float32)
         key = (name, str(device))
         ver = tuple(p._version for p in plist) + (plist[0].data_ptr(),)
         hit = self._table_cache.get(key)
@@ -179,8 +181,8 @@ class DiffNetFEM(PDE):
         Equals the loss bodies of IBN_2D.py:116-134 (c=1), solve_in_object_3d.py:75-102 (c=1/2), ..."""
         return ops.energy_loss(self.geom, u, nu, f, f_gp, dirichlet, c, jac)
 
-    def energy_loss_and_grad(self, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0):
-        return ops.energy_loss_and_grad(self.geom, u, nu, f, f_gp, dirichlet, c, jac)
+    def energy_loss_and_grad(self, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0, out=None):
+        return ops.energy_loss_and_grad(self.geom, u, nu, f, f_gp, dirichlet, c, jac, out=out)
 
     def residual(self, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
         """Assembled, Dirichlet-masked weak-form residual (12_klsum.py:80-126, e8_3d_poisson_mms.py:89-136)."""

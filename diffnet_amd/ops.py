@@ -66,38 +66,24 @@ def _gpe_bwd(gout, tables, shape, nsd, nbf, stride):
     return gin
 
 
-class _GaussPtEval(torch.autograd.Function):
-    """Linear in the field: the backward pass is the adjoint kernel wrapped in its own Function (`_GaussPtEvalT`), whose
-    backward is this one again, so the operator differentiates to any order like the reference's conv formulation."""
+class _GaussPtEval:
+    """`gauss_pt_eval` as a registered operator (diffnet_mi::gauss_pt_eval_fwd, diffnet_amd/torch_ops.py): linear in the field,
+    its backward is the adjoint operator `_GaussPtEvalT`, whose backward is this one again -- differentiable to any order like
+    the reference's conv formulation, and an ordinary graph node for torch.compile / torch.export."""
 
     @staticmethod
-    def forward(ctx, x, tables, nsd, nbf, stride):
-        out = _gpe_fwd(x, tables, nsd, nbf, stride)
-        ctx.save_for_backward(tables)
-        ctx.meta = (tuple(x.shape), nsd, nbf, stride)
-        return out
+    def apply(x, tables, nsd, nbf, stride):
+        from . import torch_ops
+        return torch_ops.gauss_pt_eval_fwd(x, tables, nsd, nbf, stride)
+
+
+class _GaussPtEvalT:
+    """Adjoint of `_GaussPtEval` (element / Gauss-point cotangents -> nodal field): diffnet_mi::gauss_pt_eval_bwd."""
 
     @staticmethod
-    def backward(ctx, gout):
-        (tables,) = ctx.saved_tensors
-        shape, nsd, nbf, stride = ctx.meta
-        return _GaussPtEvalT.apply(gout, tables, shape, nsd, nbf, stride), None, None, None, None
-
-
-class _GaussPtEvalT(torch.autograd.Function):
-    """Adjoint of `_GaussPtEval` (element/Gauss-point cotangents -> nodal field)."""
-
-    @staticmethod
-    def forward(ctx, gout, tables, shape, nsd, nbf, stride):
-        ctx.save_for_backward(tables)
-        ctx.meta = (nsd, nbf, stride)
-        return _gpe_bwd(gout, tables, shape, nsd, nbf, stride)
-
-    @staticmethod
-    def backward(ctx, gg):
-        (tables,) = ctx.saved_tensors
-        nsd, nbf, stride = ctx.meta
-        return _GaussPtEval.apply(gg, tables, nsd, nbf, stride), None, None, None, None, None
+    def apply(gout, tables, shape, nsd, nbf, stride):
+        from . import torch_ops
+        return torch_ops.gauss_pt_eval_bwd(gout, tables, list(shape), nsd, nbf, stride)
 
 
 def stack_tables(N, nsd):
@@ -122,57 +108,38 @@ def gauss_pt_eval(tensor, N, nsd=2, stride=1):
     return _GaussPtEval.apply(tensor, tables, nsd, nbf, stride)
 
 
-class _Assemble(torch.autograd.Function):
-    """Element->node scatter-add (gather form).  Linear: its backward (`_AssembleT`, the per-element gather) is a Function
-    whose backward is the assembly again."""
-
-    @staticmethod
-    def forward(ctx, r_split, nsd, nbf, base):
-        r_split = _require(r_split, "R_split", nsd + 2)
-        stride = nbf - 1
-        if r_split.shape[1] != nbf ** nsd:
-            raise ValueError(f"R_split must have {nbf ** nsd} local-basis channels, got {r_split.shape[1]}")
-        node_sp = [n * stride + 1 for n in r_split.shape[2:]]
-        if base is not None:
-            out = _require(base, "Aglobal", nsd + 2).clone()
-            if list(out.shape[2:]) != node_sp or out.shape[0] != r_split.shape[0]:
-                raise ValueError("Aglobal shape does not match R_split")
-        else:
-            out = torch.empty((r_split.shape[0], 1, *node_sp), dtype=torch.float32, device=r_split.device)
-        rc = _lib.lib().dn_assemble(_p(r_split), _p(out), r_split.shape[0], nsd, _sizes_xyz(out, nsd), nbf, stride,
-                                    1 if base is not None else 0, _stream(out))
-        _lib.check(rc, "dn_assemble")
-        ctx.meta = (tuple(r_split.shape), nsd, nbf, base is not None)
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        shape, nsd, nbf, has_base = ctx.meta
-        return _AssembleT.apply(gout, shape, nsd, nbf), None, None, (gout if has_base else None)
+def _assemble_raw(r_split, nsd, nbf, base):
+    r_split = _require(r_split, "R_split", nsd + 2)
+    stride = nbf - 1
+    if r_split.shape[1] != nbf ** nsd:
+        raise ValueError(f"R_split must have {nbf ** nsd} local-basis channels, got {r_split.shape[1]}")
+    node_sp = [n * stride + 1 for n in r_split.shape[2:]]
+    if base is not None:
+        out = _require(base, "Aglobal", nsd + 2).clone()
+        if list(out.shape[2:]) != node_sp or out.shape[0] != r_split.shape[0]:
+            raise ValueError("Aglobal shape does not match R_split")
+    else:
+        out = torch.empty((r_split.shape[0], 1, *node_sp), dtype=torch.float32, device=r_split.device)
+    rc = _lib.lib().dn_assemble(_p(r_split), _p(out), r_split.shape[0], nsd, _sizes_xyz(out, nsd), nbf, stride,
+                                1 if base is not None else 0, _stream(out))
+    _lib.check(rc, "dn_assemble")
+    return out
 
 
-class _AssembleT(torch.autograd.Function):
-    """Adjoint of `_Assemble`: gathers the nodal cotangent to the local nodes of every element."""
-
-    @staticmethod
-    def forward(ctx, gout, shape, nsd, nbf):
-        gout = _require(gout, "grad_output")
-        gs = torch.empty(shape, dtype=torch.float32, device=gout.device)
-        rc = _lib.lib().dn_assemble_bwd(_p(gout), _p(gs), shape[0], nsd, _sizes_xyz(gout, nsd), nbf, nbf - 1, _stream(gout))
-        _lib.check(rc, "dn_assemble_bwd")
-        ctx.meta = (nsd, nbf)
-        return gs
-
-    @staticmethod
-    def backward(ctx, gg):
-        nsd, nbf = ctx.meta
-        return _Assemble.apply(gg, nsd, nbf, None), None, None, None
+def _assemble_bwd_raw(gout, shape, nsd, nbf):
+    gout = _require(gout, "grad_output")
+    gs = torch.empty(shape, dtype=torch.float32, device=gout.device)
+    rc = _lib.lib().dn_assemble_bwd(_p(gout), _p(gs), shape[0], nsd, _sizes_xyz(gout, nsd), nbf, nbf - 1, _stream(gout))
+    _lib.check(rc, "dn_assemble_bwd")
+    return gs
 
 
 def assemble(r_split, nsd, nbf=2, out=None):
     """Element->node assembly (Q1_2D/3D_vector_assembly of the reference scripts, any degree):
-    returns `out + scatter_add(r_split)` (out = zeros when omitted).  Deterministic gather form."""
-    return _Assemble.apply(r_split, nsd, nbf, out)
+    returns `out + scatter_add(r_split)` (out = zeros when omitted).  Deterministic gather form; registered operator
+    diffnet_mi::assemble (linear: its backward is the per-element gather, whose backward is the assembly)."""
+    from . import torch_ops
+    return torch_ops.assemble(r_split, nsd, nbf) if out is None else torch_ops.assemble_onto(r_split, out, nsd, nbf)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -213,7 +180,7 @@ def _workspace(dev, nbytes):
 
 
 def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
-                  out_scale=1.0, want_out=True, want_sums=True, loss_scale=None):
+                  out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None):
     """One launch of dn_poisson_apply.  Returns (out | None, sums | None) where sums is a float64 device
     tensor [energy, sum(out_unscaled^2)].  With `loss_scale` a third value is returned: the 0-dim float32 tensor
     energy * loss_scale written by the same launch.  See include/diffnet_hip.h for the operator definition."""
@@ -281,7 +248,11 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
             bc.value = float(d.value)
     args.alpha, args.beta, args.c, args.wscale, args.out_scale = alpha, beta, c, wscale, out_scale
     mesh = geom.mesh_struct(B)
-    out = torch.empty_like(u) if want_out else None
+    if out is not None:
+        if not want_out or out.shape != u.shape or out.dtype != torch.float32 or out.device != u.device or not out.is_contiguous():
+            raise ValueError("out= must be a contiguous float32 tensor of u's shape on u's device")
+    elif want_out:
+        out = torch.empty_like(u)
     sums = None
     if out is not None:
         args.out = out.data_ptr()
@@ -394,23 +365,12 @@ def composed_residual(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0
     return R
 
 
-class _EnergyLoss(torch.autograd.Function):
-    """Fused energy loss: forward and the gradient wrt u come out of the same single pass."""
-
-    @staticmethod
-    def forward(ctx, u, geom, nu, f, f_gp, dirichlet, c, jac):
-        B = u.shape[0]
-        scale = 1.0 / (B * geom.nelem_total)
-        grad, _, loss = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac,
-                                      out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
-        ctx.save_for_backward(grad)
-        return loss
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, gout):
-        (grad,) = ctx.saved_tensors
-        return grad * gout, None, None, None, None, None, None, None
+def _fused(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, loss_scale):
+    """(out, sums, loss) of one dn_poisson_apply launch as the registered operator diffnet_mi::poisson_apply: differentiable
+    wrt u through all three outputs (torch_ops._pa_backward), an ordinary node for torch.compile."""
+    from . import torch_ops
+    return torch_ops.poisson_apply(u, nu, f, f_gp, *torch_ops.dirichlet_args(dirichlet), *torch_ops.geometry_args(geom),
+                                   float(alpha), float(beta), float(c), float(wscale), float(out_scale), float(loss_scale))
 
 
 def energy_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0):
@@ -419,85 +379,33 @@ def energy_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.
     dirichlet = tuple(_norm_dirichlet(dirichlet))
     if _extra_grad_inputs(nu, f, f_gp, dirichlet):
         return composed_energy(geom, u, nu, f, f_gp, dirichlet, float(c), float(jac))
-    return _EnergyLoss.apply(u, geom, nu, f, f_gp, dirichlet, float(c), float(jac))
+    scale = 1.0 / (u.shape[0] * geom.nelem_total)
+    return _fused(geom, u, nu, f, f_gp, dirichlet, 2.0 * c, 1.0, c, jac, scale, scale)[2]
 
 
-def energy_loss_and_grad(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0):
+def energy_loss_and_grad(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0, out=None):
     """(loss, dloss/du) from ONE kernel pass, outside autograd -- the form an optimiser loop wants and the
-    form bench.py measures (16 algorithmic bytes per node: read u, nu, f; write grad)."""
+    form bench.py measures (16 algorithmic bytes per node: read u, nu, f; write grad).  `out`: optional preallocated
+    gradient buffer (same shape as u)."""
     B = u.shape[0]
     scale = 1.0 / (B * geom.nelem_total)
     grad, _, loss = poisson_apply(geom, u.detach(), nu, f, f_gp, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac,
-                                  out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
+                                  out_scale=scale, want_out=True, want_sums=True, loss_scale=scale, out=out)
     return loss, grad
-
-
-def _homogeneous(dirichlet):
-    return tuple(Dirichlet(d.mask, 0.0) for d in dirichlet)
-
-
-def _saved_masks(dirichlet):
-    return [d.mask for d in dirichlet]
-
-
-class _Residual(torch.autograd.Function):
-    """Assembled weak-form residual R (zero on Dirichlet nodes).  The operator is symmetric in u, so the
-    backward pass is the same kernel applied to the incoming cotangent with f dropped."""
-
-    @staticmethod
-    def forward(ctx, u, geom, nu, f, f_gp, dirichlet, jac):
-        R, _ = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=1.0, beta=1.0, c=0.0, wscale=jac, out_scale=1.0,
-                             want_out=True, want_sums=False)
-        ctx.geom, ctx.jac, ctx.has_nu = geom, jac, nu is not None
-        ctx.save_for_backward(*([nu] if nu is not None else []), *_saved_masks(dirichlet))   # in-place edits are detected
-        return R
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, gR):
-        saved = list(ctx.saved_tensors)
-        nu = saved.pop(0) if ctx.has_nu else None
-        homog = tuple(Dirichlet(m, 0.0) for m in saved)
-        g, _ = poisson_apply(ctx.geom, gR.contiguous(), nu, None, None, homog, alpha=1.0, beta=0.0, c=0.0,
-                             wscale=ctx.jac, out_scale=1.0, want_out=True, want_sums=False)
-        return g, None, None, None, None, None, None
 
 
 def residual(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
     dirichlet = tuple(_norm_dirichlet(dirichlet))
     if _extra_grad_inputs(nu, f, f_gp, dirichlet):
         return composed_residual(geom, u, nu, f, f_gp, dirichlet, float(jac))
-    return _Residual.apply(u, geom, nu, f, f_gp, dirichlet, float(jac))
-
-
-class _ResidualLoss(torch.autograd.Function):
-    """sum(R^2) with R from the fused residual kernel; the sum of squares is reduced in the same launch."""
-
-    @staticmethod
-    def forward(ctx, u, geom, nu, f, f_gp, dirichlet, jac):
-        R, sums = poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=1.0, beta=1.0, c=0.0, wscale=jac, out_scale=1.0,
-                                want_out=True, want_sums=True)
-        ctx.geom, ctx.jac, ctx.has_nu = geom, jac, nu is not None
-        ctx.save_for_backward(R, *([nu] if nu is not None else []), *_saved_masks(dirichlet))
-        return sums[1].to(torch.float32)
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, gout):
-        saved = list(ctx.saved_tensors)
-        R = saved.pop(0)
-        nu = saved.pop(0) if ctx.has_nu else None
-        homog = tuple(Dirichlet(m, 0.0) for m in saved)
-        g, _ = poisson_apply(ctx.geom, R, nu, None, None, homog, alpha=1.0, beta=0.0, c=0.0, wscale=ctx.jac,
-                             out_scale=2.0, want_out=True, want_sums=False)
-        return g * gout, None, None, None, None, None, None
+    return _fused(geom, u, nu, f, f_gp, dirichlet, 1.0, 1.0, 0.0, jac, 1.0, 0.0)[0]
 
 
 def residual_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
     dirichlet = tuple(_norm_dirichlet(dirichlet))
     if _extra_grad_inputs(nu, f, f_gp, dirichlet):
         return torch.sum(composed_residual(geom, u, nu, f, f_gp, dirichlet, float(jac)) ** 2)
-    return _ResidualLoss.apply(u, geom, nu, f, f_gp, dirichlet, float(jac))
+    return _fused(geom, u, nu, f, f_gp, dirichlet, 1.0, 1.0, 0.0, jac, 1.0, 0.0)[1][1].to(torch.float32)
 
 
 _FSDT_WS_BYTES = {}

@@ -254,11 +254,52 @@ def test_operators_differentiate_twice(kw):
     (g,) = torch.autograd.grad(p, ug)
     np.testing.assert_allclose(float(p), float(pref), rtol=2e-5)
     close(g, gref.numpy(), rtol=1e-4, arel=1e-4)
-    # fused losses are single-pass kernels: double backward raises instead of returning constants
-    v = m.energy_loss(ug)
-    (g1,) = torch.autograd.grad(v, ug, create_graph=True)
-    with pytest.raises(RuntimeError):
-        torch.autograd.grad(g1.sum(), ug)
+    # the fused energy loss is a registered operator whose backward is expressed with the same operator: its Hessian-vector
+    # product (second backward) is the stiffness operator again, checked against double backward through the oracle
+    nu = seeded(shape, 10, 0.5)
+    bc = boundary_mask(shape)
+    vdir = seeded(shape, 11)
+    ur = u.clone().requires_grad_(True)
+    (g1r,) = torch.autograd.grad(o.energy(ur, nu, None, dirichlet=[(bc, 0.0)], c=0.5), ur, create_graph=True)
+    (hvr,) = torch.autograd.grad((g1r * vdir).sum(), ur)
+    ug = u.to(dev()).requires_grad_(True)
+    (g1,) = torch.autograd.grad(m.energy_loss(ug, nu.to(dev()), None, dirichlet=[(bc.to(dev()), 0.0)], c=0.5), ug, create_graph=True)
+    (hv,) = torch.autograd.grad((g1 * vdir.to(dev())).sum(), ug)
+    close(hv, hvr.numpy(), rtol=1e-4, arel=1e-4)
+
+
+def test_registered_operators_trace_under_torch_compile():
+    """the operators are registered with torch.library (schema + fake + autograd), so a user loss body built from
+    them is captured as ONE graph by torch.compile (fullgraph=True; backend "aot_eager": tracing + functionalisation + the
+    autograd formula, no code generation) and gives the eager result; torch.library.opcheck validates the registrations."""
+    import diffnet_amd.torch_ops  # noqa: F401
+    m = module(dict(domain_size=33, ngp_1d=3))
+    shape = (2, 1, 33, 33)
+    u, nu, f = (seeded(shape, 21 + i, lo=0.5 if i == 1 else 0.0).to(dev()) for i in range(3))
+    bc = boundary_mask(shape).to(dev())
+    w = m.gpw.to(dev()).reshape(1, -1, 1, 1)
+
+    def body(uu):      # the reference's energy loss body on the drop-in operators + the fused residual loss
+        ub = torch.where(bc > 0.5, torch.zeros_like(uu), uu)
+        dens = w * (0.5 * m.gauss_pt_evaluation(nu) * (m.gauss_pt_evaluation_der_x(ub) ** 2 + m.gauss_pt_evaluation_der_y(ub) ** 2)
+                    - m.gauss_pt_evaluation(ub) * m.gauss_pt_evaluation(f))
+        return torch.mean(torch.sum(dens, 1)) + 1e-3 * m.residual_loss(uu, nu, f, dirichlet=[(bc, 0.0)], jac=0.25) \
+            + m.energy_loss(uu, nu, f, dirichlet=[(bc, 0.0)], c=0.5)
+
+    ue = u.clone().requires_grad_(True)
+    ve = body(ue)
+    (ge,) = torch.autograd.grad(ve, ue)
+    compiled = torch.compile(body, backend="aot_eager", fullgraph=True)
+    uc = u.clone().requires_grad_(True)
+    vc = compiled(uc)
+    (gc,) = torch.autograd.grad(vc, uc)
+    np.testing.assert_allclose(float(vc), float(ve), rtol=1e-6)
+    close(gc, ge.cpu().numpy(), rtol=1e-5, arel=1e-6)
+    tables = m._stacked("dN_x_gp", dev())
+    torch.library.opcheck(torch.ops.diffnet_mi.gauss_pt_eval_fwd.default, (u.clone().requires_grad_(True), tables, 2, 2, 1),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    r = seeded((2, 4, 32, 32), 30).to(dev()).requires_grad_(True)
+    torch.library.opcheck(torch.ops.diffnet_mi.assemble.default, (r, 2, 2), test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
 
 
 def test_fsdt_loss_is_finite_at_the_all_zero_initial_state():

@@ -186,3 +186,29 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     m.degree = 2
     a.u = 1; a.out = 1
     assert L.dn_poisson_apply(C.byref(m), C.byref(a), null) == UNSUPPORTED                     # fused 3-D is Q1 only
+
+
+def test_torch_library_registration_and_fake_shapes():
+    """The hot-path operators are registered in the `diffnet_mi` namespace; their fake implementations propagate
+    shapes on fake GPU tensors without any device, which is what torch.compile / torch.export tracing relies on."""
+    import diffnet_amd.torch_ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from diffnet_amd import DiffNet3DFEM
+    for name in ("gauss_pt_eval_fwd", "gauss_pt_eval_bwd", "assemble", "assemble_bwd", "poisson_apply"):
+        assert hasattr(torch.ops.diffnet_mi, name), name
+    schema = str(torch.ops.diffnet_mi.poisson_apply.default._schema)
+    assert "Tensor? nu" in schema and "-> (Tensor, Tensor, Tensor)" in schema
+    m = DiffNet3DFEM(None, domain_size=9, nsd=3)
+    with FakeTensorMode():
+        u = torch.empty(2, 1, 9, 9, 9, device="cuda")
+        t = torch.empty(8, 8, device="cuda")
+        y = torch.ops.diffnet_mi.gauss_pt_eval_fwd(u, t, 3, 2, 1)
+        assert tuple(y.shape) == (2, 8, 8, 8, 8) and y.device.type == "cuda"
+        back = torch.ops.diffnet_mi.gauss_pt_eval_bwd(y, t, [2, 1, 9, 9, 9], 3, 2, 1)
+        assert tuple(back.shape) == (2, 1, 9, 9, 9)
+        a = torch.ops.diffnet_mi.assemble(y, 3, 2)
+        assert tuple(a.shape) == (2, 1, 9, 9, 9)
+        from diffnet_amd import torch_ops
+        out, sums, loss = torch.ops.diffnet_mi.poisson_apply(u, None, None, None, None, None, 0.0, None, None, 0.0,
+                                                             *torch_ops.geometry_args(m.geom), 1.0, 1.0, 0.5, 1.0, 1.0, 1.0)
+        assert out.shape == u.shape and tuple(sums.shape) == (2,) and sums.dtype == torch.float64 and loss.dim() == 0
