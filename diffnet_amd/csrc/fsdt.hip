@@ -150,7 +150,14 @@ __device__ __forceinline__ void fsdt_elem(const FsdtParams& p, const float (&F)[
 }
 
 // grid = (chunks_x, strips_y, B), block = T threads; one element column per thread.
-template <int P, int NGP>
+// MK: Dirichlet mask kind (0 none, 1 uint8, 2 fp32 compared with 0.5); BCF: some boundary value is a field (then all three
+// slots are loaded, an absent one re-reads its own field and is ignored).  Both are compile-time so that NO load sits inside a
+// wave-uniform branch: the compiler waits vmcnt(0) where such a branch joins, which serialised the three field loads, the
+// mask load and the boundary-field loads of every row (three memory latencies per row instead of one).
+// The P new node rows of layer k + 1 are requested before the arithmetic of layer k (software pipeline: `W`), and the
+// finished rows of layer k are stored after that request (a store issued first would be younger than the loads the next
+// consumer waits for; sitting in a divergent branch it would turn that wait into vmcnt(0)).
+template <int P, int NGP, int MK, bool BCF>
 __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
     constexpr int NB = P + 1;
     constexpr int NW = P;                  // nodes owned per thread per node row
@@ -165,19 +172,22 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
     const int ey_own = strip * R;
     const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;
     const int ey_end = min(ey_own + R, p.nely);
+    const float okf = (ex0 < p.nelx) ? 1.f : 0.f;      // threads right of the mesh compute on clamped data, scaled by 0
 
     const float* fb[3];
     const float* bcf[3];
+    bool has_bcf[3];
     float* ob[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         fb[k] = p.fld[k] + (int64_t)b * nps;
-        bcf[k] = p.bcf[k] ? p.bcf[k] + (p.bcf_batched[k] ? (int64_t)b * nps : 0) : nullptr;
+        has_bcf[k] = p.bcf[k] != nullptr;
+        bcf[k] = has_bcf[k] ? p.bcf[k] + (p.bcf_batched[k] ? (int64_t)b * nps : 0) : fb[k];
         ob[k] = p.out[k] ? p.out[k] + (int64_t)b * nps : nullptr;
     }
     const int64_t mo = p.mask_batched ? (int64_t)b * nps : 0;
-    const uint8_t* m8 = (p.mask && p.mask_is_u8) ? reinterpret_cast<const uint8_t*>(p.mask) + mo : nullptr;
-    const float* mf = (p.mask && !p.mask_is_u8) ? reinterpret_cast<const float*>(p.mask) + mo : nullptr;
+    const uint8_t* m8 = reinterpret_cast<const uint8_t*>(p.mask) + (MK == 1 ? mo : 0);
+    const float* mf = reinterpret_cast<const float*>(p.mask) + (MK == 2 ? mo : 0);
 
     float fscale[3] = {1.f, 1.f, 1.f};
     if (p.in_scale) { fscale[0] = p.in_scale[0]; fscale[1] = p.in_scale[1]; fscale[2] = p.in_scale[2]; }
@@ -197,81 +207,124 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
             for (int n = 0; n <= NW; ++n) acc[k][r][n] = 0.f;
     }
 
-    // load node row yr into slot r; Dirichlet nodes (mask >= 0.5) take the boundary values
-    auto load_row = [&](int r, int yr) {
-        const unsigned rowoff = (unsigned)yr * (unsigned)p.nx;
+    struct RawRow {
+        float v[3][NW + 1], bf[3][NW + 1], mfl[NW + 1];
+        uint8_t mb[NW + 1];
+    };
+    auto row_issue = [&](int yr, RawRow& w) {
+        const unsigned rowoff = (unsigned)min(yr, p.ny - 1) * (unsigned)p.nx;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            load_seg<NW, false>(fb[k], rowoff, x0, p.nx, cu[k][r]);
+        for (int k = 0; k < 3; ++k) load_seg<NW, false>(fb[k], rowoff, x0, p.nx, w.v[k]);
+        if constexpr (MK == 1) load_seg<NW, false>(m8, rowoff, x0, p.nx, w.mb);
+        if constexpr (MK == 2) load_seg<NW, false>(mf, rowoff, x0, p.nx, w.mfl);
+        if constexpr (BCF && MK != 0) {
 #pragma unroll
-            for (int n = 0; n <= NW; ++n) cu[k][r][n] *= fscale[k];
+            for (int k = 0; k < 3; ++k) load_seg<NW, false>(bcf[k], rowoff, x0, p.nx, w.bf[k]);
         }
+    };
+    // landed row -> slot r: input scaling, Dirichlet nodes (mask >= 0.5) take the boundary values
+    auto row_consume = [&](const RawRow& w, int r) {
         unsigned bits = 0u;
-        if (m8) {
-            uint8_t t[NW + 1];
-            load_seg<NW, false>(m8, rowoff, x0, p.nx, t);
+        if constexpr (MK == 1) {
 #pragma unroll
-            for (int n = 0; n <= NW; ++n) bits |= (t[n] != 0) ? (1u << n) : 0u;
-        } else if (mf) {
-            float t[NW + 1];
-            load_seg<NW, false>(mf, rowoff, x0, p.nx, t);
+            for (int n = 0; n <= NW; ++n) bits |= (w.mb[n] != 0) ? (1u << n) : 0u;
+        }
+        if constexpr (MK == 2) {
 #pragma unroll
-            for (int n = 0; n <= NW; ++n) bits |= (t[n] >= 0.5f) ? (1u << n) : 0u;
+            for (int n = 0; n <= NW; ++n) bits |= (w.mfl[n] >= 0.5f) ? (1u << n) : 0u;
         }
         fixed[r] = bits;
-        if (m8 || mf) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (bcf[k]) {
-                    float t[NW + 1];
-                    load_seg<NW, false>(bcf[k], rowoff, x0, p.nx, t);
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int n = 0; n <= NW; ++n) cu[k][r][n] = (bits & (1u << n)) ? t[n] : cu[k][r][n];
-                } else {
-#pragma unroll
-                    for (int n = 0; n <= NW; ++n) cu[k][r][n] = (bits & (1u << n)) ? p.bcv[k] : cu[k][r][n];
+            for (int n = 0; n <= NW; ++n) {
+                float v = w.v[k][n] * fscale[k];
+                if constexpr (MK != 0) {
+                    float bv = p.bcv[k];
+                    if constexpr (BCF) bv = has_bcf[k] ? w.bf[k][n] : bv;
+                    v = (bits & (1u << n)) ? bv : v;
                 }
+                cu[k][r][n] = v;
             }
-        }
     };
 
     float sq[3] = {0.f, 0.f, 0.f};
     int par = 0;
 
-    // Emit node row yr from acc[.][r] (+ the left neighbour's hand-over for n == 0); Dirichlet rows of the residual carry
-    // the boundary values (e1_plate_bending_fsdt.py:222-228), which cu holds at those nodes.
-    auto emit_row = [&](int r, int yr, bool owned_row) {
+    // finished node rows wait here until flush_rows() stores them (see the header)
+    float pend[P][3][NW];
+    unsigned pend_off[P];
+    bool pend_st[P];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xch[par][k][r % P][tid] = acc[k][r][NW];
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier (loads stay in flight)
-        if (owned_row && col_owner) {
+    for (int r = 0; r < P; ++r) pend_st[r] = false;
+    auto flush_rows = [&]() {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float left = (tid > 0) ? xch[par][k][r % P][tid - 1] : 0.f;
-                float o[NW];
+        for (int r = 0; r < P; ++r) {
+            if (pend_st[r]) {
 #pragma unroll
-                for (int n = 0; n < NW; ++n) {
-                    float v = acc[k][r][n] + (n == 0 ? left : 0.f);
-                    v = (fixed[r] & (1u << n)) ? cu[k][r][n] : v;
-                    sq[k] = (x0 + n < p.nx) ? fmaf(v, v, sq[k]) : sq[k];
-                    o[n] = v;
-                }
-                if (ob[k]) store_seg<NW, false>(ob[k], (unsigned)yr * (unsigned)p.nx, x0, p.nx, o);
+                for (int k = 0; k < 3; ++k)
+                    if (ob[k]) store_seg<NW, false>(ob[k], pend_off[r], x0, p.nx, pend[r][k]);
             }
+            pend_st[r] = false;
         }
     };
 
-    load_row(0, ey_begin * P);
+    // Emit node row yr from acc[.][r] (+ the left neighbour's hand-over for n == 0); Dirichlet rows of the residual carry
+    // the boundary values (e1_plate_bending_fsdt.py:222-228), which cu holds at those nodes.
+    auto emit_row = [&](int r, int slot, int yr, bool owned_row) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xch[par][k][r % P][tid] = acc[k][r][NW];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier (loads stay in flight)
+        const bool st = owned_row && col_owner;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float left = (tid > 0) ? xch[par][k][r % P][tid - 1] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                float v = acc[k][r][n] + (n == 0 ? left : 0.f);
+                v = (fixed[r] & (1u << n)) ? cu[k][r][n] : v;
+                sq[k] = (st && x0 + n < p.nx) ? fmaf(v, v, sq[k]) : sq[k];
+                pend[slot][k][n] = v;
+            }
+        }
+        pend_off[slot] = (unsigned)yr * (unsigned)p.nx;
+        pend_st[slot] = st;
+    };
+
+    RawRow W[P];
+    {
+        RawRow w0;
+        row_issue(ey_begin * P, w0);
+        row_consume(w0, 0);
+    }
+#pragma unroll
+    for (int r = 1; r <= P; ++r) row_issue(ey_begin * P + r, W[r - 1]);
     for (int ey = ey_begin; ey < ey_end; ++ey) {
 #pragma unroll
-        for (int r = 1; r <= P; ++r) load_row(r, ey * P + r);
+        for (int r = 1; r <= P; ++r) row_consume(W[r - 1], r);
+#pragma unroll
+        for (int r = 1; r <= P; ++r) row_issue((ey + 1) * P + r, W[r - 1]);      // rows beyond the mesh re-read the last one (unused)
+        flush_rows();
         const bool own_layer = ey >= ey_own;
-        if (ex0 < p.nelx) {
+        {
             static_assert(NW + 1 == NB, "one element per thread: the row state is the element's node block");
-            fsdt_elem<P, NGP>(p, cu, acc);
+            float g[3][NB][NB];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int ib = 0; ib < NB; ++ib) g[k][jb][ib] = 0.f;
+            fsdt_elem<P, NGP>(p, cu, g);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int ib = 0; ib < NB; ++ib) acc[k][jb][ib] = fmaf(okf, g[k][jb][ib], acc[k][jb][ib]);
         }
 #pragma unroll
-        for (int r = 0; r < P; ++r) emit_row(r, ey * P + r, own_layer);
+        for (int r = 0; r < P; ++r) emit_row(r, r, ey * P + r, own_layer);
         par ^= 1;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -284,7 +337,11 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
             }
         fixed[0] = fixed[P];
     }
-    if (ey_end == p.nely) emit_row(0, p.ny - 1, true);
+    flush_rows();
+    if (ey_end == p.nely) {
+        emit_row(0, 0, p.ny - 1, true);
+        flush_rows();
+    }
 
     if (p.want_sums) finish_sums3(p, sq, tid, T, red, &last_flag);
 }
@@ -336,13 +393,26 @@ static int fsdt_validate(const dn_mesh* m) {
     return 0;
 }
 
+template <int P, int NGP>
+static int fsdt_launch_mk(const FsdtParams& pp, const FsdtGeom& g, int batch, hipStream_t s) {
+    dim3 grid(g.chunks, g.strips, batch), block(g.T);
+    const int mk = !pp.mask ? 0 : (pp.mask_is_u8 ? 1 : 2);
+    const bool bcf = mk != 0 && (pp.bcf[0] || pp.bcf[1] || pp.bcf[2]);
+    switch (mk * 2 + (bcf ? 1 : 0)) {
+        case 0: case 1: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 0, false>), grid, block, 0, s, pp); return 0;
+        case 2: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, false>), grid, block, 0, s, pp); return 0;
+        case 3: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, true>), grid, block, 0, s, pp); return 0;
+        case 4: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, false>), grid, block, 0, s, pp); return 0;
+        default: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, true>), grid, block, 0, s, pp); return 0;
+    }
+}
+
 template <int P>
 static int fsdt_launch(const FsdtParams& pp, const FsdtGeom& g, int ngp, int batch, hipStream_t s) {
-    dim3 grid(g.chunks, g.strips, batch), block(g.T);
     switch (ngp) {
-        case 2: hipLaunchKernelGGL((fsdt2d_kernel<P, 2>), grid, block, 0, s, pp); return 0;
-        case 3: hipLaunchKernelGGL((fsdt2d_kernel<P, 3>), grid, block, 0, s, pp); return 0;
-        case 4: hipLaunchKernelGGL((fsdt2d_kernel<P, 4>), grid, block, 0, s, pp); return 0;
+        case 2: return fsdt_launch_mk<P, 2>(pp, g, batch, s);
+        case 3: return fsdt_launch_mk<P, 3>(pp, g, batch, s);
+        case 4: return fsdt_launch_mk<P, 4>(pp, g, batch, s);
         default: return DN_E_UNSUPPORTED;
     }
 }

@@ -38,7 +38,7 @@ struct CfRow {
 #endif
 
 #ifndef DN_CF_PF
-#define DN_CF_PF 1                // software-pipelined rows (row k + 2 in flight while layer k is computed)
+#define DN_CF_PF 0                // 1: software-pipelined rows (row k + 2 in flight while layer k is computed); measured equal (profiles/r2_2d_ab.txt), off: 79 instead of 102 VGPRs
 #endif
 
 template <int E, bool VEC, int FL>
