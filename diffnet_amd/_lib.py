@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdiffnet_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE"}
 
@@ -84,6 +84,10 @@ SYMBOLS = {
     "dn_conv3d_k4s2_wrw_workspace_bytes": (C.c_int64, [C.c_int64] * 6),
     "dn_conv3d_k4s2_wrw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                      C.c_void_p, C.c_int64, C.c_void_p]),
+    "dn_conv2d_k4s2_down": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int64] * 5 + [C.c_void_p]),
+    "dn_conv2d_k4s2_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int64] * 5 + [C.c_void_p]),
+    "dn_conv2d_k4s2_wrw_workspace_bytes": (C.c_int64, [C.c_int64] * 5),
+    "dn_conv2d_k4s2_wrw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int64] * 5 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "dn_instnorm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "dn_instnorm_act_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float,
                                       C.c_void_p, C.c_int64, C.c_void_p]),

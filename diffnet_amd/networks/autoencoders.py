@@ -5,7 +5,7 @@ with transposed convolutions + LeakyReLU, then ReflPad4 -> Conv3x3 -> Conv7x7.  
 activation commented out (:81) and so does this one."""
 from torch import nn
 
-from .fused import InstanceNormAct
+from .fused import Conv2dS2, ConvTranspose2dS2, InstanceNormAct
 
 
 def _widths(dim, i):
@@ -27,7 +27,7 @@ class Encoder(nn.Module):
         downs = []
         for i in range(n_downsample):
             cin, cout = _widths(dim, i)
-            downs += _stage(nn.Conv2d(cin, cout, 4, stride=2, padding=1), cout, 0.0)
+            downs += _stage(Conv2dS2(cin, cout, 4, stride=2, padding=1), cout, 0.0)
         self.model_blocks = nn.Sequential(*stem, *downs, nn.Tanh())
 
     def forward(self, x):
@@ -40,7 +40,7 @@ class Decoder(nn.Module):
         ups, i = [], 0
         for i in reversed(range(n_upsample)):
             cout, cin = _widths(dim, i)                   # mirrored: the decoder walks the widths backwards
-            ups += _stage(nn.ConvTranspose2d(cin, cout, 4, stride=2, padding=1), cout, 0.2)
+            ups += _stage(ConvTranspose2dS2(cin, cout, 4, stride=2, padding=1), cout, 0.2)
         head = [nn.ReflectionPad2d(4), nn.Conv2d(dim * (i + 1) * 2, out_channels, 3), nn.Conv2d(out_channels, out_channels, 7)]
         self.model_blocks = nn.Sequential(*ups, *head)
         self.activation = nn.Sigmoid() if activation == 'sigmoid' else nn.ReLU()   # declared, not applied (as the reference)

@@ -251,3 +251,105 @@ class ConvTranspose3dS2(nn.ConvTranspose3d):
         if output_size is None and _k4s2(self, x, self.in_channels):
             return _ConvT3dK4S2.apply(x, self.weight)
         return super().forward(x, output_size)
+
+
+# ---- 2-D 4 x 4 / stride 2 / padding 1 layers on the fp32 matrix cores (csrc/conv2d_k4s2.hip) ---------------------------------------
+def _c2_down(fine, w):
+    """coarse = w (*)_s2 fine: Conv2d forward with w = weight (cout, cin, 4, 4); ConvTranspose2d input gradient with w = weight (cin, cout, 4, 4)."""
+    fine, w = fine.contiguous(), w.contiguous()
+    B, Cn, H2, W2 = fine.shape
+    M = w.shape[0]
+    out = torch.empty((B, M, H2 // 2, W2 // 2), dtype=torch.float32, device=fine.device)
+    rc = _lib.lib().dn_conv2d_k4s2_down(_p(fine), _p(w), _p(out), B, Cn, M, H2 // 2, W2 // 2, _stream(fine))
+    _lib.check(rc, "dn_conv2d_k4s2_down")
+    return out
+
+
+def _c2_up(coarse, w):
+    """fine = w (*)^T coarse: ConvTranspose2d forward / Conv2d input gradient, same weight layouts as `_c2_down`."""
+    coarse, w = coarse.contiguous(), w.contiguous()
+    B, M, H, W = coarse.shape
+    Cn = w.shape[1]
+    out = torch.empty((B, Cn, 2 * H, 2 * W), dtype=torch.float32, device=coarse.device)
+    rc = _lib.lib().dn_conv2d_k4s2_up(_p(coarse), _p(w), _p(out), B, Cn, M, H, W, _stream(coarse))
+    _lib.check(rc, "dn_conv2d_k4s2_up")
+    return out
+
+
+def _c2_wrw(fine, coarse):
+    """grad_weight (M, C, 4, 4) of both layers."""
+    fine, coarse = fine.contiguous(), coarse.contiguous()
+    B, Cn = fine.shape[:2]
+    M, H, W = coarse.shape[1:]
+    gw = torch.empty((M, Cn, 4, 4), dtype=torch.float32, device=fine.device)
+    nbytes = _lib.lib().dn_conv2d_k4s2_wrw_workspace_bytes(B, Cn, M, H, W)
+    if nbytes < 0:
+        _lib.check(int(nbytes), "dn_conv2d_k4s2_wrw_workspace_bytes")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=fine.device) if nbytes else None
+    rc = _lib.lib().dn_conv2d_k4s2_wrw(_p(fine), _p(coarse), _p(gw), B, Cn, M, H, W, _p(ws), nbytes, _stream(fine))
+    _lib.check(rc, "dn_conv2d_k4s2_wrw")
+    return gw
+
+
+class _Conv2dK4S2(torch.autograd.Function):
+    """Conv2d(4 x 4, stride 2, padding 1, no bias): forward, input gradient and weight gradient are the `down`, `up` and `wrw`
+    contractions of csrc/conv2d_k4s2.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return _c2_down(x, weight)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = _c2_up(gy, weight) if ctx.needs_input_grad[0] else None
+        gw = _c2_wrw(fine=x, coarse=gy) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+class _ConvT2dK4S2(torch.autograd.Function):
+    """ConvTranspose2d(4 x 4, stride 2, padding 1, no bias): forward = `up`, input gradient = `down`, weight gradient = `wrw`."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return _c2_up(x, weight)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = _c2_down(gy, weight) if ctx.needs_input_grad[0] else None
+        gw = _c2_wrw(fine=gy, coarse=x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def _k4s2_2d(m, x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(m.kernel_size) == (4, 4) and tuple(m.stride) == (2, 2)
+            and tuple(m.padding) == (1, 1) and tuple(m.dilation) == (1, 1) and m.groups == 1 and m.padding_mode == "zeros"
+            and tuple(getattr(m, "output_padding", (0, 0))) == (0, 0))
+
+
+class Conv2dS2(nn.Conv2d):
+    """nn.Conv2d that runs 4 x 4 / stride 2 / padding 1 layers on even-sized float32 GPU inputs through the HIP kernels (bias, where
+    the layer has one, is added afterwards); anything else takes torch's path."""
+
+    def forward(self, x):
+        if _k4s2_2d(self, x) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            y = _Conv2dK4S2.apply(x, self.weight)
+            return y if self.bias is None else y + self.bias.view(1, -1, 1, 1)
+        return super().forward(x)
+
+
+class ConvTranspose2dS2(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d counterpart."""
+
+    def forward(self, x, output_size=None):
+        if output_size is None and _k4s2_2d(self, x):
+            y = _ConvT2dK4S2.apply(x, self.weight)
+            return y if self.bias is None else y + self.bias.view(1, -1, 1, 1)
+        return super().forward(x, output_size)

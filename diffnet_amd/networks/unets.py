@@ -5,11 +5,11 @@ Sigmoid.  Input sizes must be multiples of 32 (>= 64: InstanceNorm needs more th
 import torch
 from torch import nn
 
-from .fused import InstanceNormAct, upsample_pad_conv4
+from .fused import Conv2dS2, ConvTranspose2dS2, InstanceNormAct, upsample_pad_conv4
 
 
 def _down(cin, cout, normalize=True, dropout=0.0):
-    layers = [nn.Conv2d(cin, cout, 4, 2, 1, bias=False)]
+    layers = [Conv2dS2(cin, cout, 4, 2, 1, bias=False)]          # HIP: csrc/conv2d_k4s2.hip (fp32 MFMA) on the GPU
     if normalize:                                  # fused InstanceNorm + LeakyReLU (HIP); Identity keeps the reference's indices
         layers += [InstanceNormAct(cout, slope=0.2), nn.Identity()]
     else:
@@ -20,7 +20,7 @@ def _down(cin, cout, normalize=True, dropout=0.0):
 
 
 def _up(cin, cout, dropout=0.0):
-    layers = [nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=False), InstanceNormAct(cout, slope=0.0), nn.Identity()]
+    layers = [ConvTranspose2dS2(cin, cout, 4, 2, 1, bias=False), InstanceNormAct(cout, slope=0.0), nn.Identity()]
     if dropout:
         layers.append(nn.Dropout(dropout))
     return nn.Sequential(*layers)

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 4
+#define DN_ABI_VERSION 5
 
 #define DN_E_BADARG (-1)    /* null pointer / non-positive size / unsupported combination   */
 #define DN_E_UNSUPPORTED (-2) /* (nsd, degree, ngp) outside the compiled instantiations      */
@@ -228,6 +228,23 @@ int dn_instnorm_act_fwd(const float *x, float *y, float *mean, float *rstd, int6
 int dn_instnorm_act_bwd(const float *x, const float *mean, const float *rstd, const float *grad_y, float *grad_x,
                         int64_t n_inst, int64_t spatial, float slope, int64_t channels, int64_t grad_y_batch_stride,
                         void *workspace, int64_t workspace_bytes, void *stream);
+
+/* 4 x 4 / stride 2 / padding 1 convolution family of the 2-D networks (no bias), NCHW fp32, on the fp32 matrix cores.
+ * Replaces the arithmetic of `nn.Conv2d(cin, cout, 4, 2, 1, bias=False)` (UNetDown, DiffNet/networks/unets.py:13-24;
+ * autoencoders.py:29-34) and `nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=False)` (UNetUp, unets.py:27-45; autoencoders.py:39-45)
+ * in all their passes.  `fine` lives on the 2H x 2W grid, `coarse` on the H x W grid, and w[m][c][ky][kx] (m = coarse channel,
+ * c = fine channel) is Conv2d's (cout, cin, 4, 4) weight and ConvTranspose2d's (cin, cout, 4, 4) weight as they stand:
+ *   down: coarse[b,m,i,j] = sum w[m,c,ky,kx] fine[b,c,2i+ky-1,2j+kx-1]      Conv2d forward / ConvTranspose2d input gradient
+ *   up  : fine[b,c,y,x]   = sum w[m,c,ky,kx] coarse[b,m,(y+1-ky)/2,(x+1-kx)/2]  ConvTranspose2d forward / Conv2d input gradient
+ *   wrw : gw[m,c,ky,kx]   = sum coarse[b,m,i,j] fine[b,c,2i+ky-1,2j+kx-1]   weight gradient of both (deterministic two-stage sum)
+ * Shapes: fine (B,C,2H,2W), coarse (B,M,H,W), w / grad_weight (M,C,4,4). */
+int dn_conv2d_k4s2_down(const float *fine, const float *w, float *coarse, int64_t B, int64_t C, int64_t M, int64_t H, int64_t W,
+                        void *stream);
+int dn_conv2d_k4s2_up(const float *coarse, const float *w, float *fine, int64_t B, int64_t C, int64_t M, int64_t H, int64_t W,
+                      void *stream);
+int64_t dn_conv2d_k4s2_wrw_workspace_bytes(int64_t B, int64_t C, int64_t M, int64_t H, int64_t W);
+int dn_conv2d_k4s2_wrw(const float *fine, const float *coarse, float *grad_weight, int64_t B, int64_t C, int64_t M, int64_t H,
+                       int64_t W, void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -256,8 +256,63 @@ def test_unet_at_the_baseline_mesh_512_matches_reference():
     np.testing.assert_allclose(y.detach().cpu().numpy()[..., ::st, ::st], z["y"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(float(y.double().sum()), float(z["y_sum"]), rtol=1e-5)
     gtol = 2e-3
-    # nine conv levels of MIOpen arithmetic (Winograd transforms) and ReLU / LeakyReLU kinks under a binary input channel: 2e-3 of the
-    # gradient's scale pointwise, 1e-3 in the aggregate
-    np.testing.assert_allclose(gx.cpu().numpy()[..., ::st, ::st], z["grad_x"], rtol=gtol, atol=gtol * float(np.abs(z["grad_x"]).max()))
-    np.testing.assert_allclose(gw.cpu().numpy(), z["grad_w0"], rtol=gtol, atol=gtol * 0.1 * float(np.abs(z["grad_w0"]).max()))
+    # every convolution of this network is the repo's own fp32-MFMA kernel now (csrc/conv2d_k4s2.hip, upconv_out.hip).  The input
+    # gradient of nine normalised conv levels at 262 144 pixels is sensitive to summation order (the oneDNN reference is not exact
+    # either) and to ReLU / LeakyReLU kinks (a pre-activation within rounding of zero takes the other branch): median error < 1e-5
+    # of the gradient's scale, 99 % of the samples within 1e-3, all within 2e-2
+    ex = np.abs(gx.cpu().numpy()[..., ::st, ::st] - z["grad_x"]) / float(np.abs(z["grad_x"]).max())
+    assert np.median(ex) <= 1e-5 and np.quantile(ex, 0.99) <= 1e-3 and ex.max() <= 2e-2, (np.median(ex), np.quantile(ex, 0.99), ex.max())
+    ew = np.abs(gw.cpu().numpy() - z["grad_w0"]) / float(np.abs(z["grad_w0"]).max())
+    assert ew.max() <= 5e-4, ew.max()
     np.testing.assert_allclose(float(gx.double().abs().sum()), float(z["gx_abs_sum"]), rtol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,M,H,W", [(2, 2, 32, 16, 16), (1, 32, 64, 8, 8), (2, 5, 3, 3, 5), (1, 64, 128, 4, 4), (3, 130, 70, 5, 3),
+                                       (1, 256, 256, 2, 2), (2, 1, 1, 1, 1), (1, 16, 40, 33, 17)])
+def test_conv2d_k4s2_family_matches_float64_reference(B, C, M, H, W):
+    """dn_conv2d_k4s2_down / _up / _wrw (fp32 MFMA implicit GEMMs) against torch's Conv2d / ConvTranspose2d evaluated in float64 on
+    the CPU: forward, input gradient and weight gradient of both layers, ragged channel / position counts included.  fp32 products
+    with fp32 accumulation: 2e-5 of the result's scale."""
+    import torch.nn.functional as F
+    from diffnet_amd.networks.fused import Conv2dS2, ConvTranspose2dS2
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    fine = torch.randn((B, C, 2 * H, 2 * W), generator=g)
+    coarse = torch.randn((B, M, H, W), generator=g)
+    w = torch.randn((M, C, 4, 4), generator=g) * 0.1
+
+    def check(got, ref, what):
+        scale = float(ref.abs().max()) + 1e-30
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err <= 2e-5 * scale, (what, err, scale)
+
+    # Conv2d: fine -> coarse
+    conv = Conv2dS2(C, M, 4, 2, 1, bias=False).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xg = fine.to(dev).requires_grad_(True)
+    y = conv(xg)
+    gx, gw = torch.autograd.grad(y, (xg, conv.weight), coarse.to(dev))
+    xd, wd = fine.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, 2, 1)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), coarse.double())
+    check(y.detach(), yd.detach(), "conv fwd")
+    check(gx, gxd, "conv dgrad")
+    check(gw, gwd, "conv wgrad")
+    # ConvTranspose2d: coarse -> fine (weight (cin = M, cout = C, 4, 4))
+    convt = ConvTranspose2dS2(M, C, 4, 2, 1, bias=False).to(dev)
+    with torch.no_grad():
+        convt.weight.copy_(w)
+    cg = coarse.to(dev).requires_grad_(True)
+    z = convt(cg)
+    gc, gwt = torch.autograd.grad(z, (cg, convt.weight), fine.to(dev))
+    cd, wtd = coarse.double().requires_grad_(True), w.double().requires_grad_(True)
+    zd = F.conv_transpose2d(cd, wtd, None, 2, 1)
+    gcd, gwtd = torch.autograd.grad(zd, (cd, wtd), fine.double())
+    check(z.detach(), zd.detach(), "convT fwd")
+    check(gc, gcd, "convT dgrad")
+    check(gwt, gwtd, "convT wgrad")
+    # bitwise repeatable (fixed-order partial sums)
+    gw2 = torch.autograd.grad(conv(xg), conv.weight, coarse.to(dev))[0]
+    assert torch.equal(gw, gw2)
