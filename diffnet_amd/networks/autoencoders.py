@@ -5,7 +5,7 @@ with transposed convolutions + LeakyReLU, then ReflPad4 -> Conv3x3 -> Conv7x7.  
 activation commented out (:81) and so does this one."""
 from torch import nn
 
-from .fused import Conv2dS2, ConvTranspose2dS2, InstanceNormAct
+from .fused import Conv2dS2, Conv2dValid, ConvTranspose2dS2, InstanceNormAct
 
 
 def _widths(dim, i):
@@ -23,7 +23,7 @@ class Encoder(nn.Module):
         super().__init__()
         # the reference declares the first InstanceNorm with `dim` features after a 2*dim-channel conv: harmless
         # (affine=False); the number is kept for the repr only
-        stem = [nn.ReflectionPad2d(3)] + _stage(nn.Conv2d(in_channels, dim * 2, 7), dim, 0.2)
+        stem = [nn.ReflectionPad2d(3)] + _stage(Conv2dValid(in_channels, dim * 2, 7), dim, 0.2)
         downs = []
         for i in range(n_downsample):
             cin, cout = _widths(dim, i)
@@ -41,7 +41,7 @@ class Decoder(nn.Module):
         for i in reversed(range(n_upsample)):
             cout, cin = _widths(dim, i)                   # mirrored: the decoder walks the widths backwards
             ups += _stage(ConvTranspose2dS2(cin, cout, 4, stride=2, padding=1), cout, 0.2)
-        head = [nn.ReflectionPad2d(4), nn.Conv2d(dim * (i + 1) * 2, out_channels, 3), nn.Conv2d(out_channels, out_channels, 7)]
+        head = [nn.ReflectionPad2d(4), Conv2dValid(dim * (i + 1) * 2, out_channels, 3), Conv2dValid(out_channels, out_channels, 7)]
         self.model_blocks = nn.Sequential(*ups, *head)
         self.activation = nn.Sigmoid() if activation == 'sigmoid' else nn.ReLU()   # declared, not applied (as the reference)
 

@@ -1,6 +1,9 @@
-"""Fused InstanceNorm + activation module backed by the HIP kernels `dn_instnorm_act_fwd/bwd` on the GPU
-(one pass pair instead of torch's normalisation + activation kernels); on CPU tensors it evaluates the same formula
-with torch ops (the networks are plumbing around the convolutions, which stay MIOpen / oneDNN in this round)."""
+"""Network building blocks on the HIP kernels of libdiffnet_hip.so: every convolution of the three
+reference networks -- Conv2d / ConvTranspose2d 4x4 s2 (csrc/conv2d_k4s2.hip), Conv3d / ConvTranspose3d 4^3 s2 (conv3d_k4s2.hip,
+conv3d_wrw.hip), the stride-1 stem / head convolutions of the auto-encoder (conv2d_direct.hip), the fused Upsample -> Conv -> Sigmoid
+output blocks (upconv_out.hip, upconv3d_out.hip) -- forward, input gradient and weight gradient, plus InstanceNorm + activation
+(instnorm_act.hip).  The modules subclass torch's (same parameters, initialisation and state_dict keys); on CPU tensors they fall
+through to torch's implementation (parity tests against the reference's golden vectors run there too)."""
 import torch
 from torch.autograd.function import once_differentiable
 from torch import nn
@@ -183,16 +186,38 @@ def _wrw3d(fine, coarse):
     return gw
 
 
-_S2, _P1, _D1, _OP0 = [2, 2, 2], [1, 1, 1], [1, 1, 1], [0, 0, 0]
+def _c3_down(fine, w):
+    """coarse = w (*)_s2 fine (dn_conv3d_k4s2_down): Conv3d forward / ConvTranspose3d input gradient."""
+    fine, w = fine.contiguous(), w.contiguous()
+    B, Cn = fine.shape[:2]
+    d, h, wd = (s_ // 2 for s_ in fine.shape[2:])
+    M = w.shape[0]
+    out = torch.empty((B, M, d, h, wd), dtype=torch.float32, device=fine.device)
+    rc = _lib.lib().dn_conv3d_k4s2_down(_p(fine), _p(w), _p(out), B, Cn, M, d, h, wd, _stream(fine))
+    _lib.check(rc, "dn_conv3d_k4s2_down")
+    return out
+
+
+def _c3_up(coarse, w):
+    """fine = w (*)^T coarse (dn_conv3d_k4s2_up): ConvTranspose3d forward / Conv3d input gradient."""
+    coarse, w = coarse.contiguous(), w.contiguous()
+    B, M, d, h, wd = coarse.shape
+    Cn = w.shape[1]
+    out = torch.empty((B, Cn, 2 * d, 2 * h, 2 * wd), dtype=torch.float32, device=coarse.device)
+    rc = _lib.lib().dn_conv3d_k4s2_up(_p(coarse), _p(w), _p(out), B, Cn, M, d, h, wd, _stream(coarse))
+    _lib.check(rc, "dn_conv3d_k4s2_up")
+    return out
+
 
 
 class _Conv3dK4S2(torch.autograd.Function):
-    """Conv3d(4^3, stride 2, padding 1, no bias): MIOpen forward / input gradient, HIP weight gradient."""
+    """Conv3d(4^3, stride 2, padding 1, no bias): forward = `down`, input gradient = `up` (csrc/conv3d_k4s2.hip), weight gradient =
+    dn_conv3d_k4s2_wrw -- all three on the fp32 matrix cores."""
 
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
-        return F.conv3d(x, weight, None, 2, 1)
+        return _c3_down(x, weight)
 
     @staticmethod
     @once_differentiable
@@ -201,19 +226,19 @@ class _Conv3dK4S2(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, weight, None, _S2, _P1, _D1, False, _OP0, 1, [True, False, False])[0]
+            gx = _c3_up(gy, weight)
         if ctx.needs_input_grad[1]:
             gw = _wrw3d(fine=x, coarse=gy)
         return gx, gw
 
 
 class _ConvT3dK4S2(torch.autograd.Function):
-    """ConvTranspose3d(4^3, stride 2, padding 1, no bias): MIOpen forward / input gradient, HIP weight gradient."""
+    """ConvTranspose3d(4^3, stride 2, padding 1, no bias): forward = `up`, input gradient = `down`, weight gradient = wrw."""
 
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
-        return F.conv_transpose3d(x, weight, None, 2, 1)
+        return _c3_up(x, weight)
 
     @staticmethod
     @once_differentiable
@@ -222,7 +247,7 @@ class _ConvT3dK4S2(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, weight, None, _S2, _P1, _D1, True, _OP0, 1, [True, False, False])[0]
+            gx = _c3_down(gy, weight)
         if ctx.needs_input_grad[1]:
             gw = _wrw3d(fine=gy, coarse=x)
         return gx, gw
@@ -353,3 +378,49 @@ class ConvTranspose2dS2(nn.ConvTranspose2d):
             y = _ConvT2dK4S2.apply(x, self.weight)
             return y if self.bias is None else y + self.bias.view(1, -1, 1, 1)
         return super().forward(x, output_size)
+
+
+# ---- stride-1 "valid" k x k convolutions with bias (AE stem / head), csrc/conv2d_direct.hip ----------------------------------------
+class _Conv2dValid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight = x.contiguous(), weight.contiguous()
+        B, Ci, H, W = x.shape
+        Co, K = weight.shape[0], weight.shape[-1]
+        y = torch.empty((B, Co, H - K + 1, W - K + 1), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().dn_conv2d_valid_fwd(_p(x), _p(weight), _p(bias), _p(y), B, Ci, Co, H, W, K, _stream(x))
+        _lib.check(rc, "dn_conv2d_valid_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, Ci, H, W = x.shape
+        Co, K = weight.shape[0], weight.shape[-1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            rc = _lib.lib().dn_conv2d_valid_bwd_data(_p(gy), _p(weight), _p(gx), B, Ci, Co, H, W, K, _stream(x))
+            _lib.check(rc, "dn_conv2d_valid_bwd_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(weight)
+            gb = torch.empty(Co, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            rc = _lib.lib().dn_conv2d_valid_bwd_weight(_p(x), _p(gy), _p(gw), _p(gb), B, Ci, Co, H, W, K, _stream(x))
+            _lib.check(rc, "dn_conv2d_valid_bwd_weight")
+        return gx, gw, gb
+
+
+class Conv2dValid(nn.Conv2d):
+    """nn.Conv2d for square kernels up to 7 x 7, stride 1, no padding (the layer sits behind an explicit padding module): HIP kernels on
+    float32 GPU tensors, torch's path otherwise."""
+
+    def forward(self, x):
+        k = self.kernel_size
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and k[0] == k[1] and k[0] <= 7 and tuple(self.stride) == (1, 1)
+                and tuple(self.padding) == (0, 0) and tuple(self.dilation) == (1, 1) and self.groups == 1):
+            return _Conv2dValid.apply(x, self.weight, self.bias)
+        return super().forward(x)

@@ -246,6 +246,25 @@ int64_t dn_conv2d_k4s2_wrw_workspace_bytes(int64_t B, int64_t C, int64_t M, int6
 int dn_conv2d_k4s2_wrw(const float *fine, const float *coarse, float *grad_weight, int64_t B, int64_t C, int64_t M, int64_t H,
                        int64_t W, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* 4 x 4 x 4 / stride 2 / padding 1 convolution family of the 3-D generator (no bias), NCDHW fp32, fp32 matrix cores: the `down`
+ * and `up` contractions of `nn.Conv3d(cin, cout, 4, 2, 1, bias=False)` / `nn.ConvTranspose3d(cin, cout, 4, 2, 1, bias=False)`
+ * (DiffNet/networks/wgan3d.py:23-55), same conventions as dn_conv2d_k4s2_*: fine (B,C,2D,2H,2W), coarse (B,M,D,H,W), w (M,C,4,4,4).
+ * The weight gradient of both layers is dn_conv3d_k4s2_wrw. */
+int dn_conv3d_k4s2_down(const float *fine, const float *w, float *coarse, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
+                        int64_t W, void *stream);
+int dn_conv3d_k4s2_up(const float *coarse, const float *w, float *fine, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
+                      int64_t W, void *stream);
+
+/* Stride-1 "valid" k x k convolutions (k <= 7) with optional bias: the auto-encoder's stem / head layers behind an explicit
+ * ReflectionPad2d (DiffNet/networks/autoencoders.py:13 `nn.Conv2d(in_channels, dim*2, 7)`, :75 `nn.Conv2d(.., out_channels, 3)`,
+ * `nn.Conv2d(out_channels, out_channels, 7)`).  x (B,Ci,H,W), w (Co,Ci,K,K), y / gy (B,Co,H-K+1,W-K+1); gbias may be NULL. */
+int dn_conv2d_valid_fwd(const float *x, const float *w, const float *bias, float *y, int64_t B, int64_t Ci, int64_t Co, int64_t H, int64_t W,
+                        int64_t K, void *stream);
+int dn_conv2d_valid_bwd_data(const float *gy, const float *w, float *gx, int64_t B, int64_t Ci, int64_t Co, int64_t H, int64_t W, int64_t K,
+                             void *stream);
+int dn_conv2d_valid_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int64_t B, int64_t Ci, int64_t Co, int64_t H, int64_t W,
+                               int64_t K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,3 +316,76 @@ def test_conv2d_k4s2_family_matches_float64_reference(B, C, M, H, W):
     # bitwise repeatable (fixed-order partial sums)
     gw2 = torch.autograd.grad(conv(xg), conv.weight, coarse.to(dev))[0]
     assert torch.equal(gw, gw2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,M,D,H,W", [(1, 1, 16, 8, 8, 8), (2, 16, 32, 4, 4, 4), (1, 5, 3, 3, 2, 5), (1, 64, 128, 2, 2, 2), (2, 33, 70, 2, 3, 2),
+                                         (1, 128, 128, 1, 1, 1)])
+def test_conv3d_k4s2_family_matches_float64_reference(B, C, M, D, H, W):
+    """dn_conv3d_k4s2_down / _up (+ the existing _wrw) against Conv3d / ConvTranspose3d in float64 on the CPU: forward, input
+    gradient, weight gradient of both layers of the 3-D generator."""
+    import torch.nn.functional as F
+    from diffnet_amd.networks.fused import Conv3dS2, ConvTranspose3dS2
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(12)
+    fine = torch.randn((B, C, 2 * D, 2 * H, 2 * W), generator=g)
+    coarse = torch.randn((B, M, D, H, W), generator=g)
+    w = torch.randn((M, C, 4, 4, 4), generator=g) * 0.05
+
+    def check(got, ref, what):
+        scale = float(ref.abs().max()) + 1e-30
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err <= 2e-5 * scale, (what, err, scale)
+
+    conv = Conv3dS2(C, M, 4, 2, 1, bias=False).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xg = fine.to(dev).requires_grad_(True)
+    y = conv(xg)
+    gx, gw = torch.autograd.grad(y, (xg, conv.weight), coarse.to(dev))
+    xd, wd = fine.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv3d(xd, wd, None, 2, 1)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), coarse.double())
+    check(y.detach(), yd.detach(), "conv3d fwd")
+    check(gx, gxd, "conv3d dgrad")
+    if M <= 128:
+        check(gw, gwd, "conv3d wgrad")
+    convt = ConvTranspose3dS2(M, C, 4, 2, 1, bias=False).to(dev)
+    with torch.no_grad():
+        convt.weight.copy_(w)
+    cg = coarse.to(dev).requires_grad_(True)
+    z = convt(cg)
+    gc, gwt = torch.autograd.grad(z, (cg, convt.weight), fine.to(dev))
+    cd, wtd = coarse.double().requires_grad_(True), w.double().requires_grad_(True)
+    zd = F.conv_transpose3d(cd, wtd, None, 2, 1)
+    gcd, gwtd = torch.autograd.grad(zd, (cd, wtd), fine.double())
+    check(z.detach(), zd.detach(), "convT3d fwd")
+    check(gc, gcd, "convT3d dgrad")
+    check(gwt, gwtd, "convT3d wgrad")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Ci,Co,H,W,K", [(2, 1, 128, 38, 38, 7), (2, 128, 1, 40, 40, 3), (1, 1, 1, 38, 38, 7), (3, 3, 5, 9, 11, 5), (1, 2, 2, 7, 7, 7)])
+def test_conv2d_valid_matches_float64_reference(B, Ci, Co, H, W, K):
+    """dn_conv2d_valid_* (the AE's stride-1 stem / head convolutions, with bias) against float64 torch on the CPU."""
+    import torch.nn.functional as F
+    from diffnet_amd.networks.fused import Conv2dValid
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn((B, Ci, H, W), generator=g)
+    w = torch.randn((Co, Ci, K, K), generator=g) * 0.1
+    bias = torch.randn((Co,), generator=g)
+    cot = torch.randn((B, Co, H - K + 1, W - K + 1), generator=g)
+    conv = Conv2dValid(Ci, Co, K).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.copy_(bias)
+    xg = x.to(dev).requires_grad_(True)
+    y = conv(xg)
+    gx, gw, gb = torch.autograd.grad(y, (xg, conv.weight, conv.bias), cot.to(dev))
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, bd)
+    gxd, gwd, gbd = torch.autograd.grad(yd, (xd, wd, bd), cot.double())
+    for got, ref, what in ((y.detach(), yd.detach(), "fwd"), (gx, gxd, "dgrad"), (gw, gwd, "wgrad"), (gb, gbd, "bias grad")):
+        scale = float(ref.abs().max()) + 1e-30
+        assert float((got.cpu().double() - ref).abs().max()) <= 2e-5 * scale, what
