@@ -32,6 +32,16 @@ constexpr int C2_SB = 80;          // LDS row stride of a B tile [k][col]:    (8
 
 __device__ __forceinline__ c2_f32x4 mfma4(float a, float b, c2_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// v where ok, +0 elsewhere, as a bit mask: the loaded value is always consumed, so the compiler cannot sink the (clamped, always
+// legal) load into a divergent branch -- which it does for `ok ? v : 0`, adding a branch and a vmcnt(0) wait per load
+__device__ __forceinline__ unsigned opaque_mask(bool ok) {
+    unsigned m = ok ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));           // the compiler must not see that m is 0 / ~0 (it would rebuild the select and sink the load)
+    return m;
+}
+__device__ __forceinline__ float keep_if(float v, bool ok) { return __uint_as_float(__float_as_uint(v) & opaque_mask(ok)); }
+__device__ __forceinline__ float keep_mask(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
+
 // =====================================================================================================================
 // down:  coarse[b, m, p] = sum_k w[m][k] * patch[k][p],  k = c * 16 + ky * 4 + kx,  p = i * W + j
 // grid = (B * ceil(HW / 64), ceil(M / TM)), block = 256.  TM = 64 or 32 coarse channels per workgroup.
@@ -66,21 +76,31 @@ __global__ void __launch_bounds__(256) conv2d_k4s2_down_kernel(const float* __re
 
     float breg[16];
     float4 areg[TM / 16];
+    // patch loads are unconditional on clamped (in-bounds) addresses; out-of-range taps are zeroed by selects afterwards: no
+    // exec-masked branch per load, SGPR base + 32-bit offset addressing
+    unsigned xoff[4], yoff[4], tapmask[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int x = 2 * pj + t - 1, y = 2 * pi + t - 1;
+        xoff[t] = (unsigned)min(max(x, 0), W2 - 1);
+        yoff[t] = (unsigned)min(max(y, 0), H2 - 1) * (unsigned)W2;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int x = 2 * pj + kx - 1, y = 2 * pi + ky - 1;
+            tapmask[ky * 4 + kx] = opaque_mask(pok && x >= 0 && x < W2 && y >= 0 && y < H2);
+        }
     auto issue = [&](int c0) {
         const int c = c0 + q;
-        const bool cok = pok && c < C;
-        const float* fc = fb + (size_t)(cok ? c : 0) * H2 * W2;
+        const unsigned cmask = opaque_mask(c < C);
+        const unsigned coff = (unsigned)min(c, C - 1) * (unsigned)(H2 * W2);
 #pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-            const int y = 2 * pi + ky - 1;
-            const bool yok = cok && y >= 0 && y < H2;
-            const float* fr = fc + (size_t)(yok ? y : 0) * W2;
+        for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 4; ++kx) {
-                const int x = 2 * pj + kx - 1;
-                breg[ky * 4 + kx] = (yok && x >= 0 && x < W2) ? fr[x] : 0.f;
-            }
-        }
+            for (int kx = 0; kx < 4; ++kx)
+                breg[ky * 4 + kx] = keep_mask(ld_at<float>(fb, coff + yoff[ky] + xoff[kx]), tapmask[ky * 4 + kx] & cmask);
         // A tile: w[m0 + mm][c0 .. c0 + 3][16] = 64 contiguous floats per row (zero beyond M / C)
 #pragma unroll
         for (int r = 0; r < TM / 16; ++r) {
@@ -109,17 +129,32 @@ __global__ void __launch_bounds__(256) conv2d_k4s2_down_kernel(const float* __re
         const int buf = st & 1;
         const bool more = st + 1 < nsteps;
         if (more) issue((st + 1) * KC);
-#pragma unroll 4
-        for (int k4 = 0; k4 < KC * 4; ++k4) {
-            float a[RT], bb[2];
+        // operand fragments are read from LDS one group of 4 k-steps ahead of the MFMAs that consume them (register double buffer;
+        // 16 MFMAs = 512 cycles cover the LDS latency).  sched_barrier keeps the compiler from re-serialising read -> wait -> MFMA.
+        constexpr int GK = 4, NG = KC * 4 / GK;
+        float a[2][GK][RT], bb[2][GK][2];
+        auto frags = [&](int g, float (&fa)[GK][RT], float (&fbv)[GK][2]) {
 #pragma unroll
-            for (int r = 0; r < RT; ++r) a[r] = As[buf][row0 + 16 * r + li][4 * k4 + lk];
+            for (int kk = 0; kk < GK; ++kk) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) bb[s] = Bs[buf][4 * k4 + lk][col0 + 16 * s + li];
+                for (int r = 0; r < RT; ++r) fa[kk][r] = As[buf][row0 + 16 * r + li][4 * (g * GK + kk) + lk];
 #pragma unroll
-            for (int r = 0; r < RT; ++r)
+                for (int s = 0; s < 2; ++s) fbv[kk][s] = Bs[buf][4 * (g * GK + kk) + lk][col0 + 16 * s + li];
+            }
+        };
+        frags(0, a[0], bb[0]);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) acc[r][s] = mfma4(a[r], bb[s], acc[r][s]);
+        for (int g = 0; g < NG; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < NG) frags(g + 1, a[nxt], bb[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < GK; ++kk)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) acc[r][s] = mfma4(a[cur][kk][r], bb[cur][kk][s], acc[r][s]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) commit(buf ^ 1);
         __syncthreads();
@@ -182,15 +217,17 @@ __global__ void __launch_bounds__(256) conv2d_k4s2_up_kernel(const float* __rest
     auto issue = [&](int mstep) {
         const int m = mstep + q;
         const bool mok = pok && m < M;
-        const float* cm = cb + (size_t)(mok ? m : 0) * HW;
+        const float* cm = cb + (size_t)(m < M ? m : 0) * HW;
 #pragma unroll
         for (int di = -1; di <= 1; ++di) {
             const int ii = I + di;
             const bool iok = mok && ii >= 0 && ii < H;
+            const int io = min(max(ii, 0), H - 1) * W;
 #pragma unroll
             for (int dj = -1; dj <= 1; ++dj) {
                 const int jj = J + dj;
-                preg[(di + 1) * 3 + dj + 1] = (iok && jj >= 0 && jj < W) ? cm[ii * W + jj] : 0.f;
+                const float v = cm[io + min(max(jj, 0), W - 1)];
+                preg[(di + 1) * 3 + dj + 1] = keep_if(v, iok && jj >= 0 && jj < W);
             }
         }
         // weights: w[mstep + mm][c0 + cc][16]: KC * TC * 16 floats as float4
@@ -222,28 +259,37 @@ __global__ void __launch_bounds__(256) conv2d_k4s2_up_kernel(const float* __rest
         const int buf = st & 1;
         const bool more = st + 1 < nsteps;
         if (more) issue((st + 1) * KC);
+        // KC * 4 sub-steps (coarse channel mm, parity py, px), each one k-step of 4 taps; fragments of sub-step t + 1 are read
+        // from LDS while the MFMAs of sub-step t run
+        auto frag = [&](int t, float (&a)[RT], float (&bv)[2]) {
+            const int mm = t >> 2, py = (t >> 1) & 1, px = t & 1;
+            const int ky = py == 0 ? (ta == 0 ? 1 : 3) : (ta == 0 ? 0 : 2);
+            const int di = py == 0 ? (ta == 0 ? 0 : -1) : (ta == 0 ? 1 : 0);
+            const int kx = px == 0 ? (tb == 0 ? 1 : 3) : (tb == 0 ? 0 : 2);
+            const int dj = px == 0 ? (tb == 0 ? 0 : -1) : (tb == 0 ? 1 : 0);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r] = Ws[buf][mm][ky * 4 + kx][row0 + 16 * r + li];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) bv[s] = Ps[buf][mm][(di + 1) * 3 + dj + 1][col0 + 16 * s + li];
+        };
+        float fa[2][4][RT], fb2[2][4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) frag(t, fa[0][t], fb2[0][t]);
 #pragma unroll
         for (int mm = 0; mm < KC; ++mm) {
+            const int cur = mm & 1, nxt = cur ^ 1;
+            if (mm + 1 < KC) {
 #pragma unroll
-            for (int py = 0; py < 2; ++py) {
-                // lane group lk = (ta, tb) holds tap a = ta, bb = tb of the parity's 2 x 2 block
-                const int ky = py == 0 ? (ta == 0 ? 1 : 3) : (ta == 0 ? 0 : 2);
-                const int di = py == 0 ? (ta == 0 ? 0 : -1) : (ta == 0 ? 1 : 0);
-#pragma unroll
-                for (int px = 0; px < 2; ++px) {
-                    const int kx = px == 0 ? (tb == 0 ? 1 : 3) : (tb == 0 ? 0 : 2);
-                    const int dj = px == 0 ? (tb == 0 ? 0 : -1) : (tb == 0 ? 1 : 0);
-                    float a[RT], bb[2];
-#pragma unroll
-                    for (int r = 0; r < RT; ++r) a[r] = Ws[buf][mm][ky * 4 + kx][row0 + 16 * r + li];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) bb[s] = Ps[buf][mm][(di + 1) * 3 + dj + 1][col0 + 16 * s + li];
-#pragma unroll
-                    for (int r = 0; r < RT; ++r)
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) acc[py * 2 + px][r][s] = mfma4(a[r], bb[s], acc[py * 2 + px][r][s]);
-                }
+                for (int t = 0; t < 4; ++t) frag((mm + 1) * 4 + t, fa[nxt][t], fb2[nxt][t]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int par = 0; par < 4; ++par)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) acc[par][r][s] = mfma4(fa[cur][par][r], fb2[cur][par][s], acc[par][r][s]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) commit(buf ^ 1);
         __syncthreads();
@@ -301,23 +347,25 @@ __global__ void __launch_bounds__(256) conv2d_k4s2_wrw_kernel(const float* __res
         const int i = p / W, j = p % W;
         const int c = c0 + q;
         const bool cok = ok && c < C;
-        const float* fc = fine + ((size_t)b * C + (cok ? c : 0)) * H2 * W2;
+        const float* fc = fine + ((size_t)b * C + (c < C ? c : 0)) * H2 * W2;
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
             const int y = 2 * i + ky - 1;
             const bool yok = cok && y >= 0 && y < H2;
-            const float* fr = fc + (size_t)(yok ? y : 0) * W2;
+            const unsigned yo = (unsigned)min(max(y, 0), H2 - 1) * (unsigned)W2;
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx) {
                 const int x = 2 * j + kx - 1;
-                sreg[ky * 4 + kx] = (yok && x >= 0 && x < W2) ? fr[x] : 0.f;
+                const float v = fc[yo + (unsigned)min(max(x, 0), W2 - 1)];
+                sreg[ky * 4 + kx] = keep_if(v, yok && x >= 0 && x < W2);
             }
         }
         const float* cb = coarse + (size_t)b * M * HW + p;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + q + 4 * r;
-            vreg[r] = (ok && m < M) ? cb[(size_t)m * HW] : 0.f;
+            const float v = cb[(size_t)min(m, M - 1) * HW];
+            vreg[r] = keep_if(v, ok && m < M);
         }
     };
     auto commit = [&](int buf) {
@@ -334,17 +382,30 @@ __global__ void __launch_bounds__(256) conv2d_k4s2_wrw_kernel(const float* __res
         const int buf = t & 1;
         const bool more = t + 1 < tiles_per_wg;
         if (more) issue(t + 1);
-#pragma unroll 4
-        for (int k4 = 0; k4 < C2_TN / 4; ++k4) {
-            float a[2], bb[2];
+        constexpr int GK = 4, NG = C2_TN / 4 / GK;
+        float a[2][GK][2], bb[2][GK][2];
+        auto frags = [&](int g, float (&fa)[GK][2], float (&fbv)[GK][2]) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) a[r] = Vs[buf][row0 + 16 * r + li][4 * k4 + lk];
+            for (int kk = 0; kk < GK; ++kk) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) bb[s] = Ss[buf][4 * k4 + lk][col0 + 16 * s + li];
+                for (int r = 0; r < 2; ++r) fa[kk][r] = Vs[buf][row0 + 16 * r + li][4 * (g * GK + kk) + lk];
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+                for (int s = 0; s < 2; ++s) fbv[kk][s] = Ss[buf][4 * (g * GK + kk) + lk][col0 + 16 * s + li];
+            }
+        };
+        frags(0, a[0], bb[0]);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) acc[r][s] = mfma4(a[r], bb[s], acc[r][s]);
+        for (int g = 0; g < NG; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < NG) frags(g + 1, a[nxt], bb[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < GK; ++kk)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) acc[r][s] = mfma4(a[cur][kk][r], bb[cur][kk][s], acc[r][s]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) commit(buf ^ 1);
         __syncthreads();
@@ -385,7 +446,7 @@ static void c2_wrw_plan(int64_t B, int64_t C, int64_t M, int64_t H, int64_t W, i
 
 static int c2_check(int64_t B, int64_t C, int64_t M, int64_t H, int64_t W) {
     if (B < 1 || C < 1 || M < 1 || H < 1 || W < 1) return DN_E_BADARG;
-    if (B * C * 4 * H * W >= (1ll << 40) || 4 * H * W >= (1ll << 30) || M > 65535 * 32 || C > 65535 * 4) return DN_E_UNSUPPORTED;
+    if (C * 4 * H * W >= (1ll << 30) || M * H * W >= (1ll << 30) || M > 65535 * 32 || C > 65535 * 4) return DN_E_UNSUPPORTED;   // 32-bit in-sample offsets
     return 0;
 }
 
