@@ -176,6 +176,8 @@ def _wrw3d(fine, coarse):
     fine, coarse = fine.contiguous(), coarse.contiguous()
     B, CN = fine.shape[:2]
     M, (d, h, w) = coarse.shape[1], coarse.shape[2:]
+    if M > 128:        # the kernel tiles at most 128 coarse channels per launch: wider layers (ConvTranspose3d 256 -> 64) go in channel blocks
+        return torch.cat([_wrw3d(fine, coarse[:, m0:m0 + 128]) for m0 in range(0, M, 128)], 0)
     gw = torch.empty((M, CN, 4, 4, 4), dtype=torch.float32, device=fine.device)
     nbytes = _lib.lib().dn_conv3d_k4s2_wrw_workspace_bytes(B, CN, M, d, h, w)
     if nbytes < 0:
@@ -255,7 +257,7 @@ class _ConvT3dK4S2(torch.autograd.Function):
 
 def _k4s2(m, x, coarse_channels):
     return (x.is_cuda and x.dtype == torch.float32 and m.bias is None and tuple(m.kernel_size) == (4, 4, 4) and tuple(m.stride) == (2, 2, 2)
-            and tuple(m.padding) == (1, 1, 1) and tuple(m.dilation) == (1, 1, 1) and m.groups == 1 and coarse_channels <= 128
+            and tuple(m.padding) == (1, 1, 1) and tuple(m.dilation) == (1, 1, 1) and m.groups == 1
             and tuple(getattr(m, "output_padding", (0, 0, 0))) == (0, 0, 0))
 
 
