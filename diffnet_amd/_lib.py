@@ -69,6 +69,10 @@ SYMBOLS = {
                                      C.c_float, C.c_float, C.c_void_p]),
     "dn_fdm_stencil_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32,
                                      C.c_float, C.c_float, C.c_void_p]),
+    "dn_fdm_fused_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32,
+                                   C.c_float, C.c_float, C.c_void_p]),
+    "dn_fdm_fused_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32,
+                                   C.c_float, C.c_float, C.c_void_p]),
     "dn_fsdt_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
     "dn_fsdt_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnFsdtArgs), C.c_void_p]),
     "dn_upconv_out_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, C.c_int64]),

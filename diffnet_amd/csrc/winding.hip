@@ -37,7 +37,8 @@ __global__ void __launch_bounds__(256) winding_kernel(const float* __restrict__ 
             const float4 v = sp[j];
             const float dx = v.x - qx, dy = v.y - qy;
             const float den = k * (fabsf(dx) + fabsf(dy));
-            acc += (dx * v.z + dy * v.w) / (den * den * den);
+            // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions per pair: 2.2x the kernel time)
+            acc = fmaf(fmaf(dx, v.z, dy * v.w), __builtin_amdgcn_rcpf(den * den * den), acc);
         }
         __syncthreads();
     }

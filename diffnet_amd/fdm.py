@@ -68,6 +68,32 @@ class _Stencil(torch.autograd.Function):
         return gg, None, None, None, None
 
 
+class _StencilFused(torch.autograd.Function):
+    """pad + stencil + boundary fix-up in one launch each way (dn_fdm_fused_fwd/bwd): input and output on the same grid."""
+
+    @staticmethod
+    def forward(ctx, u, k9, axis, a, b):
+        u = _require(u, "u", 4)
+        if u.shape[1] != 1:
+            raise ValueError(f"expected a single-channel field (B,1,N,N), got {tuple(u.shape)}")
+        B, ny, nx = u.shape[0], u.shape[2], u.shape[3]
+        out = torch.empty_like(u)
+        rc = _lib.lib().dn_fdm_fused_fwd(_p(u), _p(out), B, ny, nx, (C.c_float * 9)(*k9), axis, a, b, _stream(u))
+        _lib.check(rc, "dn_fdm_fused_fwd")
+        ctx.meta = (k9, axis, a, b, B, ny, nx)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        k9, axis, a, b, B, ny, nx = ctx.meta
+        go = _require(go, "grad_output", 4)
+        gu = torch.empty_like(go)
+        rc = _lib.lib().dn_fdm_fused_bwd(_p(go), _p(gu), B, ny, nx, (C.c_float * 9)(*k9), axis, a, b, _stream(go))
+        _lib.check(rc, "dn_fdm_fused_bwd")
+        return gu, None, None, None, None
+
+
 class DiffNetFDM(PDE):
     def __init__(self, network, dataset=None, **kwargs):
         super().__init__(network, dataset, **kwargs)
@@ -100,6 +126,20 @@ class DiffNetFDM(PDE):
 
     def derivative_yy(self, g):
         return _Stencil.apply(g, self._k["yy"], 1, 0.0, 1.0)
+
+    # fused level (new): the replicate padding the reference applies with `self.pad(u)` is folded into the kernel
+    def dx(self, u):
+        """== derivative_x(self.pad(u)) in one launch, no padded tensor."""
+        return _StencilFused.apply(u, self._k["x"], 0, 4.0, -1.0)
+
+    def dy(self, u):
+        return _StencilFused.apply(u, self._k["y"], 1, 4.0, -1.0)
+
+    def dxx(self, u):
+        return _StencilFused.apply(u, self._k["xx"], 0, 0.0, 1.0)
+
+    def dyy(self, u):
+        return _StencilFused.apply(u, self._k["yy"], 1, 0.0, 1.0)
 
     def derivative_z(self, g):
         raise NotImplementedError("the reference class is hard-wired to nsd = 2 (DiffNetFDM.py:128); z-derivatives are unreachable there")

@@ -265,6 +265,13 @@ int dn_conv2d_valid_bwd_data(const float *gy, const float *w, float *gx, int64_t
 int dn_conv2d_valid_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int64_t B, int64_t Ci, int64_t Co, int64_t H, int64_t W,
                                int64_t K, void *stream);
 
+/* dn_fdm_stencil_* with the replicate padding folded in (`self.pad(u)` of DiffNet/DiffNetFDM.py:128-199 becomes clamped indexing):
+ * u and out are both (B,1,ny,nx); the backward pass returns the gradient on the unpadded grid (adjoint of pad + stencil + fix-up). */
+int dn_fdm_fused_fwd(const float *u, float *out, int32_t batch, int32_t ny, int32_t nx, const float *kernel9, int32_t axis, float a,
+                     float b, void *stream);
+int dn_fdm_fused_bwd(const float *grad_out, float *grad_u, int32_t batch, int32_t ny, int32_t nx, const float *kernel9, int32_t axis,
+                     float a, float b, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -405,3 +405,19 @@ def test_bench_spawns_its_own_ranks_world2_gloo_rehearsal():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["slab_3d"]["n_gpus"] == 2 and out["slab_3d"]["scaling"] == "strong" and out["slab_3d"]["value"] > 0
     assert out["roofline"]["kernel_median_ms"] >= out["roofline"]["kernel_min_ms"] > 0
+
+
+@pytest.mark.parametrize("n", [16, 33])
+def test_fdm_fused_pad_matches_reference_golden(n):
+    """dx / dy / dxx / dyy (replicate pad folded into the stencil kernel) == the reference's derivative_*(self.pad(u)) and its VJP
+    wrt the UNPADDED field (tests/golden/fdm_n*.npz hold both)."""
+    from DiffNet.DiffNetFDM import DiffNetFDM
+    z = np.load(os.path.join(GOLDEN, f"fdm_n{n}.npz"))
+    m = DiffNetFDM(None, domain_size=n).to(dev())
+    u = cu(z["u"])
+    for name in ("x", "y", "xx", "yy"):
+        ur = u.clone().requires_grad_(True)
+        d = getattr(m, "d" + name)(ur)
+        close(d, z["d_" + name], rtol=1e-5, arel=2e-6, msg=name)
+        (g,) = torch.autograd.grad(d, ur, cu(z["cot_" + name]))
+        close(g, z["vjp_" + name], rtol=1e-5, arel=2e-6, msg="vjp " + name)
