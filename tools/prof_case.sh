@@ -1,7 +1,9 @@
 #!/bin/bash
 # rocprofv3 counter passes (SQ / TCC / SPI groups in separate runs, no trace domains with --pmc) + a kernel-trace pass for one
 # tools/run_case.py invocation.  usage: tools/prof_case.sh <tag> <run_case args...>      output: gpurun_out/pmc_<tag>.txt
+#        DN_PROF_SCRIPT=tools/other.py tools/prof_case.sh <tag> <args of that script...>   profiles another driver script
 tag=$1; shift
+script=${DN_PROF_SCRIPT:-tools/run_case.py}
 export TMPDIR=/tmp
 root=$(pwd)
 out=$root/gpurun_out/pmc_$tag
@@ -14,9 +16,9 @@ for ctrs in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_
             "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32" \
             "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "MeanOccupancyPerCU"; do
   i=$((i+1))
-  (cd /tmp && rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- python3 $root/tools/run_case.py "$@" > $out/p$i.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- python3 $root/$script "$@" > $out/p$i.log 2>&1)
 done
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $root/tools/run_case.py "$@" > $out/kt.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $root/$script "$@" > $out/kt.log 2>&1)
 python3 - <<PY > $root/gpurun_out/pmc_$tag.txt
 import csv,glob,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
