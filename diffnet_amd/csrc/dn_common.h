@@ -56,11 +56,19 @@ struct VecT<4> { using type = float4; };
 // Callers guarantee in-sample byte offsets < 2^32 (dn_poisson_apply rejects samples of >= 2^30 nodes).
 template <typename V, typename T>
 __device__ __forceinline__ V ld_at(const T* __restrict__ base, unsigned index) {
+#ifdef DN_NT_LOADS          // experiment: non-temporal loads for the streamed fields (profiles/r2_2d_ab.txt)
+    return __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (index * (unsigned)sizeof(T))));
+#else
     return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (index * (unsigned)sizeof(T)));
+#endif
 }
 template <typename V, typename T>
 __device__ __forceinline__ void st_at(T* __restrict__ base, unsigned index, const V& v) {
+#ifdef DN_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(reinterpret_cast<char*>(base) + (index * (unsigned)sizeof(T))));
+#else
     *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + (index * (unsigned)sizeof(T))) = v;
+#endif
 }
 
 // Branch-free row-segment load: NW consecutive nodes starting at x0 plus the node x0+NW shared with the next
@@ -96,6 +104,43 @@ __device__ __forceinline__ void load_seg(const T* __restrict__ base, unsigned ro
         for (int k = 0; k < NW; ++k) dst[k] = ld_at<T>(base, rowoff + (unsigned)min(x0 + k, nx - 1));
     }
     dst[NW] = ld_at<T>(base, rowoff + (unsigned)min(x0 + NW, nx - 1));
+}
+
+// lane l <- lane l + 1 (whole wave), lane 63 keeps `last`
+__device__ __forceinline__ unsigned dpp_from_right_u32(unsigned v, unsigned last) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+
+// load_seg for NW = 4 aligned rows where the shared node x0 + 4 is the RIGHT NEIGHBOUR LANE's first node: one vector load per
+// lane; the extra value comes over DPP (wave_shl:1) and only lane 63 of each wave loads it from memory (its neighbour is in
+// the next wave).  A per-lane dword / byte load at a stride of 16 bytes touches 16 cache lines per wave-instruction; this form
+// issues it for one lane.  Requires consecutive lanes = consecutive x0 (x0 = 4 * lane + const within the wave).
+template <typename T>
+__device__ __forceinline__ void load_seg4_dpp(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[5]) {
+    const unsigned xl = (unsigned)min(x0, nx - 4);
+    // the node right of the wave's last lane: ONE wave-uniform address -> a scalar (SMEM) load, no divergent branch
+    const unsigned eidx = (unsigned)__builtin_amdgcn_readfirstlane((int)rowoff) +
+                          (unsigned)min(__builtin_amdgcn_readfirstlane(x0) + 256, nx - 1);
+    if constexpr (sizeof(T) == 4) {
+        const float4 v = ld_at<float4>(base, rowoff + xl);
+        const unsigned bits = __float_as_uint(reinterpret_cast<const float&>(v.x));
+        const T lastv = base[eidx];
+        const float last = reinterpret_cast<const float&>(lastv);
+        const unsigned e = dpp_from_right_u32(bits, __float_as_uint(last));
+        const float vf[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = reinterpret_cast<const T&>(vf[k]);
+        const float ef = __uint_as_float(e);
+        dst[4] = reinterpret_cast<const T&>(ef);
+    } else {
+        static_assert(sizeof(T) == 1, "load_seg4_dpp: 1- or 4-byte elements");
+        const uint32_t w = ld_at<uint32_t>(base, rowoff + xl);
+        const uint32_t last = (uint32_t)base[eidx];
+        const uint32_t e = dpp_from_right_u32(w, last);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = (T)((w >> (8 * k)) & 0xffu);
+        dst[4] = (T)(e & 0xffu);
+    }
 }
 
 // Exactly NW consecutive nodes starting at x0 (clamped like load_seg, no shared +1 node).

@@ -37,6 +37,9 @@ struct CfRow {
 #define DN_PRIO_ROT 3
 #endif
 
+#ifndef DN_CF_DPPX
+#define DN_CF_DPPX 0              // 1: E = 4 takes the shared node x0 + 4 over DPP from the neighbouring lane instead of a strided per-lane load; measured equal (profiles/r2_2d_ab.txt)
+#endif
 #ifndef DN_CF_PF
 #define DN_CF_PF 0                // 1: software-pipelined rows (row k + 2 in flight while layer k is computed); measured equal (profiles/r2_2d_ab.txt), off: 79 instead of 102 VGPRs
 #endif
@@ -69,23 +72,29 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);
     mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);
 
+    auto lseg = [&](auto base, unsigned rowoff, auto& dst) {
+        if constexpr (E == 4 && VEC && DN_CF_DPPX) load_seg4_dpp(base, rowoff, x0, p.nx, dst);
+        else load_seg<NW, VEC>(base, rowoff, x0, p.nx, dst);
+    };
     auto row_issue = [&](int yr, CfRow<E>& r) {
         const unsigned rowoff = (unsigned)min(yr, p.ny - 1) * (unsigned)p.nx;
-        load_seg<NW, VEC>(sb.u, rowoff, x0, p.nx, r.u);
-        if constexpr (HAS_NU) load_seg<NW, VEC>(sb.nu, rowoff, x0, p.nx, r.n);
-        if constexpr (HAS_F) load_seg<NW, VEC>(sb.f, rowoff, x0, p.nx, r.f);
+        lseg(sb.u, rowoff, r.u);
+        if constexpr (HAS_NU) lseg(sb.nu, rowoff, r.n);
+        if constexpr (HAS_F) lseg(sb.f, rowoff, r.f);
         if constexpr (BC_U8C) {
             // both mask slots are loaded unconditionally (an absent one re-reads the other and is ignored): a load inside a
             // wave-uniform branch makes the compiler wait vmcnt(0) where the branch joins, which would drain the pipelined rows
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                uint8_t t[NW + 1];
-                load_seg<NW, VEC>(mask8[k], rowoff, x0, p.nx, t);
-                uint32_t w = 0u;
+                if (DN_CF_PF || has_mask[k]) {        // not pipelined: an absent condition costs no load (wave-uniform branch)
+                    uint8_t t[NW + 1];
+                    lseg(mask8[k], rowoff, t);
+                    uint32_t w = 0u;
 #pragma unroll
-                for (int n = 0; n < NW; ++n) w |= (uint32_t)t[n] << (8 * n);
-                r.m8[k][0] = w;
-                r.m8[k][1] = t[NW];
+                    for (int n = 0; n < NW; ++n) w |= (uint32_t)t[n] << (8 * n);
+                    r.m8[k][0] = w;
+                    r.m8[k][1] = t[NW];
+                }
             }
         } else if constexpr (BC_ANY) {
             bc_issue<NW, VEC>(p, sb, rowoff, x0, r.bc);
@@ -98,12 +107,14 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         if constexpr (BC_U8C) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const float val = p.bc[k].value;
+                if (DN_CF_PF || has_mask[k]) {
+                    const float val = p.bc[k].value;
 #pragma unroll
-                for (int n = 0; n <= NW; ++n) {
-                    const bool set = has_mask[k] && (n < NW ? ((r.m8[k][0] >> (8 * n)) & 0xffu) != 0u : r.m8[k][1] != 0u);
-                    r.u[n] = set ? val : r.u[n];
-                    if (n < NW) r.keep[n] = set ? 0.f : r.keep[n];
+                    for (int n = 0; n <= NW; ++n) {
+                        const bool set = has_mask[k] && (n < NW ? ((r.m8[k][0] >> (8 * n)) & 0xffu) != 0u : r.m8[k][1] != 0u);
+                        r.u[n] = set ? val : r.u[n];
+                        if (n < NW) r.keep[n] = set ? 0.f : r.keep[n];
+                    }
                 }
             }
         } else if constexpr (BC_ANY) {
