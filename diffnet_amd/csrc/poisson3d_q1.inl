@@ -411,9 +411,35 @@ __device__ __forceinline__ void stage_w3(const ElemTab& T, float a0, float a1, f
 struct __attribute__((packed, aligned(4))) F2U { float a, b; };
 struct __attribute__((packed, aligned(1))) B2U { uint8_t a, b; };
 
-__device__ __forceinline__ float dpp_from_left(float v) {      // lane l <- lane l - 1 inside each row of 16 lanes, 0 for the first lane
+// lane l <- lane l - 1 inside each row of 16 lanes, 0 for the first lane.  NOT a DPP move: on gfx950 every DPP / SDWA / v_readlane
+// instruction costs a SIMD ~33 cycles (about 14 plain VALU instructions) as soon as two or more waves share it, while a
+// ds_bpermute_b32 / ds_swizzle_b32 costs ~3 (tools/micro/valu_mem.hip, profiles/r2_valu_mem.txt).  `from` is the byte address of the
+// source lane ((lane - 1) & 63) * 4, `nf` is 0 for the first lane of a row and 1 elsewhere.
+#ifndef DN_T16_DPP
+#define DN_T16_DPP 0
+#endif
+#ifndef DN_T16_PAIRED
+#define DN_T16_PAIRED 1
+#endif
+__device__ __forceinline__ float lane_from_left(float v, int from, float nf) {
+#if DN_T16_DPP
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+#else
+    return nf * __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, v)));
+#endif
 }
+
+#if defined(DN_STAMP3D) && DN_NGP == 2
+// Diagnostic build only (tools/stamp3d.py): per-wave cycle budget of the T16 loop, accumulated in scalar registers with s_memtime
+// and written once at the end of the kernel by every 61st workgroup.  Phases per layer: A = wait for the prefetched plane + stage
+// it, B = request the next plane + deferred store, C = layer arithmetic, D = hand-over write + barrier wait, E = hand-over read +
+// finish the node value.
+__device__ unsigned long long dn_stamp_buf[8192 * 8];
+extern "C" int dn_debug_stamps(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dn_stamp_buf), bytes); }
+#define DN_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); var += t__ - stamp_last; stamp_last = t__; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DN_STAMP(var) do { } while (0)
+#endif
 
 template <int NGP, int E, bool VEC, int FL, bool UW, bool T16>
 __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP == 2) ? DN_Q1W_WAVES_E1 : DN_Q1W_WAVES)) poisson3d_q1w_kernel(const PoissonParams p, const int chunks_x, const int tiles_y,
@@ -458,6 +484,10 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
 #pragma unroll
     for (int e = 0; e < E; ++e) okf[e] = (row_ok && (ex0 + e < p.nelx)) ? 1.f : 0.f;
 
+#if defined(DN_STAMP3D) && DN_NGP == 2
+    unsigned long long stamp_A = 0, stamp_B = 0, stamp_C = 0, stamp_D = 0, stamp_E = 0, stamp_n = 0, stamp_last = 0;
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ float xch[2][T16 ? 1 : NW + 2][256];
     __shared__ double red[256 / 64 + 1];
     __shared__ int last_flag;
@@ -500,7 +530,11 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
         uint8_t m8[2][2][NW + 1];
     };
     auto plane_issue = [&](int zreq, RawPlane& W) {
+#ifdef DN_ABL_ZFIX3D                       // timing experiment only: every plane re-reads the strip's first plane (cache hits)
+        const unsigned zoff = (unsigned)ez_begin * npl + (unsigned)(zreq & 1) * 4u * (unsigned)p.nx;
+#else
         const unsigned zoff = (unsigned)min(zreq, p.nz - 1) * npl;
+#endif
         const unsigned rowoff[2] = {zoff + row0, zoff + row1};
         float (&ru)[2][NW + 1] = W.ru;
         float (&rn)[2][NW + 1] = W.rn;
@@ -512,17 +546,67 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
             if constexpr (T16) {
                 // both nodes of the row in one load; threads right of the mesh read the last valid pair (their element is masked)
                 const unsigned o2 = rowoff[jb] + x0c;
+#ifdef DN_ABL_NX4                          // timing experiment only: DN_ABL_NX4 aligned dwordx4 loads per layer and thread, nothing else
+                if (jb == 0) {
+                    float4 a = ld_at<float4>(sb.u, o2 & ~3u);
+                    if (DN_ABL_NX4 > 1) { const float4 t = ld_at<float4>(sb.nu, o2 & ~3u); a.y += t.x; a.z += t.y; }
+                    if (DN_ABL_NX4 > 2) { const float4 t = ld_at<float4>(sb.f, o2 & ~3u); a.w += t.z; a.x += t.w; }
+                    ru[0][0] = a.x; ru[0][1] = a.y; ru[1][0] = a.z; ru[1][1] = a.w;
+                    rn[0][0] = a.y; rn[0][1] = a.z; rn[1][0] = a.w; rn[1][1] = a.x;
+                    rf[0][0] = a.z; rf[0][1] = a.w; rf[1][0] = a.x; rf[1][1] = a.y;
+                    if constexpr (BC_U8C) {
+                        const uint8_t mz = (uint8_t)(a.x == 123.456f);
+                        m8[0][0][0] = m8[0][0][1] = m8[0][1][0] = m8[0][1][1] = m8[1][0][0] = m8[1][0][1] = m8[1][1][0] = m8[1][1][1] = mz;
+                    }
+                }
+                continue;
+#endif
+#ifdef DN_ABL_ROW0DWORD                    // timing experiment only: one aligned dword / byte per field for row 0
+                if (jb == 0) {
+                    const float a0 = ld_at<float>(sb.u, o2);
+                    ru[jb][0] = a0; ru[jb][1] = a0 + 0.5f;
+                    if constexpr (HAS_NU) { const float t = ld_at<float>(sb.nu, o2); rn[jb][0] = t; rn[jb][1] = t; }
+                    if constexpr (HAS_F) { const float t = ld_at<float>(sb.f, o2); rf[jb][0] = t; rf[jb][1] = t; }
+                    if constexpr (BC_U8C) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) { const uint8_t t = ld_at<uint8_t>(mask8[k], o2); m8[jb][k][0] = t; m8[jb][k][1] = t; }
+                    }
+                    continue;
+                }
+#endif
+#if defined(DN_ABL_LOADS3D) || defined(DN_ABL_ROW0ONLY) || defined(DN_ABL_ROW0DWORD)   // timing experiment only: no VMEM loads (all rows / row 1 only); values made up from the offset
+#if !defined(DN_ABL_LOADS3D)
+                if (jb == 1)
+#endif
+                {
+                    const float t = __uint_as_float((o2 & 0xffffu) | 0x3f800000u);
+                    ru[jb][0] = t; ru[jb][1] = t + 0.5f;
+                    rn[jb][0] = t; rn[jb][1] = t; rf[jb][0] = t; rf[jb][1] = t;
+                    if constexpr (BC_U8C) { m8[jb][0][0] = m8[jb][0][1] = m8[jb][1][0] = m8[jb][1][1] = (uint8_t)(o2 == 0xffffffffu); }
+                    continue;
+                }
+#endif
+#if DN_T16_PAIRED          // one 4-byte-aligned dwordx2 / ushort per node pair; two aligned dword loads instead (DN_T16_PAIRED=0) measured 165 -> 249 us at 256^3: the second load hits lines still in flight (profiles/r2_3d_bottleneck.md)
                 const F2U a = ld_at<F2U>(sb.u, o2);
                 ru[jb][0] = a.a; ru[jb][1] = a.b;
                 if constexpr (HAS_NU) { const F2U t = ld_at<F2U>(sb.nu, o2); rn[jb][0] = t.a; rn[jb][1] = t.b; }
                 if constexpr (HAS_F) { const F2U t = ld_at<F2U>(sb.f, o2); rf[jb][0] = t.a; rf[jb][1] = t.b; }
+#else
+                ru[jb][0] = ld_at<float>(sb.u, o2); ru[jb][1] = ld_at<float>(sb.u, o2 + 1u);
+                if constexpr (HAS_NU) { rn[jb][0] = ld_at<float>(sb.nu, o2); rn[jb][1] = ld_at<float>(sb.nu, o2 + 1u); }
+                if constexpr (HAS_F) { rf[jb][0] = ld_at<float>(sb.f, o2); rf[jb][1] = ld_at<float>(sb.f, o2 + 1u); }
+#endif
                 if constexpr (BC_U8C) {
                     // unconditional loads (an absent mask reads the other one and is ignored): a load inside a uniform branch makes
                     // the compiler wait vmcnt(0) at the end of the branch, which serialises every load of the plane behind it
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
+#if DN_T16_PAIRED
                         const B2U t = ld_at<B2U>(mask8[k], o2);
                         m8[jb][k][0] = t.a; m8[jb][k][1] = t.b;
+#else
+                        m8[jb][k][0] = ld_at<uint8_t>(mask8[k], o2); m8[jb][k][1] = ld_at<uint8_t>(mask8[k], o2 + 1u);
+#endif
                     }
                 } else if constexpr (BC_ANY) {
                     bc_issue<NW, false>(p, sb, rowoff[jb], (int)x0c, braw[jb]);
@@ -612,24 +696,36 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
     };
 
     const unsigned out_row = (unsigned)ey * (unsigned)p.nx;
+    const int from_left = (int)(((unsigned)tid - 1u) & 63u) << 2;      // T16 hand-over: source lane of lane_from_left
+    const float nfirst = tx > 0 ? 1.f : 0.f;
     float pend_v = 0.f;                       // T16: output of the last emitted plane, not yet stored
     unsigned pend_off = 0u;
     bool pend_st = false;
     auto flush_store = [&]() {
+#ifdef DN_ABL_STORE3D                      // timing experiment only
+        if (pend_st && pend_v == 123.456f) st_at<float>(sb.out, pend_off, pend_v);
+#else
         if (pend_st) st_at<float>(sb.out, pend_off, pend_v);
+#endif
         pend_st = false;
     };
     auto emit_plane = [&](const float (&o)[2][NW + 1], const float (&keep)[NW], int z, bool owned_plane) {
         if constexpr (T16) {
-            const float left = dpp_from_left(o[0][1]);                  // right-hand contribution of the thread to the left
-            xch[par][0][tid] = o[1][0] + dpp_from_left(o[1][1]);        // up slot with the up-right part of the left thread folded in
+            const float left = lane_from_left(o[0][1], from_left, nfirst);          // right-hand contribution of the thread to the left
+#ifdef DN_ABL_XCH3D                        // timing experiment only: no LDS hand-over, no barrier
+            float t = o[0][0] + left + o[1][0] + lane_from_left(o[1][1], from_left, nfirst);
+#else
+            DN_STAMP(stamp_C);
+            xch[par][0][tid] = o[1][0] + lane_from_left(o[1][1], from_left, nfirst);        // up slot with the up-right part of the left thread folded in
 #ifndef DN_ABLATE_BAR3D                    // timing experiment only: results are wrong without the barrier
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
+            DN_STAMP(stamp_D);
             // the value is stored by flush_store(), AFTER the next plane has been consumed and the one after it requested: a
             // store issued here would be younger than those loads' consumer wait, which the compiler turns into vmcnt(0)
             float t = o[0][0] + left;
             if (ty > 0) t += xch[par][0][tid - 16];
+#endif
             t *= keep[0];
             const bool st = owned_plane && owner && noderow_ok;
             sq_acc = st ? fmaf(t, t, sq_acc) : sq_acc;
@@ -699,16 +795,28 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
         RawPlane W;
         plane_issue(ez_begin + 1, W);
         int ez = ez_begin;
+#if defined(DN_STAMP3D) && DN_NGP == 2
+        stamp_last = __builtin_amdgcn_s_memtime();
+#endif
 #pragma nounroll
         for (; ez + 1 < ez_end; ez += 2) {
             plane_consume(W, SB);
+            DN_STAMP(stamp_A);
             plane_issue(ez + 2, W);
             flush_store();
+            DN_STAMP(stamp_B);
             layer(ez, SA, SB);
+            DN_STAMP(stamp_E);
             plane_consume(W, SA);
+            DN_STAMP(stamp_A);
             plane_issue(ez + 3, W);
             flush_store();
+            DN_STAMP(stamp_B);
             layer(ez + 1, SB, SA);
+            DN_STAMP(stamp_E);
+#if defined(DN_STAMP3D) && DN_NGP == 2
+            stamp_n += 2;
+#endif
         }
         if (ez < ez_end) {
             plane_consume(W, SB);
@@ -743,6 +851,18 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
         if constexpr (T16) flush_store();
     }
 
+#if defined(DN_STAMP3D) && DN_NGP == 2
+    if constexpr (T16) {
+        if (blockIdx.x % 61u == 0u && (tid & 63) == 0) {
+            const unsigned slot = (blockIdx.x / 61u) * 4u + (unsigned)(tid >> 6);
+            if (slot < 8192u) {
+                unsigned long long* d = dn_stamp_buf + slot * 8u;
+                d[0] = stamp_A; d[1] = stamp_B; d[2] = stamp_C; d[3] = stamp_D; d[4] = stamp_E; d[5] = stamp_n;
+                d[6] = stamp_t0; d[7] = __builtin_amdgcn_s_memtime();
+            }
+        }
+    }
+#endif
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, TX * TY, red, &last_flag, (double)p.T.esc);
 }
 
