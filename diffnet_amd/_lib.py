@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DN_LIB_PATH") or os.path.join(HERE, "libdiffnet_hip.so")     # DN_LIB_PATH: a variant build (tools/variant_build.sh)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE"}
 
@@ -23,7 +23,12 @@ class DnMesh(C.Structure):
 
 class DnDirichlet(C.Structure):
     _fields_ = [("mask", C.c_void_p), ("field", C.c_void_p), ("value", C.c_float),
-                ("mask_is_u8", C.c_int32), ("mask_batched", C.c_int32), ("field_batched", C.c_int32)]
+                ("mask_kind", C.c_int32), ("mask_batched", C.c_int32), ("field_batched", C.c_int32),
+                ("box_faces", C.c_int32), ("row_words", C.c_int32)]
+
+
+MASK_F32, MASK_U8, MASK_BITS, MASK_BOX = 0, 1, 2, 3
+FACE_XLO, FACE_XHI, FACE_YLO, FACE_YHI, FACE_ZLO, FACE_ZHI = 1, 2, 4, 8, 16, 32
 
 
 class DnPoissonArgs(C.Structure):
@@ -102,6 +107,8 @@ SYMBOLS = {
                                       C.c_void_p, C.c_int64, C.c_void_p]),
     "dn_instnorm_act_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float,
                                       C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dn_pack_mask_bits": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dn_unpack_mask_bits": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dn_winding_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p]),
 }

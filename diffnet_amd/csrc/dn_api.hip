@@ -56,3 +56,51 @@ extern "C" const char* dn_config_get(const char* key) {
     const int k = key_index(key);
     return k < 0 ? nullptr : g_cfg[k];
 }
+
+// ---- Dirichlet mask images <-> DN_MASK_BITS (include/diffnet_hip.h) ----------------------------------------------------------
+namespace dn {
+__global__ void __launch_bounds__(256) pack_mask_bits_kernel(const void* __restrict__ mask, int is_u8, long long rows, int nx, int row_words,
+                                                             uint32_t* __restrict__ bits) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one 32-bit word per thread
+    if (w >= rows * row_words) return;
+    const long long row = w / row_words;
+    const int x0 = (int)(w % row_words) * 32;
+    uint32_t v = 0u;
+    for (int i = 0; i < 32 && x0 + i < nx; ++i) {
+        const long long idx = row * nx + x0 + i;
+        const bool set = is_u8 ? reinterpret_cast<const uint8_t*>(mask)[idx] != 0 : reinterpret_cast<const float*>(mask)[idx] > 0.5f;
+        v |= set ? (1u << i) : 0u;
+    }
+    bits[w] = v;
+}
+__global__ void __launch_bounds__(256) unpack_mask_bits_kernel(const uint32_t* __restrict__ bits, long long rows, int nx, int row_words,
+                                                               uint8_t* __restrict__ mask) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nx) return;
+    const long long row = i / nx;
+    const int x = (int)(i % nx);
+    mask[i] = (uint8_t)((bits[row * row_words + (x >> 5)] >> (x & 31)) & 1u);
+}
+}  // namespace dn
+
+extern "C" int dn_pack_mask_bits(const void* mask, int32_t mask_kind, int64_t rows, int32_t nx, int32_t row_words, uint32_t* bits, void* stream) {
+    if (!mask || !bits || rows < 0 || nx < 1 || row_words < (nx + 31) / 32 || (mask_kind != DN_MASK_F32 && mask_kind != DN_MASK_U8)) return DN_E_BADARG;
+    const long long n = (long long)rows * row_words;
+    if (n == 0) return 0;
+    if ((n + 255) / 256 >= (1ll << 31)) return DN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(dn::pack_mask_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mask,
+                       (int)(mask_kind == DN_MASK_U8), (long long)rows, (int)nx, (int)row_words, bits);
+    DN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dn_unpack_mask_bits(const uint32_t* bits, int64_t rows, int32_t nx, int32_t row_words, uint8_t* mask_u8, void* stream) {
+    if (!mask_u8 || !bits || rows < 0 || nx < 1 || row_words < (nx + 31) / 32) return DN_E_BADARG;
+    const long long n = (long long)rows * nx;
+    if (n == 0) return 0;
+    if ((n + 255) / 256 >= (1ll << 31)) return DN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(dn::unpack_mask_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), bits,
+                       (long long)rows, (int)nx, (int)row_words, mask_u8);
+    DN_LAUNCH_CHECK();
+    return 0;
+}

@@ -20,7 +20,9 @@
 
 namespace dn {
 
-enum : int { CF_NU = 1, CF_F = 2, CF_BC = 8, CF_BC_U8C = 16 };
+// CF_BC_PACKED: bit-packed masks / box faces with constant values; CF_PK_NB1 / CF_PK_NB2: one / two of the conditions are bit arrays
+// (compile-time: a load inside a wave-uniform branch costs an s_waitcnt vmcnt(0) where the branch joins)
+enum : int { CF_NU = 1, CF_F = 2, CF_BC = 8, CF_BC_U8C = 16, CF_BC_PACKED = 32, CF_PK_NB1 = 64, CF_PK_NB2 = 128 };
 
 template <int E>
 struct CfRow {
@@ -28,6 +30,8 @@ struct CfRow {
     float keep[E];
     BcRaw<E> bc;
     uint32_t m8[2][2];
+    uint32_t mb[2];          // CF_BC_PACKED: the 2-byte windows of the bit arrays that hold the thread's E + 1 nodes of this row
+    uint32_t bx[2];          //                 box-face bits of those nodes, per condition
 };
 
 #ifndef DN_Q1_2D_WAVES
@@ -48,7 +52,7 @@ template <int E, bool VEC, int FL>
 __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(const PoissonParams p) {
     constexpr int NW = E;
     constexpr bool HAS_NU = (FL & CF_NU) != 0, HAS_F = (FL & CF_F) != 0;
-    constexpr bool BC_ANY = (FL & (CF_BC | CF_BC_U8C)) != 0, BC_U8C = (FL & CF_BC_U8C) != 0;
+    constexpr bool BC_ANY = (FL & (CF_BC | CF_BC_U8C | CF_BC_PACKED)) != 0, BC_U8C = (FL & CF_BC_U8C) != 0, BC_PACKED = (FL & CF_BC_PACKED) != 0;
     const int T = blockDim.x;
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
@@ -72,6 +76,43 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);
     mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);
 
+    // CF_BC_PACKED: per condition either one bit per node in HBM (one 2-byte load per thread, row and bit array) or the domain faces
+    // (no load).  Branch-free: NB loads are always issued; what a condition contributes is selected with wave-uniform masks.
+    constexpr unsigned NBITS = (1u << (NW + 1)) - 1u;
+    constexpr int NB = !BC_PACKED ? 0 : ((FL & CF_PK_NB2) ? 2 : ((FL & CF_PK_NB1) ? 1 : 0));
+    const bool isbits[2] = {p.bc[0].kind == DN_MASK_BITS, p.bc[1].kind == DN_MASK_BITS};
+    const unsigned bsel[2] = {isbits[0] ? NBITS : 0u, isbits[1] ? NBITS : 0u};
+    // load slot j reads the bit array of condition src[j]; with one array it is whichever condition has it
+    const int src0 = (NB == 2 || isbits[0]) ? 0 : 1;
+    const uint8_t* bptr[2] = {reinterpret_cast<const uint8_t*>(sb.mask[src0]), reinterpret_cast<const uint8_t*>(sb.mask[1])};
+    const unsigned brow[2] = {(unsigned)p.bc[src0].row_bytes, (unsigned)p.bc[1].row_bytes};
+    unsigned bbyte[2], bshift[2], boxx[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rb = max((int)brow[j], 2);
+        bbyte[j] = (unsigned)min(x0 >> 3, rb - 2);                    // 2-byte window inside the row that holds bits x0 .. x0 + NW
+        bshift[j] = min((unsigned)x0 - 8u * bbyte[j], 31u);           // > 15 only for threads right of the mesh
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int faces = p.bc[k].kind == DN_MASK_BOX ? p.bc[k].box_faces : 0;
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) {
+            const bool on = ((faces & DN_FACE_XLO) && x0 + n == 0) || ((faces & DN_FACE_XHI) && x0 + n == p.nx - 1);
+            boxx[k] |= on ? (1u << n) : 0u;
+        }
+    }
+    const int ylo[2] = {(p.bc[0].kind == DN_MASK_BOX && (p.bc[0].box_faces & DN_FACE_YLO)) ? 0 : -1,
+                        (p.bc[1].kind == DN_MASK_BOX && (p.bc[1].box_faces & DN_FACE_YLO)) ? 0 : -1};
+    const int yhi[2] = {(p.bc[0].kind == DN_MASK_BOX && (p.bc[0].box_faces & DN_FACE_YHI)) ? p.ny - 1 : -1,
+                        (p.bc[1].kind == DN_MASK_BOX && (p.bc[1].box_faces & DN_FACE_YHI)) ? p.ny - 1 : -1};
+    auto packed_issue = [&](int yc, CfRow<E>& r) {                   // yc: node row, already clamped into the mesh
+#pragma unroll
+        for (int j = 0; j < NB; ++j) r.mb[j] = (uint32_t)ld_at<uint16_t>(bptr[j], (unsigned)yc * brow[j] + bbyte[j]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) r.bx[k] = (yc == ylo[k] || yc == yhi[k]) ? NBITS : boxx[k];
+    };
+
     auto lseg = [&](auto base, unsigned rowoff, auto& dst) {
         if constexpr (E == 4 && VEC && DN_CF_DPPX) load_seg4_dpp(base, rowoff, x0, p.nx, dst);
         else load_seg<NW, VEC>(base, rowoff, x0, p.nx, dst);
@@ -81,7 +122,9 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         lseg(sb.u, rowoff, r.u);
         if constexpr (HAS_NU) lseg(sb.nu, rowoff, r.n);
         if constexpr (HAS_F) lseg(sb.f, rowoff, r.f);
-        if constexpr (BC_U8C) {
+        if constexpr (BC_PACKED) {
+            packed_issue(min(yr, p.ny - 1), r);
+        } else if constexpr (BC_U8C) {
             // both mask slots are loaded unconditionally (an absent one re-reads the other and is ignored): a load inside a
             // wave-uniform branch makes the compiler wait vmcnt(0) where the branch joins, which would drain the pipelined rows
 #pragma unroll
@@ -104,7 +147,18 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     auto row_bc = [&](CfRow<E>& r) {
 #pragma unroll
         for (int n = 0; n < NW; ++n) r.keep[n] = 1.f;
-        if constexpr (BC_U8C) {
+        if constexpr (BC_PACKED) {
+            unsigned b0 = r.bx[0], b1 = r.bx[1];
+            if constexpr (NB == 2) { b0 |= (r.mb[0] >> bshift[0]) & bsel[0]; b1 |= (r.mb[1] >> bshift[1]) & bsel[1]; }
+            if constexpr (NB == 1) { const unsigned w = r.mb[0] >> bshift[0]; b0 |= w & bsel[0]; b1 |= w & bsel[1]; }
+            const float v0 = p.bc[0].value, v1 = p.bc[1].value;
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) {
+                r.u[n] = (b0 & (1u << n)) ? v0 : r.u[n];
+                r.u[n] = (b1 & (1u << n)) ? v1 : r.u[n];
+                if (n < NW) r.keep[n] = ((b0 | b1) & (1u << n)) ? 0.f : 1.f;
+            }
+        } else if constexpr (BC_U8C) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (DN_CF_PF || has_mask[k]) {
@@ -290,13 +344,19 @@ static void cf_launch_one(const PoissonParams& pp, const Geom2D& g, int batch, h
 
 template <int E, bool VEC>
 static void cf_launch_flags(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
-    const bool any = pp.bc[0].mask || pp.bc[1].mask;
-    bool u8c = any;
-    for (int k = 0; k < 2; ++k)
-        if (pp.bc[k].mask && (!pp.bc[k].mask_is_u8 || pp.bc[k].field)) u8c = false;
+    const bool any = pp.bc[0].kind >= 0 || pp.bc[1].kind >= 0;
+    bool u8c = any, packed = false;
+    for (int k = 0; k < 2; ++k) {
+        if (pp.bc[k].kind >= 0 && (!pp.bc[k].mask_is_u8 || pp.bc[k].field)) u8c = false;
+        if (pp.bc[k].kind == DN_MASK_BITS || pp.bc[k].kind == DN_MASK_BOX) packed = true;     // dn_poisson_apply admits no mix with mask images
+    }
+    const int nbits = (pp.bc[0].kind == DN_MASK_BITS) + (pp.bc[1].kind == DN_MASK_BITS);
     const int nf = (pp.nu ? CF_NU : 0) | (pp.f ? CF_F : 0);
 #define DN_CF(FLAGS)                                                                         \
     (!any ? cf_launch_one<E, VEC, (FLAGS)>(pp, g, batch, s)                                  \
+          : packed ? (nbits == 2 ? cf_launch_one<E, VEC, (FLAGS) | CF_BC_PACKED | CF_PK_NB2>(pp, g, batch, s)          \
+                     : nbits == 1 ? cf_launch_one<E, VEC, (FLAGS) | CF_BC_PACKED | CF_PK_NB1>(pp, g, batch, s)        \
+                                  : cf_launch_one<E, VEC, (FLAGS) | CF_BC_PACKED>(pp, g, batch, s))                   \
           : u8c ? cf_launch_one<E, VEC, (FLAGS) | CF_BC_U8C>(pp, g, batch, s)                \
                 : cf_launch_one<E, VEC, (FLAGS) | CF_BC>(pp, g, batch, s))
     switch (nf) {

@@ -11,6 +11,9 @@ struct DirichletDev {
     const float* field;
     float value;
     int mask_is_u8, mask_batched, field_batched;
+    int kind;              // DN_MASK_* of a present condition, -1 when absent
+    int box_faces;         // DN_MASK_BOX
+    int row_bytes;         // DN_MASK_BITS: bytes per node row
 };
 
 struct PoissonParams {
@@ -56,9 +59,12 @@ __device__ __forceinline__ SampleBases sample_bases(const PoissonParams& p, int 
     for (int k = 0; k < 2; ++k) {
         const DirichletDev& d = p.bc[k];
         const int64_t mo = d.mask_batched ? (int64_t)b * nps : 0;
-        s.mask[k] = d.mask ? (d.mask_is_u8 ? (const void*)(reinterpret_cast<const uint8_t*>(d.mask) + mo)
-                                           : (const void*)(reinterpret_cast<const float*>(d.mask) + mo))
-                           : nullptr;
+        if (d.kind == DN_MASK_BITS)        // bit-packed: rows of row_bytes bytes, ny * nz rows per sample
+            s.mask[k] = reinterpret_cast<const uint8_t*>(d.mask) + (d.mask_batched ? (int64_t)b * ((int64_t)p.ny * p.nz) * d.row_bytes : 0);
+        else
+            s.mask[k] = d.mask ? (d.mask_is_u8 ? (const void*)(reinterpret_cast<const uint8_t*>(d.mask) + mo)
+                                               : (const void*)(reinterpret_cast<const float*>(d.mask) + mo))
+                               : nullptr;
         s.field[k] = d.field ? d.field + (d.field_batched ? (int64_t)b * nps : 0) : nullptr;
     }
     return s;

@@ -374,6 +374,24 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     if (m->nsd == 3 && m->degree != 1) return DN_E_UNSUPPORTED;
     const int P = m->degree;
     if (m->ngp < (P == 1 ? 2 : 3)) return DN_E_UNSUPPORTED;
+    bool packed_bc = false;                   // bit-packed / geometry-derived conditions: 2-D Q1, nodal or absent forcing, constant values
+    for (int k = 0; k < 2; ++k) {
+        const dn_dirichlet& d = a->bc[k];
+        if (d.mask_kind < DN_MASK_F32 || d.mask_kind > DN_MASK_BOX) return DN_E_BADARG;
+        const bool present = d.mask_kind == DN_MASK_BOX ? d.box_faces != 0 : d.mask != nullptr;
+        if (present && (d.mask_kind == DN_MASK_BITS || d.mask_kind == DN_MASK_BOX)) {
+            packed_bc = true;
+            if (d.field) return DN_E_BADARG;
+            if (d.mask_kind == DN_MASK_BITS && d.row_words < (m->nx + 31) / 32) return DN_E_BADARG;
+        }
+    }
+    if (packed_bc) {
+        if (m->nsd != 2 || P != 1 || a->f_gp || config(CFG_Q1_RULE_KERNEL) != nullptr) return DN_E_UNSUPPORTED;
+        for (int k = 0; k < 2; ++k) {         // the compact form does not mix with per-node mask images
+            const dn_dirichlet& d = a->bc[k];
+            if (d.mask && (d.mask_kind == DN_MASK_F32 || d.mask_kind == DN_MASK_U8)) return DN_E_UNSUPPORTED;
+        }
+    }
     const bool want_red = a->energy || a->sumsq || a->energy_f32;
     auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
     // vector loads/stores of NW nodes are legal when every row segment start is NW-element aligned
@@ -381,7 +399,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         bool ok = (NW == 2 || NW == 4) && (m->nx % NW == 0) && aligned(a->u, 4 * NW) && aligned(a->nu, 4 * NW) &&
                   aligned(a->f, 4 * NW) && aligned(a->out, 4 * NW);
         for (int k = 0; k < 2; ++k)
-            ok = ok && aligned(a->bc[k].mask, a->bc[k].mask_is_u8 ? NW : 4 * NW) && aligned(a->bc[k].field, 4 * NW);
+            if (a->bc[k].mask_kind == DN_MASK_F32 || a->bc[k].mask_kind == DN_MASK_U8)
+                ok = ok && aligned(a->bc[k].mask, a->bc[k].mask_kind == DN_MASK_U8 ? NW : 4 * NW) && aligned(a->bc[k].field, 4 * NW);
         return ok;
     };
     const bool allow_e4 = vec_ok(4);
@@ -433,9 +452,13 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.u = a->u; pp.nu = a->nu; pp.f = a->f; pp.fgp = a->f_gp;
     pp.nu_batched = a->nu_batched; pp.f_batched = a->f_batched;
     for (int k = 0; k < 2; ++k) {
-        pp.bc[k].mask = a->bc[k].mask; pp.bc[k].field = a->bc[k].field; pp.bc[k].value = a->bc[k].value;
-        pp.bc[k].mask_is_u8 = a->bc[k].mask_is_u8; pp.bc[k].mask_batched = a->bc[k].mask_batched;
-        pp.bc[k].field_batched = a->bc[k].field_batched;
+        const dn_dirichlet& d = a->bc[k];
+        const bool present = d.mask_kind == DN_MASK_BOX ? d.box_faces != 0 : d.mask != nullptr;
+        pp.bc[k].mask = d.mask_kind == DN_MASK_BOX ? nullptr : d.mask; pp.bc[k].field = d.field; pp.bc[k].value = d.value;
+        pp.bc[k].mask_is_u8 = d.mask_kind == DN_MASK_U8; pp.bc[k].mask_batched = d.mask_batched;
+        pp.bc[k].field_batched = d.field_batched;
+        pp.bc[k].kind = present ? d.mask_kind : -1;
+        pp.bc[k].box_faces = d.box_faces; pp.bc[k].row_bytes = 4 * d.row_words;
     }
     pp.out_scale = a->out_scale; pp.out = a->out;
     pp.counter = reinterpret_cast<unsigned*>(a->workspace);

@@ -153,6 +153,89 @@ class Dirichlet:
         self.value = value
 
 
+class PackedMask:
+    """A Dirichlet mask held in HBM with ONE BIT per node (C ABI: DN_MASK_BITS, include/diffnet_hip.h) instead of the reference's
+    fp32 image (`DiffNet/datasets/parametric/images.py:30`): 1/8 B per node in the loss instead of 4.  Build it once when the
+    dataset is placed on the device: `PackedMask.pack(mask)` with mask (B|1, 1, *N) float32 / uint8 / bool on the GPU.  Usable
+    wherever a mask is: the 2-D Q1 fused kernels read the bits directly, every other path gets the (cached) uint8 image."""
+
+    def __init__(self, bits, shape):
+        self.bits = bits                    # int32 (B, rows per sample, row_words)
+        self.shape = tuple(shape)           # (B, 1, *N) of the image
+        self._u8 = None
+
+    @property
+    def row_words(self):
+        return int(self.bits.shape[-1])
+
+    @staticmethod
+    def pack(mask):
+        if not isinstance(mask, torch.Tensor) or not mask.is_cuda:
+            raise DiffNetHipError("PackedMask.pack needs a CUDA tensor")
+        m = mask.to(torch.uint8) if mask.dtype == torch.bool else mask
+        if m.dtype not in (torch.float32, torch.uint8):
+            raise TypeError("Dirichlet mask must be float32, uint8 or bool")
+        m = m.contiguous()
+        nx = m.shape[-1]
+        rows = m.numel() // nx
+        rw = (nx + 31) // 32
+        bits = torch.empty((m.shape[0], rows // m.shape[0], rw), dtype=torch.int32, device=m.device)
+        rc = _lib.lib().dn_pack_mask_bits(m.data_ptr(), _lib.MASK_U8 if m.dtype == torch.uint8 else _lib.MASK_F32, rows, nx, rw,
+                                          bits.data_ptr(), _stream(m))
+        _lib.check(rc, "dn_pack_mask_bits")
+        return PackedMask(bits, m.shape)
+
+    def image(self):
+        """The uint8 image (B|1, 1, *N), unpacked once."""
+        if self._u8 is None:
+            out = torch.empty(self.shape, dtype=torch.uint8, device=self.bits.device)
+            nx = self.shape[-1]
+            rc = _lib.lib().dn_unpack_mask_bits(self.bits.data_ptr(), out.numel() // nx, nx, self.row_words, out.data_ptr(), _stream(out))
+            _lib.check(rc, "dn_unpack_mask_bits")
+            self._u8 = out
+        return self._u8
+
+
+class BoxFaces:
+    """Dirichlet condition on faces of the domain box, derived from the geometry (C ABI: DN_MASK_BOX): no mask array is read at
+    all.  The reference builds these masks as images (`IBN/poisson-2d/parametric/IBN_2D.py:69-73`, `rectangles.py:16,232-233`).
+    faces: "all" or any of "xlo", "xhi", "ylo", "yhi", "zlo", "zhi" (x = last tensor axis)."""
+    _BITS = {"xlo": _lib.FACE_XLO, "xhi": _lib.FACE_XHI, "ylo": _lib.FACE_YLO, "yhi": _lib.FACE_YHI, "zlo": _lib.FACE_ZLO, "zhi": _lib.FACE_ZHI}
+
+    def __init__(self, faces="all"):
+        if isinstance(faces, str):
+            faces = list(self._BITS) if faces == "all" else [faces]
+        self.bits = 0
+        for f in faces:
+            self.bits |= self._BITS[f]
+        self._img = {}
+
+    def image(self, node_shape, device):
+        """The uint8 image (1, 1, *N) of the selected faces (cached per shape and device)."""
+        key = (tuple(node_shape), str(device))
+        img = self._img.get(key)
+        if img is None:
+            nsd = len(node_shape)
+            img = torch.zeros((1, 1, *node_shape), dtype=torch.uint8, device=device)
+            for ax, name in zip(range(nsd - 1, -1, -1), "xyz"):       # x is the last tensor axis
+                idx = [slice(None)] * (nsd + 2)
+                if self.bits & self._BITS[name + "lo"]:
+                    idx[2 + ax] = 0; img[tuple(idx)] = 1
+                if self.bits & self._BITS[name + "hi"]:
+                    idx[2 + ax] = -1; img[tuple(idx)] = 1
+            self._img[key] = img
+        return img
+
+
+def _mask_image(m, like):
+    """Any mask form -> tensor image usable in torch.where against `like` (B,1,*N)."""
+    if isinstance(m, PackedMask):
+        return m.image()
+    if isinstance(m, BoxFaces):
+        return m.image(like.shape[2:], like.device)
+    return m
+
+
 def _norm_dirichlet(dirichlet):
     out = []
     for d in dirichlet or ():
@@ -218,8 +301,26 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
         if tuple(f_gp.shape[1:]) != (geom.ngp_total, *geom.elem_shape):
             raise ValueError(f"f_gp must have shape (B|1,{geom.ngp_total},{geom.elem_shape})")
         args.f_gp, args.f_batched = f_gp.data_ptr(), fb
-    for k, d in enumerate(_norm_dirichlet(dirichlet)):
+    dl = _norm_dirichlet(dirichlet)
+    # bit-packed / geometry-derived conditions: read directly by the 2-D Q1 kernels with nodal or absent forcing when every
+    # condition of the call is one of them with a constant value; otherwise they are expanded to their (cached) uint8 images
+    compact = (nsd == 2 and geom.deg == 1 and f_gp is None and len(dl) > 0 and _lib.lib().dn_config_get(b"Q1_RULE_KERNEL") in (None, b"") and
+               all(isinstance(d.mask, (PackedMask, BoxFaces)) and not isinstance(d.value, torch.Tensor) for d in dl))
+    for k, d in enumerate(dl):
         m = d.mask
+        if compact:
+            bc = args.bc[k]
+            bc.value = float(d.value)
+            if isinstance(m, BoxFaces):
+                bc.mask_kind, bc.box_faces = _lib.MASK_BOX, m.bits
+            else:
+                if tuple(m.shape[1:]) != (1, *node_shape) or m.shape[0] not in (1, B) or m.bits.device != u.device:
+                    raise ValueError(f"packed Dirichlet mask of shape {m.shape} does not match u")
+                keep.append(m.bits)
+                bc.mask, bc.mask_kind, bc.row_words = m.bits.data_ptr(), _lib.MASK_BITS, m.row_words
+                bc.mask_batched = int(m.shape[0] == B)
+            continue
+        m = _mask_image(m, u)
         if not isinstance(m, torch.Tensor) or not m.is_cuda:
             raise DiffNetHipError("Dirichlet mask must be a CUDA tensor")
         if m.dtype == torch.bool:
@@ -232,7 +333,7 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
         keep.append(m)
         bc = args.bc[k]
         bc.mask = m.data_ptr()
-        bc.mask_is_u8 = int(m.dtype == torch.uint8)
+        bc.mask_kind = _lib.MASK_U8 if m.dtype == torch.uint8 else _lib.MASK_F32
         bc.mask_batched = int(m.shape[0] == B)
         if isinstance(d.value, torch.Tensor):
             v = d.value
@@ -308,7 +409,7 @@ def _apply_dirichlet(u, dirichlet):
             v = v.to(u.device).expand_as(u)
         else:
             v = torch.full_like(u, float(v))
-        u = torch.where(_dirichlet_cond(d.mask), v, u)
+        u = torch.where(_dirichlet_cond(_mask_image(d.mask, u)), v, u)
     return u
 
 
@@ -361,7 +462,7 @@ def composed_residual(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0
         fg = f_gp if f_gp is not None else ev(f, "N_gp")
         R = R - evT((wg * fg).expand(u.shape[0], -1, *fg.shape[2:]), "N_gp")
     for d in dirichlet:
-        R = torch.where(_dirichlet_cond(d.mask), torch.zeros_like(R), R)
+        R = torch.where(_dirichlet_cond(_mask_image(d.mask, R)), torch.zeros_like(R), R)
     return R
 
 
@@ -369,7 +470,7 @@ def _fused(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, l
     """(out, sums, loss) of one dn_poisson_apply launch as the registered operator diffnet_mi::poisson_apply: differentiable
     wrt u through all three outputs (torch_ops._pa_backward), an ordinary node for torch.compile."""
     from . import torch_ops
-    return torch_ops.poisson_apply(u, nu, f, f_gp, *torch_ops.dirichlet_args(dirichlet), *torch_ops.geometry_args(geom),
+    return torch_ops.poisson_apply(u, nu, f, f_gp, *torch_ops.dirichlet_args(dirichlet, u), *torch_ops.geometry_args(geom),
                                    float(alpha), float(beta), float(c), float(wscale), float(out_scale), float(loss_scale))
 
 

@@ -171,6 +171,8 @@ def poisson_apply(u: torch.Tensor, nu: Optional[torch.Tensor], f: Optional[torch
     d = []
     for m, fld, v in ((mask0, field0, value0), (mask1, field1, value1)):
         if m is not None:
+            if m.dtype == torch.int32:          # bit-packed mask (ops.PackedMask.bits): (B|1, node rows, row_words)
+                m = _ops.PackedMask(m, (m.shape[0], 1, *geom.node_shape))
             d.append(_ops.Dirichlet(m, fld if fld is not None else v))
     out, sums, loss = _ops.poisson_apply(geom, u, nu, f, f_gp, d, alpha=alpha, beta=beta, c=c, wscale=wscale, out_scale=out_scale,
                                          want_out=True, want_sums=True, loss_scale=loss_scale)
@@ -231,15 +233,27 @@ def geometry_args(geom):
     return geom.nsd, geom.deg, geom.ngp_1d, [int(s) for s in geom.sizes], [float(h) for h in geom.hs]
 
 
-def dirichlet_args(dirichlet):
-    """(mask0, field0, value0, mask1, field1, value1) from up to two Dirichlet conditions."""
+def dirichlet_args(dirichlet, like=None):
+    """(mask0, field0, value0, mask1, field1, value1) from up to two Dirichlet conditions.  The operator schema carries tensors
+    only: a PackedMask travels as its int32 bit tensor, BoxFaces as the (cached) bit-packed image of the faces (`like`: the
+    nodal field, for its shape and device)."""
     out = []
     ds = list(dirichlet) + [None] * (2 - len(dirichlet))
     for d in ds:
         if d is None:
             out += [None, None, 0.0]
-        elif isinstance(d.value, torch.Tensor):
-            out += [d.mask, d.value, 0.0]
+            continue
+        m = d.mask
+        if isinstance(m, _ops.BoxFaces):
+            key = ("bits", tuple(like.shape[2:]), str(like.device))
+            pm = m._img.get(key)
+            if pm is None:
+                pm = m._img[key] = _ops.PackedMask.pack(m.image(like.shape[2:], like.device))
+            m = pm
+        if isinstance(m, _ops.PackedMask):
+            m = m.bits if not isinstance(d.value, torch.Tensor) else m.image()
+        if isinstance(d.value, torch.Tensor):
+            out += [m, d.value, 0.0]
         else:
-            out += [d.mask, None, float(d.value)]
+            out += [m, None, float(d.value)]
     return out

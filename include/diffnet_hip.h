@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 5
+#define DN_ABI_VERSION 6
 
 #define DN_E_BADARG (-1)    /* null pointer / non-positive size / unsupported combination   */
 #define DN_E_UNSUPPORTED (-2) /* (nsd, degree, ngp) outside the compiled instantiations      */
@@ -64,15 +64,35 @@ typedef struct dn_mesh {
 /* One Dirichlet condition: u <- where(mask > 0.5, value, u) with value = field[node] when
  * `field` is non-null (broadcast over the batch when field_batched == 0) else the constant.
  * Mirrors the torch.where lines of the loss bodies, e.g. IBN/poisson-2d/parametric/IBN_2D.py:119-121,
- * examples/poisson/single_instance/e8_2d_poisson_mms.py:120. mask may be fp32 (reference) or u8. */
+ * examples/poisson/single_instance/e8_2d_poisson_mms.py:120.
+ * Mask formats (`mask_kind`):
+ *   DN_MASK_F32  the reference's fp32 image, compared with 0.5            (4 B per node)
+ *   DN_MASK_U8   uint8 / bool, non-zero = set                             (1 B per node)
+ *   DN_MASK_BITS one bit per node: node x of a node row is bit (x & 31) of 32-bit word (x >> 5) of that row, rows
+ *                `row_words` words apart (>= ceil(nx / 32)), rows of a sample contiguous, samples ny*[nz*]row_words words
+ *                apart -- what dn_pack_mask_bits() writes                 (1/8 B per node)
+ *   DN_MASK_BOX  no array at all: the condition holds on the domain faces named in `box_faces` (IBN_2D.py:69-73 builds exactly
+ *                this mask as an image, DiffNet/datasets/single_instances/rectangles.py:16,232-233 likewise); `mask` is ignored
+ * BITS and BOX take a constant `value` (field must be NULL) and are implemented by the 2-D Q1 kernels with nodal / absent
+ * forcing (the IBN_2D / bench path); every other kernel returns DN_E_UNSUPPORTED for them -- expand with dn_unpack_mask_bits(). */
+enum { DN_MASK_F32 = 0, DN_MASK_U8 = 1, DN_MASK_BITS = 2, DN_MASK_BOX = 3 };
+enum { DN_FACE_XLO = 1, DN_FACE_XHI = 2, DN_FACE_YLO = 4, DN_FACE_YHI = 8, DN_FACE_ZLO = 16, DN_FACE_ZHI = 32 };
 typedef struct dn_dirichlet {
-    const void *mask;     /* (B,1,*N) or (1,1,*N); NULL = condition absent              */
+    const void *mask;     /* (B,1,*N) or (1,1,*N); NULL = condition absent (DN_MASK_BOX: ignored) */
     const float *field;   /* optional Dirichlet values                                  */
     float value;
-    int32_t mask_is_u8;   /* 0: fp32 mask compared with 0.5, 1: uint8 (non-zero = set)  */
+    int32_t mask_kind;    /* DN_MASK_*  (0 / 1 keep their round-1 meaning "mask_is_u8") */
     int32_t mask_batched; /* 1: (B,...), 0: one mask shared by the whole batch          */
     int32_t field_batched;
+    int32_t box_faces;    /* DN_MASK_BOX: bit set of DN_FACE_*                          */
+    int32_t row_words;    /* DN_MASK_BITS: 32-bit words per node row                    */
 } dn_dirichlet;
+
+/* uint8 / fp32 mask image -> DN_MASK_BITS layout and back (one launch each; rows = B*ny[*nz] node rows of nx nodes).
+ * The reference keeps masks as fp32 images in its datasets (DiffNet/datasets/parametric/images.py:30); packing them once when
+ * the dataset is placed in HBM turns a 4 (or 1) B/node stream of the loss into 1/8 B/node. */
+int dn_pack_mask_bits(const void *mask, int32_t mask_kind, int64_t rows, int32_t nx, int32_t row_words, uint32_t *bits, void *stream);
+int dn_unpack_mask_bits(const uint32_t *bits, int64_t rows, int32_t nx, int32_t row_words, uint8_t *mask_u8, void *stream);
 
 /* Arguments of the fused Poisson operator
  *     out_a = zero_on_dirichlet( sum_e sum_g W_g ( alpha * nu_g * gradN_a . grad u_g  -  beta * N_a * f_g ) )
