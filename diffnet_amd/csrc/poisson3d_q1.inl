@@ -866,6 +866,225 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, TX * TY, red, &last_flag, (double)p.T.esc);
 }
 
+// =============================================================================================================
+// Third form (default for nodal / absent forcing and no or uint8 constant-value conditions): EVERY NODE IS REQUESTED ONCE per
+// workgroup and plane.  The T16 form above asks for every node four times (two rows x two columns of threads, misaligned
+// dwordx2 / ushort pairs): 182 TA-cycles per wave and layer, which is what bounds it (profiles/r2_3d_bottleneck.md).  Here a thread
+// loads only the node it owns -- aligned dword / byte loads, 4 rows x 16 lanes per wave-instruction --, applies the Dirichlet
+// conditions to it once, and publishes {u', nu, f, keep} as one 16-byte record in an LDS tile of 17 x 17 nodes; the 33 halo nodes
+// of the tile (column 16, row 16) are loaded 9 per wave by lanes 0..8 of the same unconditional instructions.  After the barrier
+// the hand-over needs anyway, a thread reads the four records of its element with ds_read_b128.  One barrier per layer:
+//     request plane k + 2  ->  gather + stage plane k + 1 from LDS  ->  layer k  ->  publish plane k + 2, hand-over  ->  barrier  ->  finish plane k
+// =============================================================================================================
+template <int NGP, int FL, bool UW>
+__global__ void __launch_bounds__(256, 5) poisson3d_q1n_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
+    constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, BC_U8C = (FL & FL3_BC_U8C) != 0;
+    static_assert((FL & (FL3_FGP | FL3_BC)) == 0, "node-owner form: nodal forcing, uint8 constant-value conditions");
+    constexpr int E = 1, NW = 1;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * 16 + tx;
+    unsigned lid = blockIdx.x;                    // XCD-aware decode, see poisson3d_q1m_kernel
+    {
+        const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
+        lid = xcd * base + min(xcd, rem) + idx;
+    }
+    const int chunk = (int)(lid % (unsigned)chunks_x);
+    lid /= (unsigned)chunks_x;
+    const int tile = (int)(lid % (unsigned)tiles_y);
+    lid /= (unsigned)tiles_y;
+    const int strip = (int)(lid % (unsigned)strips_z), b = (int)(lid / (unsigned)strips_z);
+    const int nx0 = chunk * 15, ny0 = tile * 15;               // first node of the tile
+    const int x0 = nx0 + tx, ey = ny0 + ty;                    // the thread's node == lower-left node of its element
+    const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);
+    const unsigned npl = (unsigned)(p.nx * p.ny);
+    const int64_t nps = (int64_t)npl * p.nz;
+    const SampleBases sb = sample_bases(p, b, nps);
+    const int R = p.rows_per_strip;
+    const int ez_own = strip * R;
+    const int ez_begin = ez_own > 0 ? ez_own - 1 : 0;
+    const int ez_end = min(ez_own + R, p.nelz);
+    const bool noderow_ok = ey < p.ny;
+    const float okf = (ey < p.nely && x0 < p.nelx) ? 1.f : 0.f;         // elements beyond the mesh: computed on clamped data, scaled by 0
+
+    __shared__ float4 rec[2][17 * 17];            // [plane parity][node row * 17 + node column] = {u after Dirichlet, nu, f, keep}
+    __shared__ float xch[2][256];
+    __shared__ double red[256 / 64 + 1];
+    __shared__ int last_flag;
+
+    // in-plane offsets (nodes, clamped into the mesh) of the node this thread owns and of the halo node it fetches
+    const unsigned own_off = (unsigned)min(ey, p.ny - 1) * (unsigned)p.nx + (unsigned)min(x0, p.nx - 1);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hidx = min(wave * 9 + min(lane, 8), 32);         // 33 halo nodes, 9 per wave (lanes 0..8; the other lanes repeat lane 8)
+    const int hrow = hidx < 16 ? hidx : 16, hcol = hidx < 16 ? 16 : hidx - 16;
+    const unsigned halo_off = (unsigned)min(ny0 + hrow, p.ny - 1) * (unsigned)p.nx + (unsigned)min(nx0 + hcol, p.nx - 1);
+    const bool halo_lane = lane < 9 && wave * 9 + lane < 33;
+    const int own_rec = ty * 17 + tx, halo_rec = hrow * 17 + hcol;
+
+    const bool has_mask[2] = {sb.mask[0] != nullptr, sb.mask[1] != nullptr};
+    const uint8_t* mask8[2];
+    mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);      // an absent condition re-reads the other one and is
+    mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);      // ignored: no load inside a wave-uniform branch
+
+    struct RawNodes { float u[2], n[2], f[2]; uint8_t m[2][2]; };       // [0] own node, [1] halo node
+    auto plane_request = [&](int zreq, RawNodes& W) {
+        const unsigned zoff = (unsigned)min(zreq, p.nz - 1) * npl;
+        const unsigned o[2] = {zoff + own_off, zoff + halo_off};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            W.u[h] = ld_at<float>(sb.u, o[h]);
+            if constexpr (HAS_NU) W.n[h] = ld_at<float>(sb.nu, o[h]);
+            if constexpr (HAS_F) W.f[h] = ld_at<float>(sb.f, o[h]);
+            if constexpr (BC_U8C) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) W.m[h][k] = ld_at<uint8_t>(mask8[k], o[h]);
+            }
+        }
+    };
+    auto plane_publish = [&](const RawNodes& W, int zpl) {
+        float4 r[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float uu = W.u[h], keep = 1.f;
+            if constexpr (BC_U8C) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const bool set = has_mask[k] && W.m[h][k] != 0;
+                    uu = set ? p.bc[k].value : uu;
+                    keep = set ? 0.f : keep;
+                }
+            }
+            r[h] = make_float4(uu, HAS_NU ? W.n[h] : 1.f, HAS_F ? W.f[h] : 0.f, keep);
+        }
+        rec[zpl & 1][own_rec] = r[0];
+        if (halo_lane) rec[zpl & 1][halo_rec] = r[1];
+    };
+    float keep_lo = 1.f, keep_up = 1.f;           // keep of the own node in the lower / upper plane of the current layer
+    auto plane_gather = [&](int zpl, PlaneW<NGP, 1>& S, float& keep) {
+        const float4* t = &rec[zpl & 1][own_rec];
+        const float4 a0 = t[0], a1 = t[1], b0 = t[17], b1 = t[18];
+        keep = a0.w;
+        stage_u3<NGP>(p.T, a0.x, a1.x, b0.x, b1.x, S.VU[0], S.VX[0], S.VY[0]);
+        if constexpr (HAS_NU) stage_w3<NGP, UW>(p.T, a0.y, a1.y, b0.y, b1.y, S.VN[0]);
+        if constexpr (HAS_F) stage_w3<NGP, UW>(p.T, a0.z, a1.z, b0.z, b1.z, S.VF[0]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    PlaneW<NGP, 1> SA, SB;
+    float cU[NGP][NGP], cX[NGP], cY[NGP];
+#pragma unroll
+    for (int j = 0; j < NGP; ++j) {
+        cX[j] = cY[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) {
+            cU[j][i] = 0.f;
+            SA.VN[0][j][i] = SB.VN[0][j][i] = T_W(p.T, j, UW) * T_W(p.T, i, UW);    // nu absent: the constant field 1
+            SA.VF[0][j][i] = SB.VF[0][j][i] = 0.f;
+        }
+    }
+
+    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
+    int par = 0;
+
+    // adjoint of stage_u3: cotangents of one plane's stage values -> contributions to the element's 2 x 2 nodes
+    auto plane_transpose = [&](const float (&tU)[NGP][NGP], const float (&tX)[NGP], const float (&tY)[NGP], float (&o)[2][2]) {
+        float s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) {
+            float sv = 0.f, t = 0.f;
+#pragma unroll
+            for (int j = 0; j < NGP; ++j) { sv += tU[j][i]; t = fmaf(p.T.b[j][1], tU[j][i], t); }
+            const float c1 = t + tY[i], c0 = sv - c1;
+            s0 += c0; t0 = fmaf(p.T.b[i][1], c0, t0);
+            s1 += c1; t1 = fmaf(p.T.b[i][1], c1, t1);
+        }
+        float sX = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) { sX += tX[j]; d1 = fmaf(p.T.b[j][1], tX[j], d1); }
+        const float g01 = t0 + (sX - d1), g11 = t1 + d1;
+        o[0][1] = okf * g01; o[0][0] = okf * (s0 - g01);
+        o[1][1] = okf * g11; o[1][0] = okf * (s1 - g11);
+    };
+
+    const unsigned out_row = (unsigned)ey * (unsigned)p.nx;
+    const int from_left = (int)(((unsigned)tid - 1u) & 63u) << 2;
+    const float nfirst = tx > 0 ? 1.f : 0.f;
+    float pend_v = 0.f;
+    unsigned pend_off = 0u;
+    bool pend_st = false;
+    auto flush_store = [&]() {
+        if (pend_st) st_at<float>(sb.out, pend_off, pend_v);
+        pend_st = false;
+    };
+    // hand the finished contributions over, (optionally) publish the plane requested at the top of the layer, ONE barrier, finish the node
+    auto emit_plane = [&](const float (&o)[2][2], float keep, int z, bool owned_plane, const RawNodes* W, int zpub) {
+        const float left = lane_from_left(o[0][1], from_left, nfirst);
+        xch[par][tid] = o[1][0] + lane_from_left(o[1][1], from_left, nfirst);
+        if (W != nullptr) plane_publish(*W, zpub);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float t = o[0][0] + left;
+        if (ty > 0) t += xch[par][tid - 16];
+        t *= keep;
+        const bool st = owned_plane && owner && noderow_ok;
+        sq_acc = st ? fmaf(t, t, sq_acc) : sq_acc;
+        pend_v = t * p.out_scale;
+        pend_off = (unsigned)z * npl + out_row + (unsigned)x0;
+        pend_st = st && sb.out != nullptr && x0 < p.nx;
+        par ^= 1;
+    };
+    auto layer = [&](int ez, const PlaneW<NGP, 1>& L, const PlaneW<NGP, 1>& U, float keep, const RawNodes* W) {
+        const bool own_layer = ez >= ez_own;
+        const float cnt = (own_layer && owner) ? 1.f : 0.f;
+        float o[2][2], fg[1] = {0.f};
+        float tU[NGP][NGP], tX[NGP], tY[NGP], e1, e2;
+        q1_layer_3d_w<NGP, false, HAS_F, UW>(p.T, L.VU[0], U.VU[0], L.VX[0], U.VX[0], L.VY[0], U.VY[0], L.VN[0], U.VN[0], L.VF[0], U.VF[0],
+                                             fg, cU, cX, cY, tU, tX, tY, e1, e2);
+        asm volatile("" : "+v"(e1), "+v"(e2));
+        e1_acc = fmaf(cnt * okf, e1, e1_acc);
+        e2_acc = fmaf(cnt * okf, e2, e2_acc);
+        plane_transpose(tU, tX, tY, o);
+        __builtin_amdgcn_sched_barrier(0);
+        emit_plane(o, keep, ez, own_layer, W, ez + 2);
+    };
+
+    // prologue: planes ez_begin and ez_begin + 1 into LDS, the lower one staged
+    RawNodes W;
+    plane_request(ez_begin, W);
+    plane_publish(W, ez_begin);
+    plane_request(ez_begin + 1, W);
+    __syncthreads();
+    plane_gather(ez_begin, SA, keep_lo);
+    plane_publish(W, ez_begin + 1);
+    __syncthreads();
+    int ez = ez_begin;
+#pragma nounroll
+    for (; ez + 1 < ez_end; ez += 2) {
+        plane_request(ez + 2, W);                 // lands while this layer is computed; published before the layer's barrier
+        flush_store();
+        plane_gather(ez + 1, SB, keep_up);
+        layer(ez, SA, SB, keep_lo, &W);
+        plane_request(ez + 3, W);
+        flush_store();
+        plane_gather(ez + 2, SA, keep_lo);
+        layer(ez + 1, SB, SA, keep_up, &W);
+    }
+    bool odd = false;
+    if (ez < ez_end) {
+        flush_store();
+        plane_gather(ez + 1, SB, keep_up);
+        layer(ez, SA, SB, keep_lo, nullptr);
+        odd = true;
+    }
+    flush_store();
+    if (ez_end == p.nelz) {       // the last strip owns the top boundary plane: only the layer below contributes
+        float o[2][2];
+        plane_transpose(cU, cX, cY, o);
+        emit_plane(o, odd ? keep_up : keep_lo, p.nz - 1, true, nullptr, 0);
+        flush_store();
+    }
+
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, 256, red, &last_flag, (double)p.T.esc);
+}
+
 // ---- dispatch ---------------------------------------------------------------------------------------------
 template <int NGP, int E, bool VEC, int FL>
 static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
@@ -876,6 +1095,18 @@ static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hip
     }
     bool unit = true;                                   // the exact 2-point rule: all weights 1
     for (int i = 0; i < NGP; ++i) unit = unit && pp.T.w[i] == 1.0f;
+    if constexpr (E == 1 && (FL & (FL3_FGP | FL3_BC)) == 0) {
+        if (g.TX == 16 && g.TY == 16 && pp.nx >= 2 && config(CFG_Q1_3D_T16) == nullptr) {      // node-owner form (every node requested once)
+            if constexpr (NGP == 2) {
+                if (unit) {
+                    hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL, false>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+            return;
+        }
+    }
     if constexpr (E == 1) {
         if (g.TX == 16 && pp.nx >= 2) {                // 16-wide tiles, one element per thread: DPP hand-over, paired loads
             if constexpr (NGP == 2) {
