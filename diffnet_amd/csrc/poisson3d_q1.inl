@@ -876,8 +876,17 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
 // the hand-over needs anyway, a thread reads the four records of its element with ds_read_b128.  One barrier per layer:
 //     request plane k + 2  ->  gather + stage plane k + 1 from LDS  ->  layer k  ->  publish plane k + 2, hand-over  ->  barrier  ->  finish plane k
 // =============================================================================================================
+#ifndef DN_TAB_VGPR
+#define DN_TAB_VGPR 0             // 1: 1-D tables in vector registers (103 VGPRs, 4 waves): measured equal (profiles/r2_prio3d.txt), off
+#endif
+#ifndef DN_Q1N_WAVES
+#define DN_Q1N_WAVES 5
+#endif
+#ifndef DN_PRIO3D
+#define DN_PRIO3D 0               // 1 / 2: static / rotating wave priorities per workgroup: measured equal (profiles/r2_prio3d.txt), off
+#endif
 template <int NGP, int FL, bool UW>
-__global__ void __launch_bounds__(256, 5) poisson3d_q1n_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
+__global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
     constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, BC_U8C = (FL & FL3_BC_U8C) != 0;
     static_assert((FL & (FL3_FGP | FL3_BC)) == 0, "node-owner form: nodal forcing, uint8 constant-value conditions");
     constexpr int E = 1, NW = 1;
@@ -906,6 +915,23 @@ __global__ void __launch_bounds__(256, 5) poisson3d_q1n_kernel(const PoissonPara
     const bool noderow_ok = ey < p.ny;
     const float okf = (ey < p.nely && x0 < p.nelx) ? 1.f : 0.f;         // elements beyond the mesh: computed on clamped data, scaled by 0
 
+    // DN_TAB_VGPR: the 1-D tables the loop multiplies with in VECTOR registers.  In isolation a VALU instruction with an SGPR operand
+    // does not pair with another wave's instruction on gfx950 (3.8 SIMD-cycles per instruction at 90 % SGPR-operand share against
+    // 2.3 with none, tools/micro/valu_sgpr.hip, profiles/r2_valu_sgpr.txt) and half of this loop's instructions read a table
+    // entry -- but this kernel's waves do not pair anyway (its layer period is the sum of its phases), so the switch measured equal.
+    ElemTab TV = p.T;
+#if DN_TAB_VGPR
+#define DN_V(x) asm volatile("" : "+v"(x))
+#pragma unroll
+    for (int j = 0; j < NGP; ++j) {
+        DN_V(TV.b[j][1]);
+        if constexpr (!UW) { DN_V(TV.w[j]); DN_V(TV.wb[j]); }
+    }
+    DN_V(TV.m[1]); DN_V(TV.m01);
+    if constexpr (HAS_F) { DN_V(TV.m[2]); DN_V(TV.m12); DN_V(TV.nbw); }
+    DN_V(TV.kap[0]); DN_V(TV.kap[1]); DN_V(TV.kap[2]);
+#undef DN_V
+#endif
     __shared__ float4 rec[2][17 * 17];            // [plane parity][node row * 17 + node column] = {u after Dirichlet, nu, f, keep}
     __shared__ float xch[2][256];
     __shared__ double red[256 / 64 + 1];
@@ -963,9 +989,9 @@ __global__ void __launch_bounds__(256, 5) poisson3d_q1n_kernel(const PoissonPara
         const float4* t = &rec[zpl & 1][own_rec];
         const float4 a0 = t[0], a1 = t[1], b0 = t[17], b1 = t[18];
         keep = a0.w;
-        stage_u3<NGP>(p.T, a0.x, a1.x, b0.x, b1.x, S.VU[0], S.VX[0], S.VY[0]);
-        if constexpr (HAS_NU) stage_w3<NGP, UW>(p.T, a0.y, a1.y, b0.y, b1.y, S.VN[0]);
-        if constexpr (HAS_F) stage_w3<NGP, UW>(p.T, a0.z, a1.z, b0.z, b1.z, S.VF[0]);
+        stage_u3<NGP>(TV, a0.x, a1.x, b0.x, b1.x, S.VU[0], S.VX[0], S.VY[0]);
+        if constexpr (HAS_NU) stage_w3<NGP, UW>(TV, a0.y, a1.y, b0.y, b1.y, S.VN[0]);
+        if constexpr (HAS_F) stage_w3<NGP, UW>(TV, a0.z, a1.z, b0.z, b1.z, S.VF[0]);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -977,7 +1003,7 @@ __global__ void __launch_bounds__(256, 5) poisson3d_q1n_kernel(const PoissonPara
 #pragma unroll
         for (int i = 0; i < NGP; ++i) {
             cU[j][i] = 0.f;
-            SA.VN[0][j][i] = SB.VN[0][j][i] = T_W(p.T, j, UW) * T_W(p.T, i, UW);    // nu absent: the constant field 1
+            SA.VN[0][j][i] = SB.VN[0][j][i] = T_W(TV, j, UW) * T_W(TV, i, UW);    // nu absent: the constant field 1
             SA.VF[0][j][i] = SB.VF[0][j][i] = 0.f;
         }
     }
@@ -992,14 +1018,14 @@ __global__ void __launch_bounds__(256, 5) poisson3d_q1n_kernel(const PoissonPara
         for (int i = 0; i < NGP; ++i) {
             float sv = 0.f, t = 0.f;
 #pragma unroll
-            for (int j = 0; j < NGP; ++j) { sv += tU[j][i]; t = fmaf(p.T.b[j][1], tU[j][i], t); }
+            for (int j = 0; j < NGP; ++j) { sv += tU[j][i]; t = fmaf(TV.b[j][1], tU[j][i], t); }
             const float c1 = t + tY[i], c0 = sv - c1;
-            s0 += c0; t0 = fmaf(p.T.b[i][1], c0, t0);
-            s1 += c1; t1 = fmaf(p.T.b[i][1], c1, t1);
+            s0 += c0; t0 = fmaf(TV.b[i][1], c0, t0);
+            s1 += c1; t1 = fmaf(TV.b[i][1], c1, t1);
         }
         float sX = 0.f, d1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NGP; ++j) { sX += tX[j]; d1 = fmaf(p.T.b[j][1], tX[j], d1); }
+        for (int j = 0; j < NGP; ++j) { sX += tX[j]; d1 = fmaf(TV.b[j][1], tX[j], d1); }
         const float g01 = t0 + (sX - d1), g11 = t1 + d1;
         o[0][1] = okf * g01; o[0][0] = okf * (s0 - g01);
         o[1][1] = okf * g11; o[1][0] = okf * (s1 - g11);
@@ -1036,7 +1062,7 @@ __global__ void __launch_bounds__(256, 5) poisson3d_q1n_kernel(const PoissonPara
         const float cnt = (own_layer && owner) ? 1.f : 0.f;
         float o[2][2], fg[1] = {0.f};
         float tU[NGP][NGP], tX[NGP], tY[NGP], e1, e2;
-        q1_layer_3d_w<NGP, false, HAS_F, UW>(p.T, L.VU[0], U.VU[0], L.VX[0], U.VX[0], L.VY[0], U.VY[0], L.VN[0], U.VN[0], L.VF[0], U.VF[0],
+        q1_layer_3d_w<NGP, false, HAS_F, UW>(TV, L.VU[0], U.VU[0], L.VX[0], U.VX[0], L.VY[0], U.VY[0], L.VN[0], U.VN[0], L.VF[0], U.VF[0],
                                              fg, cU, cX, cY, tU, tX, tY, e1, e2);
         asm volatile("" : "+v"(e1), "+v"(e2));
         e1_acc = fmaf(cnt * okf, e1, e1_acc);
@@ -1056,8 +1082,36 @@ __global__ void __launch_bounds__(256, 5) poisson3d_q1n_kernel(const PoissonPara
     plane_publish(W, ez_begin + 1);
     __syncthreads();
     int ez = ez_begin;
+    // Wave priorities against lock-step: workgroups that start together and do identical work fall into phase (all request, then all
+    // gather, then all compute: the layer period becomes the SUM of the VALU, TA and LDS times instead of their maximum).  Different
+    // priorities for the workgroups resident on a CU let one run ahead through its arithmetic while the others use the memory paths.
+    const int prio_hash = (int)((blockIdx.x >> 8) & 3u);
+    auto set_prio = [&](int step) {
+#if DN_PRIO3D == 1
+        (void)step;
+        switch (prio_hash) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#elif DN_PRIO3D == 2
+        switch ((prio_hash + (step >> 1)) & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#else
+        (void)step;
+#endif
+    };
+    set_prio(0);
 #pragma nounroll
     for (; ez + 1 < ez_end; ez += 2) {
+#if DN_PRIO3D == 2
+        set_prio(ez - ez_begin);
+#endif
         plane_request(ez + 2, W);                 // lands while this layer is computed; published before the layer's barrier
         flush_store();
         plane_gather(ez + 1, SB, keep_up);
