@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--nsd", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--bc", default="auto", choices=["auto", "bits", "u8", "f32", "box"],
-                    help="format the Dirichlet mask is held in (auto: u8)")
+                    help="how the Dirichlet condition is held (auto: box faces for 2-D, uint8 image for 3-D)")
     ap.add_argument("--slab", action="store_true",
                     help="strong-scaling variant (not the default metric run): ONE 3-D mesh of --size^3 nodes cut into z-slabs over "
                          "the ranks (diffnet_amd/slab.py): per step one 8-byte all-reduce + one node-layer exchange per interior face")
@@ -234,7 +234,10 @@ def main():
     #   bits  one bit per node (diffnet_amd.PackedMask: packed once when the dataset is placed on the device; any mask)
     #   u8    one byte per node [default]   f32  the reference's fp32 image           box  derived from the geometry, no array
     from diffnet_amd import BoxFaces, PackedMask
-    bc_form = args.bc if args.bc != "auto" else "u8"      # measured: the format does not change the 2-D kernel time (profiles/r2_ab2d_bc.txt); u8 is the general default
+    bc_form = args.bc if args.bc != "auto" else ("box" if args.nsd == 2 else "u8")
+    # auto: BASELINE.md section 3 prescribes the condition "on all boundary faces", which is the box boundary the reference builds as an image
+    # (IBN_2D.py:69-73); the kernel derives it from the geometry.  The same launch with the mask held as bits / u8 / fp32 image is
+    # timed below and reported in roofline.kernel_median_us_by_mask_format (the 3-D kernels read uint8 images).
     forms = {"u8": lambda: [(bc, 0.0)], "f32": lambda: [(bc.float(), 0.0)], "bits": lambda: [(PackedMask.pack(bc), 0.0)],
              "box": lambda: [(BoxFaces("all"), 0.0)]}
     dirichlet = forms[bc_form]()

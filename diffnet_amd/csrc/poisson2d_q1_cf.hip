@@ -27,10 +27,11 @@ enum : int { CF_NU = 1, CF_F = 2, CF_BC = 8, CF_BC_U8C = 16, CF_BC_PACKED = 32, 
 template <int E>
 struct CfRow {
     float u[E + 1], n[E + 1], f[E + 1];
+    float g[E + 1];          // x-stage of the forcing term: (1-D element mass matrix in x) applied to f over the thread's own elements
     float keep[E];
     BcRaw<E> bc;
     uint32_t m8[2][2];
-    uint32_t mb[2];          // CF_BC_PACKED: the 2-byte windows of the bit arrays that hold the thread's E + 1 nodes of this row
+    uint32_t mb[2];          // CF_BC_PACKED: bits of the row's nodes x0, x0 + 1, ... from the bit arrays (bit n = node x0 + n)
     uint32_t bx[2];          //                 box-face bits of those nodes, per condition
 };
 
@@ -43,6 +44,9 @@ struct CfRow {
 
 #ifndef DN_CF_DPPX
 #define DN_CF_DPPX 0              // 1: E = 4 takes the shared node x0 + 4 over DPP from the neighbouring lane instead of a strided per-lane load; measured equal (profiles/r2_2d_ab.txt)
+#endif
+#ifndef DN_CF_FMASS
+#define DN_CF_FMASS 1
 #endif
 #ifndef DN_CF_PF
 #define DN_CF_PF 0                // 1: software-pipelined rows (row k + 2 in flight while layer k is computed); measured equal (profiles/r2_2d_ab.txt), off: 79 instead of 102 VGPRs
@@ -84,15 +88,19 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     const unsigned bsel[2] = {isbits[0] ? NBITS : 0u, isbits[1] ? NBITS : 0u};
     // load slot j reads the bit array of condition src[j]; with one array it is whichever condition has it
     const int src0 = (NB == 2 || isbits[0]) ? 0 : 1;
-    const uint8_t* bptr[2] = {reinterpret_cast<const uint8_t*>(sb.mask[src0]), reinterpret_cast<const uint8_t*>(sb.mask[1])};
-    const unsigned brow[2] = {(unsigned)p.bc[src0].row_bytes, (unsigned)p.bc[1].row_bytes};
-    unsigned bbyte[2], bshift[2], boxx[2] = {0u, 0u};
+    const uint32_t* bptr[2] = {reinterpret_cast<const uint32_t*>(sb.mask[src0]), reinterpret_cast<const uint32_t*>(sb.mask[1])};
+    // two ALIGNED dwords per bit array and row (the word that holds node x0 and the next one; 8 lanes share an address) and one
+    // v_alignbit: an unaligned 2-byte window costs the address path 16 cycles per wave-instruction, an aligned dword 4.5
+    const unsigned brow[2] = {(unsigned)p.bc[src0].row_bytes / 4u, (unsigned)p.bc[1].row_bytes / 4u};       // words per node row
+    unsigned bw0[2], bw1[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int rb = max((int)brow[j], 2);
-        bbyte[j] = (unsigned)min(x0 >> 3, rb - 2);                    // 2-byte window inside the row that holds bits x0 .. x0 + NW
-        bshift[j] = min((unsigned)x0 - 8u * bbyte[j], 31u);           // > 15 only for threads right of the mesh
+        const int rw = max((int)brow[j], 1);
+        bw0[j] = (unsigned)min(x0 >> 5, rw - 1);
+        bw1[j] = (unsigned)min((x0 >> 5) + 1, rw - 1);
     }
+    const unsigned bsh = (unsigned)x0 & 31u;
+    unsigned boxx[2] = {0u, 0u};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int faces = p.bc[k].kind == DN_MASK_BOX ? p.bc[k].box_faces : 0;
@@ -108,7 +116,11 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
                         (p.bc[1].kind == DN_MASK_BOX && (p.bc[1].box_faces & DN_FACE_YHI)) ? p.ny - 1 : -1};
     auto packed_issue = [&](int yc, CfRow<E>& r) {                   // yc: node row, already clamped into the mesh
 #pragma unroll
-        for (int j = 0; j < NB; ++j) r.mb[j] = (uint32_t)ld_at<uint16_t>(bptr[j], (unsigned)yc * brow[j] + bbyte[j]);
+        for (int j = 0; j < NB; ++j) {
+            const unsigned ro = (unsigned)yc * brow[j];
+            const uint32_t w0 = ld_at<uint32_t>(bptr[j], ro + bw0[j]), w1 = ld_at<uint32_t>(bptr[j], ro + bw1[j]);
+            r.mb[j] = __builtin_amdgcn_alignbit(w1, w0, bsh);          // bit n = node x0 + n
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) r.bx[k] = (yc == ylo[k] || yc == yhi[k]) ? NBITS : boxx[k];
     };
@@ -149,8 +161,8 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         for (int n = 0; n < NW; ++n) r.keep[n] = 1.f;
         if constexpr (BC_PACKED) {
             unsigned b0 = r.bx[0], b1 = r.bx[1];
-            if constexpr (NB == 2) { b0 |= (r.mb[0] >> bshift[0]) & bsel[0]; b1 |= (r.mb[1] >> bshift[1]) & bsel[1]; }
-            if constexpr (NB == 1) { const unsigned w = r.mb[0] >> bshift[0]; b0 |= w & bsel[0]; b1 |= w & bsel[1]; }
+            if constexpr (NB == 2) { b0 |= r.mb[0] & bsel[0]; b1 |= r.mb[1] & bsel[1]; }
+            if constexpr (NB == 1) { b0 |= r.mb[0] & bsel[0]; b1 |= r.mb[0] & bsel[1]; }
             const float v0 = p.bc[0].value, v1 = p.bc[1].value;
 #pragma unroll
             for (int n = 0; n <= NW; ++n) {
@@ -210,15 +222,46 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     const float my0 = p.T.m[0], my1 = p.T.m[1], my2 = p.T.m[2], my3 = p.T.m[3];
     const float k0 = p.T.q1c[0], k1 = p.T.q1c[1], h0 = p.T.q1c[2], h1 = p.T.q1c[3], nb = -p.T.beta;
 
+    // forcing term as a tensor-product mass matrix applied row by row (14 instead of 28 instructions per element: -11 % VALU instructions,
+    // time unchanged -- the kernel moves its ~312 MB at 5.45 TB/s whatever the arithmetic costs, profiles/r2_ab2d_fmass.txt); not in the
+    // generic mask / value-field form, whose register budget it would push from 4 to 3 waves per SIMD
+    constexpr bool FMASS = HAS_F && DN_CF_FMASS && (FL & CF_BC) == 0;
+    const float cx00 = p.T.q1mx[0], cx01 = p.T.q1mx[1], cx11 = p.T.q1mx[2], cy00 = p.T.q1my[0], cy01 = p.T.q1my[1], cy11 = p.T.q1my[2];
+    // sum_g W_g f_g N_a(g) with f bilinear is (mass_x (x) mass_y) f.  x-stage, once per node row: g[n] = the row's forcing seen through
+    // the thread's own elements (elements beyond the mesh excluded; the node shared with the right neighbour gets the rest over the
+    // hand-over that o[] takes anyway, by linearity)
+    auto fstage = [&](CfRow<E>& r) {
+        if constexpr (FMASS) {
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) r.g[n] = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (ex0 + e < p.nelx) {
+                    r.g[e] = fmaf(cx01, r.f[e + 1], fmaf(cx00, r.f[e], r.g[e]));
+                    r.g[e + 1] = fmaf(cx11, r.f[e + 1], cx01 * r.f[e]);
+                }
+            }
+        }
+    };
+
     // one element layer between the lower row L (Dirichlet applied) and the freshly landed upper row U; cin holds the
     // contributions of the layer below to L's nodes, cout receives this layer's contributions to U's nodes
     auto layer = [&](int ey, const CfRow<E>& L, CfRow<E>& U, const float (&cin)[NW + 1], float (&cout)[NW + 1]) {
         const bool own_layer = ey >= ey_own;
         const float cnt = (own_layer && col_owner) ? 1.f : 0.f;
-        if (!DN_CF_PF) row_bc(U);
+        if (!DN_CF_PF) { row_bc(U); fstage(U); }
         float o[NW + 1], le1 = 0.f, le2 = 0.f;
 #pragma unroll
         for (int n = 0; n <= NW; ++n) { o[n] = cin[n]; cout[n] = 0.f; }
+        if constexpr (FMASS) {            // y-stage of the forcing term for the whole row segment, and its energy  u . (M f)
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) {
+                const float tlo = fmaf(cy01, U.g[n], cy00 * L.g[n]), tup = fmaf(cy11, U.g[n], cy01 * L.g[n]);
+                o[n] = fmaf(nb, tlo, o[n]);
+                cout[n] = nb * tup;
+                le2 = fmaf(U.u[n], tup, fmaf(L.u[n], tlo, le2));
+            }
+        }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             if (ex0 + e < p.nelx) {       // elements beyond the domain are skipped (and: scheduling fence between elements)
@@ -237,7 +280,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
                 const float tY0 = fmaf(UXY, B1, UY * B0), tY1 = fmaf(UXY, B2, UY * B1);
                 le1 += fmaf(h1, fmaf(UXY, tY1, UY * tY0), h0 * fmaf(UXY, tX1, UX * tX0));
                 float cU0 = 0.f, cUX = k0 * tX0, cUY = k1 * tY0, cUXY = fmaf(k0, tX1, k1 * tY1);
-                if constexpr (HAS_F) {
+                if constexpr (HAS_F && !FMASS) {
                     const float F0 = L.f[e], FX = L.f[e + 1] - F0, FY = U.f[e] - F0, FXY = (U.f[e + 1] - U.f[e]) - FX;
                     const float S0 = fmaf(mx1, FX, mx0 * F0), S1 = fmaf(mx1, FXY, mx0 * FY);
                     const float T0 = fmaf(mx2, FX, mx1 * F0), T1 = fmaf(mx2, FXY, mx1 * FY);
@@ -278,6 +321,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     for (int n = 0; n <= NW; ++n) carryA[n] = carryB[n] = 0.f;
     row_issue(ey_begin, RA);
     row_bc(RA);
+    fstage(RA);
     int ey = ey_begin;
     bool odd = false;
 #if DN_CF_PF
@@ -287,6 +331,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         auto consume = [&](CfRow<E>& r) {
             r = W;
             row_bc(r);
+            fstage(r);
         };
         row_issue(ey_begin + 1, W);
         for (; ey + 1 < ey_end; ey += 2) {

@@ -48,6 +48,9 @@ struct ElemTab {
     float m01, m12;      // m[0] - m[1], m[1] - m[2]
     float esc;           // wscale: factor of both energy sums of the second-form kernel (1 for the other kernels)
     float nbw;           // -beta * wscale
+    // closed-form 2-D Q1 kernel: the 1-D element mass matrix [[c00, c01], [c01, c11]] = sum_g w_g [(1-b)^2, b(1-b); b(1-b), b^2] of the
+    // rule (from its moments, in double): the forcing term is (mass_x (x) mass_y) f, applied axis by axis (x carries wscale)
+    float q1mx[3], q1my[3];   // c00, c01, c11
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -434,6 +434,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
             const double bb = m->basis[g][1];
             mm[0] += m->gpw[g]; mm[1] += m->gpw[g] * bb; mm[2] += m->gpw[g] * bb * bb; mm[3] += m->gpw[g] * bb * bb * bb;
         }
+        pp.T.q1my[0] = (float)(mm[0] - 2.0 * mm[1] + mm[2]); pp.T.q1my[1] = (float)(mm[1] - mm[2]); pp.T.q1my[2] = (float)mm[2];
+        for (int r = 0; r < 3; ++r) pp.T.q1mx[r] = (float)((double)(r == 0 ? mm[0] - 2.0 * mm[1] + mm[2] : (r == 1 ? mm[1] - mm[2] : mm[2])) * (double)a->wscale);
         for (int r = 0; r < 4; ++r) {
             pp.T.m[r] = (float)mm[r];
             pp.T.mxs[r] = (float)(mm[r] * (double)a->wscale);

@@ -49,7 +49,8 @@ def test_compact_conditions_equal_the_mask_images_bitwise(kw, with_nu_f):
     nu = cu(seeded((B, 1, n, n), 2) + 0.5) if with_nu_f else None
     f = cu(seeded((B, 1, n, n), 3)) if with_nu_f else None
     src = rand_mask((B, 1, n, n), 7).to(torch.uint8).to(dev())        # immersed "source", per sample (IBN_2D.py:119)
-    box = boundary_mask((1, 1, n, n)).to(dev())                        # exterior "sink" = the box boundary (IBN_2D.py:69-73)
+    box = boundary_mask((1, 1, n, n)).to(torch.uint8).to(dev())        # exterior "sink" = the box boundary (IBN_2D.py:69-73)
+    # (uint8 images: the fp32-image form of the kernel sums the forcing term per element instead of per row -- equal to rounding, not bitwise)
     ref_loss, ref_grad = m.energy_loss_and_grad(u, nu, f, dirichlet=[(src, 1.0), (box, 0.0)], c=1.0)
     forms = {"bits+box": [(PackedMask.pack(src), 1.0), (BoxFaces("all"), 0.0)],
              "bits+bits": [(PackedMask.pack(src), 1.0), (PackedMask.pack(box), 0.0)],

@@ -4,7 +4,7 @@ import os
 import sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM, _lib   # noqa: E402
+from diffnet_amd import BoxFaces, DiffNet2DFEM, DiffNet3DFEM, PackedMask, _lib   # noqa: E402
 
 nsd, n, B, ngp = (int(v) for v in sys.argv[1:5])
 plan = sys.argv[5] if len(sys.argv) > 5 else ""
@@ -20,7 +20,9 @@ for d in range(2, len(shape)):
     idx = [slice(None)] * len(shape); idx[d] = 0; bc[tuple(idx)] = 1; idx[d] = -1; bc[tuple(idx)] = 1
 if plan:
     _lib.config_set("PLAN3D" if nsd == 3 else "PLAN2D", plan)
+form = os.environ.get("DN_BC_FORM", "u8")          # how the Dirichlet condition is held: u8 | bits | box | f32
+dirichlet = {"u8": [(bc, 0.0)], "f32": [(bc.float(), 0.0)], "bits": [(PackedMask.pack(bc), 0.0)], "box": [(BoxFaces(), 0.0)]}[form]
 for _ in range(reps):
-    m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+    m.energy_loss_and_grad(u, nu, f, dirichlet=dirichlet, c=1.0)
 torch.cuda.synchronize()
 print("done")
