@@ -98,9 +98,11 @@ def test_energy_ibn2d(tag):
     # the non-autograd single-pass entry point returns the same pair
     v2, g2 = m.energy_loss_and_grad(cu(z["u"]), None, f, dirichlet=[(src, 1.0), (sink, 0.0)], c=1.0)
     assert torch.equal(v2, v.detach()) and torch.equal(g2, g)
-    # uint8 / bool masks are equivalent to the reference's float masks
+    # uint8 / bool masks are equivalent to the reference's float masks (to rounding: the uint8 form of the kernel sums the forcing
+    # term row by row, the fp32-image form element by element)
     v3, g3 = m.energy_loss_and_grad(cu(z["u"]), None, f, dirichlet=[(src > 0.5, 1.0), ((sink > 0.5).to(torch.uint8), 0.0)], c=1.0)
-    assert torch.equal(v3, v2) and torch.equal(g3, g2)
+    np.testing.assert_allclose(float(v3), float(v2), rtol=2e-6)
+    close(g3, g2.cpu().numpy(), rtol=2e-6, arel=2e-6)
 
 
 @pytest.mark.parametrize("tag", ["n17", "n33", "n17_g3"])
