@@ -32,7 +32,7 @@ def timed(fn, n=20, warm=3):
     host_us = (time.perf_counter() - t0) / n * 1e6
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda._sleep(int(_SLEEP_CYC_PER_US * host_us * n * 1.5) + 1000)
+    torch.cuda._sleep(int(_SLEEP_CYC_PER_US * host_us * n * 3.0) + 1000)     # the blocker must outlast the enqueue work (x1.5 was not enough on loaded hosts: 1.6 ms outliers)
     a.record()
     for _ in range(n):
         fn()
