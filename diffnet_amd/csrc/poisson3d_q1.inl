@@ -13,7 +13,7 @@
 
 namespace dn {
 
-enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8, FL3_BC_U8C = 16 };   // FL3_BC_U8C: uint8 masks with constant values only
+enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8, FL3_BC_U8C = 16, FL3_BC_ONE = 32 };   // FL3_BC_U8C: uint8 masks with constant values only; FL3_BC_ONE (node-owner form): exactly one of them
 
 template <int NGP, int E>
 struct PlaneState3D {
@@ -888,6 +888,7 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
 template <int NGP, int FL, bool UW>
 __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
     constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, BC_U8C = (FL & FL3_BC_U8C) != 0;
+    constexpr int NMASK = !BC_U8C ? 0 : ((FL & FL3_BC_ONE) ? 1 : 2);     // uint8 mask arrays read per node (compile-time: no load in a uniform branch)
     static_assert((FL & (FL3_FGP | FL3_BC)) == 0, "node-owner form: nodal forcing, uint8 constant-value conditions");
     constexpr int E = 1, NW = 1;
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -951,6 +952,8 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
     mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);      // an absent condition re-reads the other one and is
     mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);      // ignored: no load inside a wave-uniform branch
 
+    // with one condition, slot 0 of mask8 / bcval is the one that is present
+    const float bcval[2] = {NMASK == 1 ? (has_mask[0] ? p.bc[0].value : p.bc[1].value) : p.bc[0].value, p.bc[1].value};
     struct RawNodes { float u[2], n[2], f[2]; uint8_t m[2][2]; };       // [0] own node, [1] halo node
     auto plane_request = [&](int zreq, RawNodes& W) {
         const unsigned zoff = (unsigned)min(zreq, p.nz - 1) * npl;
@@ -962,7 +965,7 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
             if constexpr (HAS_F) W.f[h] = ld_at<float>(sb.f, o[h]);
             if constexpr (BC_U8C) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) W.m[h][k] = ld_at<uint8_t>(mask8[k], o[h]);
+                for (int k = 0; k < NMASK; ++k) W.m[h][k] = ld_at<uint8_t>(mask8[k], o[h]);
             }
         }
     };
@@ -973,9 +976,9 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
             float uu = W.u[h], keep = 1.f;
             if constexpr (BC_U8C) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const bool set = has_mask[k] && W.m[h][k] != 0;
-                    uu = set ? p.bc[k].value : uu;
+                for (int k = 0; k < NMASK; ++k) {
+                    const bool set = (NMASK == 1 || has_mask[k]) && W.m[h][k] != 0;
+                    uu = set ? bcval[k] : uu;
                     keep = set ? 0.f : keep;
                 }
             }
@@ -1151,13 +1154,17 @@ static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hip
     for (int i = 0; i < NGP; ++i) unit = unit && pp.T.w[i] == 1.0f;
     if constexpr (E == 1 && (FL & (FL3_FGP | FL3_BC)) == 0) {
         if (g.TX == 16 && g.TY == 16 && pp.nx >= 2 && config(CFG_Q1_3D_T16) == nullptr) {      // node-owner form (every node requested once)
+            constexpr int FL1 = (FL & FL3_BC_U8C) ? (FL | FL3_BC_ONE) : FL;
+            const bool one = (FL & FL3_BC_U8C) && ((pp.bc[0].mask != nullptr) != (pp.bc[1].mask != nullptr));
             if constexpr (NGP == 2) {
                 if (unit) {
-                    hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+                    if (one) hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL1, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+                    else hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
                     return;
                 }
             }
-            hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL, false>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+            if (one) hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL1, false>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+            else hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL, false>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
             return;
         }
     }
