@@ -267,6 +267,32 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
     """One launch of dn_poisson_apply.  Returns (out | None, sums | None) where sums is a float64 device
     tensor [energy, sum(out_unscaled^2)].  With `loss_scale` a third value is returned: the 0-dim float32 tensor
     energy * loss_scale written by the same launch.  See include/diffnet_hip.h for the operator definition."""
+    return PoissonPlan(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out).launch()
+
+
+class PoissonPlan:
+    """A dn_poisson_apply call prepared once for FIXED buffers: validation, the argument structs, the outputs and the workspace are
+    set up at construction; `launch()` is one ctypes call (~3 us of host time instead of ~25).  For loops that evaluate the operator
+    on the same tensors every step -- the slab-parallel path (diffnet_amd/slab.py), whose per-rank kernels are shorter than the
+    host-side preparation -- and for anything captured into a HIP graph.  Outputs are overwritten by every launch."""
+
+    def __init__(self, geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
+                 out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None):
+        self.mesh, self.args, self.keep, self.result = _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale,
+                                                                        want_out, want_sums, loss_scale, out)
+        self.device = u.device
+        self._fn = _lib.lib().dn_poisson_apply
+        self._mesh_ref, self._args_ref = C.byref(self.mesh), C.byref(self.args)
+
+    def launch(self):
+        rc = self._fn(self._mesh_ref, self._args_ref, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc:
+            _lib.check(rc, "dn_poisson_apply")
+        return self.result
+
+
+def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out):
+    """Validation + argument structs of one dn_poisson_apply call: (mesh, args, tensors to keep alive, result tuple)."""
     nsd = geom.nsd
     u = _require(u, "u", nsd + 2)
     B = u.shape[0]
@@ -377,11 +403,8 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
             raise ValueError("loss_scale needs want_sums=True")
         loss32 = torch.empty((), dtype=torch.float32, device=u.device)
         args.energy_f32, args.energy_scale = loss32.data_ptr(), float(loss_scale)
-    rc = _lib.lib().dn_poisson_apply(C.byref(mesh), C.byref(args), _stream(u))
-    _lib.check(rc, "dn_poisson_apply")
-    if loss_scale is not None:
-        return out, sums, loss32
-    return out, sums
+    keep += [t for t in (out, sums, loss32) if t is not None]
+    return mesh, args, keep, ((out, sums, loss32) if loss_scale is not None else (out, sums))
 
 
 # ---- composed (operator-level) forms: differentiable wrt EVERY tensor input ------------------------------------

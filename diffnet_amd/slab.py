@@ -210,20 +210,55 @@ class SlabPoisson:
                                  c=c, wscale=jac, out_scale=scale, want_out=True, want_sums=False)
         return g[:, :, keep]
 
-    def energy_loss_and_grad(self, u_local, nu=None, f=None, dirichlet=(), c=1.0, jac=1.0):
+    def _thin_plan(self, sl, u, nu, f, dirichlet, c, jac, scale):
+        """Prepared launch over the one element layer next to a face, or None when the two node layers are not a contiguous view of
+        the slab tensors (batch > 1: the cut would be a copy made per evaluation)."""
         from . import ops
+        cut = lambda t: None if t is None else t[:, :, sl]
+        views = [cut(u), cut(nu), cut(f)] + [cut(x.mask) for x in ops._norm_dirichlet(dirichlet) if isinstance(x.mask, torch.Tensor)]
+        if any(v is not None and not v.is_contiguous() for v in views):
+            return None
+        if any(not isinstance(x.mask, torch.Tensor) or isinstance(x.value, torch.Tensor) for x in ops._norm_dirichlet(dirichlet)):
+            return None
+        d = [ops.Dirichlet(cut(x.mask), x.value) for x in ops._norm_dirichlet(dirichlet)]
+        return ops.PoissonPlan(self.fem_thin.geom, cut(u), cut(nu), cut(f), None, d, alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale,
+                               want_out=True, want_sums=False)
+
+    def _plans(self, u_local, nu, f, dirichlet, c, jac, scale):
+        """The step's launches prepared once per set of buffers (ops.PoissonPlan): at 256^3 over 8 ranks a rank's kernels take ~30 us,
+        the host-side preparation of three dn_poisson_apply calls ~75 us.  Re-prepared when a buffer, shape or coefficient changes."""
+        from . import ops
+        dl = ops._norm_dirichlet(dirichlet)
+        key = (u_local.data_ptr(), tuple(u_local.shape), None if nu is None else nu.data_ptr(), None if f is None else f.data_ptr(),
+               tuple((x.mask.data_ptr() if isinstance(x.mask, torch.Tensor) else id(x.mask),
+                      x.value.data_ptr() if isinstance(x.value, torch.Tensor) else float(x.value)) for x in dl), float(c), float(jac))
+        if getattr(self, "_plan_key", None) != key:
+            dec = self.dec
+            main = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale,
+                                   want_out=True, want_sums=True)
+            lo = self._thin_plan(slice(0, 2), u_local, nu, f, dirichlet, c, jac, scale) if (self.overlap and dec.rank > 0) else None
+            hi = self._thin_plan(slice(-2, None), u_local, nu, f, dirichlet, c, jac, scale) if (self.overlap and dec.rank + 1 < dec.world) else None
+            self._plan_key, self._plan = key, (main, lo, hi)
+        return self._plan
+
+    def energy_loss_and_grad(self, u_local, nu=None, f=None, dirichlet=(), c=1.0, jac=1.0):
+        """(global loss, this rank's slab of its gradient).  The gradient tensor is owned by the prepared launch and overwritten by the
+        next evaluation on the same buffers."""
         B = u_local.shape[0]
         dec = self.dec
         scale = 1.0 / (B * dec.nel_global)
+        main, plan_lo, plan_hi = self._plans(u_local, nu, f, dirichlet, c, jac, scale)
 
         def local():
-            grad, sums = ops.poisson_apply(self.fem.geom, u_local, nu, f, None, dirichlet, alpha=2.0 * c, beta=1.0, c=c,
-                                           wscale=jac, out_scale=scale, want_out=True, want_sums=True)
+            grad, sums = main.launch()
             return sums[0], grad
 
         def parts():
-            lo = self._thin_part(slice(0, 2), 0, u_local, nu, f, dirichlet, c, jac, scale) if dec.rank > 0 else None
-            hi = self._thin_part(slice(-2, None), 1, u_local, nu, f, dirichlet, c, jac, scale) if dec.rank + 1 < dec.world else None
+            lo = hi = None
+            if dec.rank > 0:
+                lo = plan_lo.launch()[0][:, :, 0] if plan_lo is not None else self._thin_part(slice(0, 2), 0, u_local, nu, f, dirichlet, c, jac, scale)
+            if dec.rank + 1 < dec.world:
+                hi = plan_hi.launch()[0][:, :, 1] if plan_hi is not None else self._thin_part(slice(-2, None), 1, u_local, nu, f, dirichlet, c, jac, scale)
             return lo, hi
 
         loss, grad = slab_energy_loss_and_grad(dec, local, B, self.group, parts if self.overlap else None, self.exchange)
