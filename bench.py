@@ -195,6 +195,8 @@ def main():
                          "the ranks (diffnet_amd/slab.py): per step one 8-byte all-reduce + one node-layer exchange per interior face")
     ap.add_argument("--slab-size", type=int, default=256, help="mesh of the slab leg appended to the default run (0 = skip)")
     ap.add_argument("--slab-steps", type=int, default=50)
+    ap.add_argument("--slab-batch", type=int, default=1, help="samples of the slab leg's mesh (BASELINE configs[3] is parametric: the reference trains it with batch 8)")
+    ap.add_argument("--slab-timeout", type=float, default=180.0, help="watchdog of the slab leg, seconds")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -322,11 +324,7 @@ def main():
     except Exception:
         pass
 
-    # strong-scaling leg of BASELINE configs[3] in the same run (all ranks take part): one 256^3 mesh cut into z-slabs
-    slab = None
-    if args.slab_size and args.nsd == 2 and args.size == 512:
-        slab = slab_leg(args, rank, world, dev, dist, args.slab_size, 1, 2, args.slab_steps, 10)
-
+    out = None
     if rank == 0:
         value = units_per_step * world * args.steps / dt
         out = {
@@ -347,11 +345,36 @@ def main():
                          "frac_at_median": alg_bytes / (kern_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
                          "kernel_median_us_by_mask_format": bc_forms_us},
         }
-        if slab is not None:
-            out["slab_3d"] = slab
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, c)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+
+    # strong-scaling leg of BASELINE configs[3] in the same run (all ranks take part): one 256^3 mesh cut into z-slabs.  The headline
+    # measurement above is complete at this point; the leg runs under a watchdog so that a failure or a hang in its point-to-point
+    # exchange (first exercised over RCCL on the driver's multi-GPU node) still leaves the ONE JSON line, with the reason in "slab_3d".
+    if args.slab_size and args.nsd == 2 and args.size == 512:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["slab_3d"] = {"error": f"slab leg did not finish within {args.slab_timeout} s (n_gpus={world})"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.slab_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            slab = slab_leg(args, rank, world, dev, dist, args.slab_size, args.slab_batch, 2, args.slab_steps, 10)
+            if rank == 0:
+                out["slab_3d"] = slab
+        except Exception as e:                       # noqa: BLE001 -- reported, not hidden: the line says what failed
+            if rank == 0:
+                out["slab_3d"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+                print(json.dumps(out), flush=True)
+            os._exit(0)                              # peers may be stuck in a collective: no orderly teardown (their watchdogs end them)
+        dog.cancel()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
