@@ -105,13 +105,16 @@ class InterfaceExchange:
         if dec.world == 1 or ref is None:
             return
         send_lo, recv_lo, send_hi, recv_hi = self._buffers(ref)
+        # a contiguous device-resident part is sent from where it is (no staging copy); `sent` is what finish() adds to the received part
+        direct = lambda p: p.is_contiguous() and not self.host
+        self.sent = [None, None]
         ops = []
         if dec.rank > 0:
-            send_lo.copy_(part_lo)
-            ops += [dist.P2POp(dist.isend, send_lo, dec.rank - 1, self.group), dist.P2POp(dist.irecv, recv_lo, dec.rank - 1, self.group)]
+            self.sent[0] = part_lo if direct(part_lo) else send_lo.copy_(part_lo)
+            ops += [dist.P2POp(dist.isend, self.sent[0], dec.rank - 1, self.group), dist.P2POp(dist.irecv, recv_lo, dec.rank - 1, self.group)]
         if dec.rank + 1 < dec.world:
-            send_hi.copy_(part_hi)
-            ops += [dist.P2POp(dist.isend, send_hi, dec.rank + 1, self.group), dist.P2POp(dist.irecv, recv_hi, dec.rank + 1, self.group)]
+            self.sent[1] = part_hi if direct(part_hi) else send_hi.copy_(part_hi)
+            ops += [dist.P2POp(dist.isend, self.sent[1], dec.rank + 1, self.group), dist.P2POp(dist.irecv, recv_hi, dec.rank + 1, self.group)]
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream(ref.device))
             with torch.cuda.stream(self.side):
@@ -129,11 +132,12 @@ class InterfaceExchange:
         if self.side is not None:
             torch.cuda.current_stream(grad_local.device).wait_stream(self.side)
         self.reqs = []
-        send_lo, recv_lo, send_hi, recv_hi = (b.to(grad_local.device) for b in self.buf) if self.host else self.buf
+        _, recv_lo, _, recv_hi = (b.to(grad_local.device) for b in self.buf) if self.host else self.buf
+        sent_lo, sent_hi = (None if t is None else t.to(grad_local.device) for t in self.sent)
         if dec.rank > 0:
-            torch.add(recv_lo, send_lo, out=grad_local[:, :, 0])            # lower rank's contribution first
+            torch.add(recv_lo, sent_lo, out=grad_local[:, :, 0])            # lower rank's contribution first
         if dec.rank + 1 < dec.world:
-            torch.add(send_hi, recv_hi, out=grad_local[:, :, -1])
+            torch.add(sent_hi, recv_hi, out=grad_local[:, :, -1])
         return grad_local
 
 
