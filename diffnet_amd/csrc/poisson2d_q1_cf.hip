@@ -52,8 +52,18 @@ struct CfRow {
 #define DN_CF_PF 0                // 1: software-pipelined rows (row k + 2 in flight while layer k is computed); measured equal (profiles/r2_2d_ab.txt), off: 79 instead of 102 VGPRs
 #endif
 
+#ifdef DN_STAMP2D
+// Diagnostic build only (tools/clock2d.py): shader-clock ticks (s_memtime) and constant-100-MHz ticks (s_memrealtime) of every workgroup's
+// lifetime -> the clock the kernel really ran at (the MI355X lowers it under load: profiles/r2_clock_under_load.txt)
+__device__ unsigned long long dn_stamp2d_buf[8192 * 2];
+extern "C" int dn_debug_stamps2d(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dn_stamp2d_buf), bytes); }
+#endif
+
 template <int E, bool VEC, int FL>
 __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(const PoissonParams p) {
+#ifdef DN_STAMP2D
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int NW = E;
     constexpr bool HAS_NU = (FL & CF_NU) != 0, HAS_F = (FL & CF_F) != 0;
     constexpr bool BC_ANY = (FL & (CF_BC | CF_BC_U8C | CF_BC_PACKED)) != 0, BC_U8C = (FL & CF_BC_U8C) != 0, BC_PACKED = (FL & CF_BC_PACKED) != 0;
@@ -379,6 +389,15 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         flush_store();
     }
 
+#ifdef DN_STAMP2D
+    if (tid == 0) {
+        const unsigned slot = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (slot < 8192u) {
+            dn_stamp2d_buf[2 * slot] = __builtin_amdgcn_s_memtime() - stamp_t0;
+            dn_stamp2d_buf[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
+        }
+    }
+#endif
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);
 }
 

@@ -933,6 +933,10 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
     DN_V(TV.kap[0]); DN_V(TV.kap[1]); DN_V(TV.kap[2]);
 #undef DN_V
 #endif
+#if defined(DN_STAMP3D) && DN_NGP == 2
+    unsigned long long stamp_A = 0, stamp_B = 0, stamp_C = 0, stamp_D = 0, stamp_E = 0, stamp_n = 0, stamp_last = 0;
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_rt0 = __builtin_amdgcn_s_memrealtime();   // shader clock / constant 100 MHz clock
+#endif
     __shared__ float4 rec[2][17 * 17];            // [plane parity][node row * 17 + node column] = {u after Dirichlet, nu, f, keep}
     __shared__ float xch[2][256];
     __shared__ double red[256 / 64 + 1];
@@ -1046,10 +1050,12 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
     };
     // hand the finished contributions over, (optionally) publish the plane requested at the top of the layer, ONE barrier, finish the node
     auto emit_plane = [&](const float (&o)[2][2], float keep, int z, bool owned_plane, const RawNodes* W, int zpub) {
+        DN_STAMP(stamp_C);
         const float left = lane_from_left(o[0][1], from_left, nfirst);
         xch[par][tid] = o[1][0] + lane_from_left(o[1][1], from_left, nfirst);
         if (W != nullptr) plane_publish(*W, zpub);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        DN_STAMP(stamp_D);
         float t = o[0][0] + left;
         if (ty > 0) t += xch[par][tid - 16];
         t *= keep;
@@ -1110,6 +1116,9 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
 #endif
     };
     set_prio(0);
+#if defined(DN_STAMP3D) && DN_NGP == 2
+    stamp_last = __builtin_amdgcn_s_memtime();
+#endif
 #pragma nounroll
     for (; ez + 1 < ez_end; ez += 2) {
 #if DN_PRIO3D == 2
@@ -1117,12 +1126,21 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
 #endif
         plane_request(ez + 2, W);                 // lands while this layer is computed; published before the layer's barrier
         flush_store();
+        DN_STAMP(stamp_A);
         plane_gather(ez + 1, SB, keep_up);
+        DN_STAMP(stamp_B);
         layer(ez, SA, SB, keep_lo, &W);
+        DN_STAMP(stamp_E);
         plane_request(ez + 3, W);
         flush_store();
+        DN_STAMP(stamp_A);
         plane_gather(ez + 2, SA, keep_lo);
+        DN_STAMP(stamp_B);
         layer(ez + 1, SB, SA, keep_up, &W);
+        DN_STAMP(stamp_E);
+#if defined(DN_STAMP3D) && DN_NGP == 2
+        stamp_n += 2;
+#endif
     }
     bool odd = false;
     if (ez < ez_end) {
@@ -1139,8 +1157,31 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
         flush_store();
     }
 
+#if defined(DN_STAMP3D) && DN_NGP == 2
+    if (tid == 0) {                               // node-owner build: wave 0 of EVERY workgroup (per-CU timelines, tools/stamp3d.py)
+        const unsigned slot = blockIdx.x;
+        if (slot < 8192u) {
+            unsigned long long* d = dn_stamp_buf + slot * 8u;
+            // where the wave ran: HW_REG_HW_ID (4: wave / SIMD / CU / SH / SE ids) and HW_REG_XCC_ID (20), whole registers
+            const unsigned long long hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+            d[0] = stamp_A; d[1] = stamp_B; d[2] = stamp_C; d[3] = stamp_D;
+            d[4] = stamp_E | ((__builtin_amdgcn_s_memrealtime() - stamp_rt0) << 40);          // lifetime in 10-ns ticks in the upper bits
+            d[5] = stamp_n | (hwid << 16) | ((xcc & 0xffull) << 48);
+            d[6] = stamp_t0; d[7] = __builtin_amdgcn_s_memtime();
+        }
+    }
+#endif
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, 256, red, &last_flag, (double)p.T.esc);
 }
+
+#if DN_NGP == 2
+// diagnostic: resident workgroups per CU the runtime grants the default 3-D kernel (tools/occ3d.py prints it)
+extern "C" int dn_debug_occupancy_q1n(void) {
+    int n = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, poisson3d_q1n_kernel<2, FL3_NU | FL3_F | FL3_BC_U8C | FL3_BC_ONE, true>, 256, 0) != hipSuccess) return -1;
+    return n;
+}
+#endif
 
 // ---- dispatch ---------------------------------------------------------------------------------------------
 template <int NGP, int E, bool VEC, int FL>

@@ -15,6 +15,10 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 241
 R = n - 1
 m = DiffNet3DFEM(None, domain_size=n, nsd=3).to(dev)
+try:
+    print("hipOccupancyMaxActiveBlocksPerMultiprocessor(poisson3d_q1n_kernel, 256 threads) =", _lib.lib().dn_debug_occupancy_q1n(), flush=True)
+except AttributeError:
+    pass
 _lib.config_set("PLAN3D", f"16,16,1,{R}")
 for B in [int(v) for v in (sys.argv[2].split(',') if len(sys.argv) > 2 else '1,2,3,4,5,6,7,8'.split(','))]:
     shape = (B, 1, n, n, n)

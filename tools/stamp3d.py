@@ -31,15 +31,50 @@ h.dn_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
 rc = h.dn_debug_stamps(buf.ctypes.data, buf.nbytes)
 assert rc == 0, rc
 r = buf.reshape(-1, 8)
-r = r[r[:, 5] > 0].astype(np.float64)
+r = r[(r[:, 5] & np.uint64(0xffff)) > 0]
+hwid = ((r[:, 5] >> np.uint64(16)) & np.uint64(0xffffffff)).astype(np.int64)     # node-owner build: HW_REG_HW_ID of the wave (0 in the T16 build)
+xcd = ((r[:, 5] >> np.uint64(48)) & np.uint64(0xf)).astype(np.int64)             # HW_REG_XCC_ID
+cu = (hwid >> 8) & 0xf
+sh = (hwid >> 12) & 0x1
+se = (hwid >> 13) & 0x7
+rt = (r[:, 4] >> np.uint64(40)).astype(np.float64)          # node-owner build: wave lifetime on the constant 100 MHz clock
+r[:, 4] = r[:, 4] & np.uint64((1 << 40) - 1)
+r = r.astype(np.float64)
+r[:, 5] = (r[:, 5].astype(np.uint64) & np.uint64(0xffff)).astype(np.float64)
 print(f"n={n} B={B} plan={plan or 'default'}: {len(r)} sampled waves, layers per wave in the loop: {r[:,5].mean():.1f}")
 per = r[:, :5] / r[:, 5:6]
-names = ["A wait+stage plane", "B issue loads+store", "C layer arithmetic", "D xch write+barrier", "E xch read+finish"]
+names = ["A request loads+store", "B gather (LDS) + stage", "C layer arithmetic", "D hand-over+publish+barrier", "E xch read+finish"]      # node-owner form (poisson3d_q1n_kernel); the T16 form (DN Q1_3D_T16=1): A wait+stage, B issue, C, D, E
 tot = per.sum(1)
 for i, nm in enumerate(names):
     print(f"  {nm:22s} mean {per[:, i].mean():8.0f}  median {np.median(per[:, i]):8.0f}  p10 {np.percentile(per[:, i], 10):8.0f}  p90 {np.percentile(per[:, i], 90):8.0f}  cycles per layer")
 print(f"  {'total per layer':22s} mean {tot.mean():8.0f}  median {np.median(tot):8.0f}")
 life = r[:, 7] - r[:, 6]
+if rt.any():
+    mhz = life / (rt * 10e-3)          # shader-clock ticks per microsecond
+    print(f"  SHADER CLOCK while the waves ran (s_memtime ticks / s_memrealtime): mean {mhz.mean():.0f} MHz  min {mhz.min():.0f}  max {mhz.max():.0f};  wave lifetime {rt.mean() * 0.01:.1f} us")
 print(f"  wave lifetime mean {life.mean():.0f} ticks (s_memtime: 100 MHz constant clock on gfx9? compare with total*layers = {(tot * r[:,5]).mean():.0f})")
-t0 = r[:, 6] - r[:, 6].min()
-print(f"  wave start times: min 0  median {np.median(t0):.0f}  max {t0.max():.0f};  end max {(r[:,7]-r[:,6].min()).max():.0f}")
+keys = list(zip(xcd.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
+print("  distinct (xcc, se, sh, cu) of the sampled waves:", len(set(keys)))
+if hwid.any():          # per-CU timelines (node-owner build: one record per workgroup)
+    import collections
+    byc = collections.defaultdict(list)
+    for kk, st, en in zip(keys, r[:, 6], r[:, 7]):
+        byc[kk].append((st, en))
+    cnt = np.array([len(v) for v in byc.values()])
+    print(f"  workgroups per CU: min {cnt.min()} median {int(np.median(cnt))} max {cnt.max()}  (CUs used: {len(byc)})")
+    spans, conc = [], []
+    for v in byc.values():
+        v.sort()
+        t0c = v[0][0]
+        spans.append(max(e for _, e in v) - t0c)
+        # how many workgroups of this CU had started before the first one ended
+        conc.append(sum(1 for st, _ in v if st < v[0][1]))
+    spans = np.array(spans)
+    print(f"  per-CU busy span (first start -> last end): median {np.median(spans):.0f}  max {spans.max():.0f} ticks;  workgroups started before the CU's first one ended: median {int(np.median(conc))} max {max(conc)}")
+for x in range(8):
+    sel = xcd == x
+    if sel.sum() < 2:
+        continue
+    st = r[sel, 6] - r[sel, 6].min()
+    en = r[sel, 7] - r[sel, 6].min()
+    print(f"  XCD {x}: {sel.sum():3d} sampled waves, start after the first one: median {np.median(st):9.0f}  p75 {np.percentile(st, 75):9.0f}  max {st.max():9.0f};  last end {en.max():9.0f} ticks")
