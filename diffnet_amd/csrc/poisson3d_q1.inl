@@ -13,7 +13,7 @@
 
 namespace dn {
 
-enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8, FL3_BC_U8C = 16, FL3_BC_ONE = 32 };   // FL3_BC_U8C: uint8 masks with constant values only; FL3_BC_ONE (node-owner form): exactly one of them
+enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8, FL3_BC_U8C = 16, FL3_BC_ONE = 32, FL3_E1G = 64 };   // FL3_BC_U8C: uint8 masks with constant values only; FL3_BC_ONE (node-owner form): exactly one of them
 
 template <int NGP, int E>
 struct PlaneState3D {
@@ -888,7 +888,10 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
 template <int NGP, int FL, bool UW>
 __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
     constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, BC_U8C = (FL & FL3_BC_U8C) != 0;
-    constexpr int NMASK = !BC_U8C ? 0 : ((FL & FL3_BC_ONE) ? 1 : 2);     // uint8 mask arrays read per node (compile-time: no load in a uniform branch)
+    constexpr int NMASK = !BC_U8C ? 0 : ((FL & FL3_BC_ONE) ? 1 : 2);
+    // FL3_E1G: the stiffness part of the energy is not summed Gauss point by Gauss point but taken from the finished nodal values:
+    // sum_a u_a out_a = alpha * sum W nu |grad u|^2 - beta * sum W f u  (u = sum_a u_a N_a), one FMA per node instead of 15 per element
+    constexpr bool E1G = (FL & FL3_E1G) != 0;     // uint8 mask arrays read per node (compile-time: no load in a uniform branch)
     static_assert((FL & (FL3_FGP | FL3_BC)) == 0, "node-owner form: nodal forcing, uint8 constant-value conditions");
     constexpr int E = 1, NW = 1;
     const int tx = threadIdx.x, ty = threadIdx.y;
@@ -992,10 +995,12 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
         if (halo_lane) rec[zpl & 1][halo_rec] = r[1];
     };
     float keep_lo = 1.f, keep_up = 1.f;           // keep of the own node in the lower / upper plane of the current layer
-    auto plane_gather = [&](int zpl, PlaneW<NGP, 1>& S, float& keep) {
+    float u_lo = 0.f, u_up = 0.f, ut_acc = 0.f;   // E1G: the own node's value after the Dirichlet conditions, sum of u * out over the owned nodes
+    auto plane_gather = [&](int zpl, PlaneW<NGP, 1>& S, float& keep, float& uown) {
         const float4* t = &rec[zpl & 1][own_rec];
         const float4 a0 = t[0], a1 = t[1], b0 = t[17], b1 = t[18];
         keep = a0.w;
+        uown = a0.x;
         stage_u3<NGP>(TV, a0.x, a1.x, b0.x, b1.x, S.VU[0], S.VX[0], S.VY[0]);
         if constexpr (HAS_NU) stage_w3<NGP, UW>(TV, a0.y, a1.y, b0.y, b1.y, S.VN[0]);
         if constexpr (HAS_F) stage_w3<NGP, UW>(TV, a0.z, a1.z, b0.z, b1.z, S.VF[0]);
@@ -1049,7 +1054,7 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
         pend_st = false;
     };
     // hand the finished contributions over, (optionally) publish the plane requested at the top of the layer, ONE barrier, finish the node
-    auto emit_plane = [&](const float (&o)[2][2], float keep, int z, bool owned_plane, const RawNodes* W, int zpub) {
+    auto emit_plane = [&](const float (&o)[2][2], float keep, float uown, int z, bool owned_plane, const RawNodes* W, int zpub) {
         DN_STAMP(stamp_C);
         const float left = lane_from_left(o[0][1], from_left, nfirst);
         xch[par][tid] = o[1][0] + lane_from_left(o[1][1], from_left, nfirst);
@@ -1058,27 +1063,32 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
         DN_STAMP(stamp_D);
         float t = o[0][0] + left;
         if (ty > 0) t += xch[par][tid - 16];
-        t *= keep;
         const bool st = owned_plane && owner && noderow_ok;
+        if constexpr (E1G) ut_acc = st ? fmaf(t, uown, ut_acc) : ut_acc;      // before the Dirichlet rows are zeroed
+        t *= keep;
         sq_acc = st ? fmaf(t, t, sq_acc) : sq_acc;
         pend_v = t * p.out_scale;
         pend_off = (unsigned)z * npl + out_row + (unsigned)x0;
         pend_st = st && sb.out != nullptr && x0 < p.nx;
         par ^= 1;
     };
-    auto layer = [&](int ez, const PlaneW<NGP, 1>& L, const PlaneW<NGP, 1>& U, float keep, const RawNodes* W) {
+    auto layer = [&](int ez, const PlaneW<NGP, 1>& L, const PlaneW<NGP, 1>& U, float keep, float uown, const RawNodes* W) {
         const bool own_layer = ez >= ez_own;
         const float cnt = (own_layer && owner) ? 1.f : 0.f;
         float o[2][2], fg[1] = {0.f};
         float tU[NGP][NGP], tX[NGP], tY[NGP], e1, e2;
         q1_layer_3d_w<NGP, false, HAS_F, UW>(TV, L.VU[0], U.VU[0], L.VX[0], U.VX[0], L.VY[0], U.VY[0], L.VN[0], U.VN[0], L.VF[0], U.VF[0],
                                              fg, cU, cX, cY, tU, tX, tY, e1, e2);
-        asm volatile("" : "+v"(e1), "+v"(e2));
-        e1_acc = fmaf(cnt * okf, e1, e1_acc);
+        if constexpr (E1G) {
+            asm volatile("" : "+v"(e2));
+        } else {
+            asm volatile("" : "+v"(e1), "+v"(e2));
+            e1_acc = fmaf(cnt * okf, e1, e1_acc);
+        }
         e2_acc = fmaf(cnt * okf, e2, e2_acc);
         plane_transpose(tU, tX, tY, o);
         __builtin_amdgcn_sched_barrier(0);
-        emit_plane(o, keep, ez, own_layer, W, ez + 2);
+        emit_plane(o, keep, uown, ez, own_layer, W, ez + 2);
     };
 
     // prologue: planes ez_begin and ez_begin + 1 into LDS, the lower one staged
@@ -1087,7 +1097,7 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
     plane_publish(W, ez_begin);
     plane_request(ez_begin + 1, W);
     __syncthreads();
-    plane_gather(ez_begin, SA, keep_lo);
+    plane_gather(ez_begin, SA, keep_lo, u_lo);
     plane_publish(W, ez_begin + 1);
     __syncthreads();
     int ez = ez_begin;
@@ -1127,16 +1137,16 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
         plane_request(ez + 2, W);                 // lands while this layer is computed; published before the layer's barrier
         flush_store();
         DN_STAMP(stamp_A);
-        plane_gather(ez + 1, SB, keep_up);
+        plane_gather(ez + 1, SB, keep_up, u_up);
         DN_STAMP(stamp_B);
-        layer(ez, SA, SB, keep_lo, &W);
+        layer(ez, SA, SB, keep_lo, u_lo, &W);
         DN_STAMP(stamp_E);
         plane_request(ez + 3, W);
         flush_store();
         DN_STAMP(stamp_A);
-        plane_gather(ez + 2, SA, keep_lo);
+        plane_gather(ez + 2, SA, keep_lo, u_lo);
         DN_STAMP(stamp_B);
-        layer(ez + 1, SB, SA, keep_up, &W);
+        layer(ez + 1, SB, SA, keep_up, u_up, &W);
         DN_STAMP(stamp_E);
 #if defined(DN_STAMP3D) && DN_NGP == 2
         stamp_n += 2;
@@ -1145,15 +1155,15 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
     bool odd = false;
     if (ez < ez_end) {
         flush_store();
-        plane_gather(ez + 1, SB, keep_up);
-        layer(ez, SA, SB, keep_lo, nullptr);
+        plane_gather(ez + 1, SB, keep_up, u_up);
+        layer(ez, SA, SB, keep_lo, u_lo, nullptr);
         odd = true;
     }
     flush_store();
     if (ez_end == p.nelz) {       // the last strip owns the top boundary plane: only the layer below contributes
         float o[2][2];
         plane_transpose(cU, cX, cY, o);
-        emit_plane(o, odd ? keep_up : keep_lo, p.nz - 1, true, nullptr, 0);
+        emit_plane(o, odd ? keep_up : keep_lo, odd ? u_up : u_lo, p.nz - 1, true, nullptr, 0);
         flush_store();
     }
 
@@ -1171,6 +1181,7 @@ __global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const 
         }
     }
 #endif
+    if constexpr (E1G) e1_acc = (ut_acc / p.T.esc + p.T.beta * e2_acc) / p.T.alpha;       // per-thread share of sum W nu |grad u|^2 (the identity holds for the total)
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, 256, red, &last_flag, (double)p.T.esc);
 }
 
@@ -1199,6 +1210,13 @@ static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hip
             const bool one = (FL & FL3_BC_U8C) && ((pp.bc[0].mask != nullptr) != (pp.bc[1].mask != nullptr));
             if constexpr (NGP == 2) {
                 if (unit) {
+                    // energy from the nodal values (FL3_E1G) whenever the launch has a stiffness part and sums are wanted
+                    const bool e1g = pp.T.alpha != 0.f && pp.want_sums && config(CFG_Q1_3D_E1SUM) == nullptr;
+                    if (e1g) {
+                        if (one) hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL1 | FL3_E1G, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+                        else hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL | FL3_E1G, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+                        return;
+                    }
                     if (one) hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL1, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
                     else hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, FL, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
                     return;
