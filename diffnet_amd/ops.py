@@ -250,15 +250,20 @@ def _norm_dirichlet(dirichlet):
 
 
 _WS = {}
+_WS_LOCK = __import__("threading").Lock()
 _POISSON_WS_BYTES = {}
 
 
 def _workspace(dev, nbytes):
+    """The reduction workspace of (device, current stream): launches on one stream are ordered, so they may share it; a launch on
+    another stream gets its own (the ABI asks for one workspace per concurrently used stream).  A prepared launch (PoissonPlan)
+    keeps the workspace of the stream it was prepared on and must be launched on that stream."""
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)   # ABI: zero-filled once
-        _WS[key] = ws
+    with _WS_LOCK:
+        ws = _WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)   # ABI: zero-filled once
+            _WS[key] = ws
     return ws
 
 
@@ -281,11 +286,15 @@ class PoissonPlan:
         self.mesh, self.args, self.keep, self.result = _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale,
                                                                         want_out, want_sums, loss_scale, out)
         self.device = u.device
+        self.stream = torch.cuda.current_stream(u.device).cuda_stream      # the reduction workspace belongs to this stream
         self._fn = _lib.lib().dn_poisson_apply
         self._mesh_ref, self._args_ref = C.byref(self.mesh), C.byref(self.args)
 
     def launch(self):
-        rc = self._fn(self._mesh_ref, self._args_ref, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        cur = torch.cuda.current_stream(self.device).cuda_stream
+        if self.args.workspace and cur != self.stream:
+            raise DiffNetHipError("PoissonPlan.launch: prepared on another stream (its reduction workspace is per stream); prepare one plan per stream")
+        rc = self._fn(self._mesh_ref, self._args_ref, C.c_void_p(cur))
         if rc:
             _lib.check(rc, "dn_poisson_apply")
         return self.result

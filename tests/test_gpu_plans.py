@@ -1,0 +1,56 @@
+"""GPU tests of the prepared launch (ops.PoissonPlan) and of the two ways the 3-D kernel sums the stiffness energy."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import boundary_mask, close, cu, dev, module, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kw,B", [(dict(domain_size=64, ngp_1d=3), 3), (dict(domain_size=33, nsd=3), 2)])
+def test_prepared_launch_equals_the_one_shot_call_and_follows_its_buffers(kw, B):
+    from diffnet_amd import ops
+    m = module(kw)
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = cu(seeded(shape, 1)), cu(seeded(shape, 2) + 0.5), cu(seeded(shape, 3))
+    bc = boundary_mask((1,) + shape[1:]).to(torch.uint8).to(dev())
+    scale = 1.0 / (B * m.geom.nelem_total)
+    kwargs = dict(alpha=2.0, beta=1.0, c=1.0, wscale=1.0, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
+    ref = ops.poisson_apply(m.geom, u, nu, f, None, [(bc, 0.0)], **kwargs)
+    plan = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], **kwargs)
+    got = plan.launch()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    # the plan reads its buffers at launch time: new values in place -> new results, same output tensors
+    u.mul_(0.5)
+    ref2 = ops.poisson_apply(m.geom, u, nu, f, None, [(bc, 0.0)], **kwargs)
+    got2 = plan.launch()
+    assert got2[0].data_ptr() == got[0].data_ptr()
+    for a, b in zip(got2, ref2):
+        assert torch.equal(a, b)
+    # a plan with a reduction workspace belongs to the stream it was prepared on
+    side = torch.cuda.Stream(dev())
+    with torch.cuda.stream(side):
+        with pytest.raises(Exception, match="another stream"):
+            plan.launch()
+
+
+def test_3d_energy_from_nodal_values_equals_the_gauss_point_sum():
+    """sum_a u_a out_a = alpha * sum W nu |grad u|^2 - beta * sum W f u: the default 3-D kernel takes the stiffness energy from the
+    finished nodal values; dn_config_set("Q1_3D_E1SUM") sums it Gauss point by Gauss point.  Same loss to fp32 rounding, same gradient."""
+    from diffnet_amd import _lib
+    m = module(dict(domain_size=65, nsd=3))
+    shape = (2, 1, 65, 65, 65)
+    u, nu, f = cu(seeded(shape, 11)), cu(seeded(shape, 12) + 0.5), cu(seeded(shape, 13))
+    bc = boundary_mask((1,) + shape[1:]).to(torch.uint8).to(dev())
+    src = (seeded(shape, 14) < 0.03).to(torch.uint8).to(dev())
+    for c in (1.0, 0.5):
+        la, ga = m.energy_loss_and_grad(u, nu, f, dirichlet=[(src, 1.0), (bc, 0.0)], c=c)
+        _lib.config_set("Q1_3D_E1SUM", "1")
+        try:
+            lb, gb = m.energy_loss_and_grad(u, nu, f, dirichlet=[(src, 1.0), (bc, 0.0)], c=c)
+        finally:
+            _lib.config_set("Q1_3D_E1SUM", "")
+        assert torch.equal(ga, gb)
+        np.testing.assert_allclose(float(la), float(lb), rtol=3e-6)
