@@ -238,8 +238,9 @@ def main():
     from diffnet_amd import BoxFaces, PackedMask
     bc_form = args.bc if args.bc != "auto" else ("box" if args.nsd == 2 else "u8")
     # auto: BASELINE.md section 3 prescribes the condition "on all boundary faces", which is the box boundary the reference builds as an image
-    # (IBN_2D.py:69-73); the kernel derives it from the geometry.  The same launch with the mask held as bits / u8 / fp32 image is
-    # timed below and reported in roofline.kernel_median_us_by_mask_format (the 3-D kernels read uint8 images).
+    # (IBN_2D.py:69-73); the kernel derives it from the geometry.  The same launch with the mask held as one bit per node (a general mask
+    # array: 0-2 us slower depending on the box), as a uint8 or as the reference's fp32 image is timed below and reported in
+    # roofline.kernel_median_us_by_mask_format (the 3-D kernels read uint8 images).
     forms = {"u8": lambda: [(bc, 0.0)], "f32": lambda: [(bc.float(), 0.0)], "bits": lambda: [(PackedMask.pack(bc), 0.0)],
              "box": lambda: [(BoxFaces("all"), 0.0)]}
     dirichlet = forms[bc_form]()
@@ -310,13 +311,14 @@ def main():
     bc_forms_us = {}
     if args.nsd == 2 and rank == 0:          # the same launch with the condition held in the other formats (median of 30, informational)
         for name, mk in forms.items():
-            d2 = dirichlet if name == bc_form else mk()
-            for _ in range(3):
-                ops.poisson_apply(m.geom, u, nu, f, None, d2, alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale)
+            pl = plans[0] if name == bc_form else _ops.PoissonPlan(m.geom, u, nu, f, None, mk(), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0,
+                                                                   out_scale=scale0, want_out=True, want_sums=True, loss_scale=scale0)
+            for _ in range(5):
+                pl.launch()
             ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
             for a, b in ev2:
                 a.record()
-                ops.poisson_apply(m.geom, u, nu, f, None, d2, alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale)
+                pl.launch()
                 b.record()
             torch.cuda.synchronize()
             bc_forms_us[name] = round(sorted(a.elapsed_time(b) for a, b in ev2)[15] * 1e3, 2)

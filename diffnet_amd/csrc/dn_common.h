@@ -54,18 +54,42 @@ struct VecT<4> { using type = float4; };
 // lets the compiler pick `global_load/store ... v_off, s[base:base+1]` (SGPR base + 32-bit VGPR offset); indexing
 // `base[u32_index]` does not, because index * sizeof(T) may exceed 32 bits, and costs a 64-bit VALU add per access.
 // Callers guarantee in-sample byte offsets < 2^32 (dn_poisson_apply rejects samples of >= 2^30 nodes).
+#ifndef DN_NT_STORES
+#define DN_NT_STORES 0     // per translation unit: 1 in the 2-D closed-form kernel (poisson2d_q1_cf.hip); measured neutral to 3 % slower in the 3-D kernel
+#endif
 template <typename V, typename T>
 __device__ __forceinline__ V ld_at(const T* __restrict__ base, unsigned index) {
-#ifdef DN_NT_LOADS          // experiment: non-temporal loads for the streamed fields (profiles/r2_2d_ab.txt)
-    return __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (index * (unsigned)sizeof(T))));
+#ifdef DN_NT_LOADS          // experiment: non-temporal loads for the streamed fields (profiles/r2_ab2d_nt.txt)
+    const char* a = reinterpret_cast<const char*>(base) + (index * (unsigned)sizeof(T));
+    if constexpr (sizeof(V) == 16) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(a));
+        return __builtin_bit_cast(V, t);
+    } else if constexpr (sizeof(V) == 8) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(a));
+        return __builtin_bit_cast(V, t);
+    } else {
+        return __builtin_nontemporal_load(reinterpret_cast<const V*>(a));
+    }
 #else
     return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (index * (unsigned)sizeof(T)));
 #endif
 }
 template <typename V, typename T>
 __device__ __forceinline__ void st_at(T* __restrict__ base, unsigned index, const V& v) {
-#ifdef DN_NT_STORES
-    __builtin_nontemporal_store(v, reinterpret_cast<V*>(reinterpret_cast<char*>(base) + (index * (unsigned)sizeof(T))));
+#if DN_NT_STORES            // the operators' outputs are written once and not read again by the launch: non-temporal stores (2-D bench
+                            // kernel 54.3 -> 52.8 us, profiles/r2_ab2d_nt.txt; non-temporal LOADS are 20 % slower: halo rows and shared nodes are re-read)
+    char* a = reinterpret_cast<char*>(base) + (index * (unsigned)sizeof(T));
+    if constexpr (sizeof(V) == 16) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(__builtin_bit_cast(v4f, v), reinterpret_cast<v4f*>(a));
+    } else if constexpr (sizeof(V) == 8) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(__builtin_bit_cast(v2f, v), reinterpret_cast<v2f*>(a));
+    } else {
+        __builtin_nontemporal_store(v, reinterpret_cast<V*>(a));
+    }
 #else
     *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + (index * (unsigned)sizeof(T))) = v;
 #endif
