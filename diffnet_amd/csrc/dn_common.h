@@ -130,6 +130,20 @@ __device__ __forceinline__ void load_seg(const T* __restrict__ base, unsigned ro
     dst[NW] = ld_at<T>(base, rowoff + (unsigned)min(x0 + NW, nx - 1));
 }
 
+// load_seg for a field that is streamed once (coefficients): the aligned vector part as a NON-TEMPORAL load, the shared node as usual
+template <int NW, bool VEC, typename T>
+__device__ __forceinline__ void load_seg_stream(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[NW + 1]) {
+    if constexpr (VEC && NW == 4 && sizeof(T) == 4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const unsigned xl = (unsigned)min(x0, nx - NW);
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(base) + (rowoff + xl) * 4u));
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        dst[NW] = ld_at<T>(base, rowoff + (unsigned)min(x0 + NW, nx - 1));
+    } else {
+        load_seg<NW, VEC>(base, rowoff, x0, nx, dst);
+    }
+}
+
 // lane l <- lane l + 1 (whole wave), lane 63 keeps `last`
 __device__ __forceinline__ unsigned dpp_from_right_u32(unsigned v, unsigned last) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);

@@ -49,6 +49,9 @@ struct CfRow {
 #ifndef DN_CF_FMASS
 #define DN_CF_FMASS 1
 #endif
+#ifndef DN_CF_NT_COEF
+#define DN_CF_NT_COEF 0           // 1: non-temporal vector loads for nu and f (profiles/r2_ab2d_nt.txt)
+#endif
 #ifndef DN_CF_PF
 #define DN_CF_PF 0                // 1: software-pipelined rows (row k + 2 in flight while layer k is computed); measured equal (profiles/r2_2d_ab.txt), off: 79 instead of 102 VGPRs
 #endif
@@ -143,8 +146,13 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     auto row_issue = [&](int yr, CfRow<E>& r) {
         const unsigned rowoff = (unsigned)min(yr, p.ny - 1) * (unsigned)p.nx;
         lseg(sb.u, rowoff, r.u);
+#if DN_CF_NT_COEF
+        if constexpr (HAS_NU) load_seg_stream<NW, VEC>(sb.nu, rowoff, x0, p.nx, r.n);
+        if constexpr (HAS_F) load_seg_stream<NW, VEC>(sb.f, rowoff, x0, p.nx, r.f);
+#else
         if constexpr (HAS_NU) lseg(sb.nu, rowoff, r.n);
         if constexpr (HAS_F) lseg(sb.f, rowoff, r.f);
+#endif
         if constexpr (BC_PACKED) {
             packed_issue(min(yr, p.ny - 1), r);
         } else if constexpr (BC_U8C) {
