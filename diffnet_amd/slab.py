@@ -239,7 +239,7 @@ class SlabPoisson:
         if getattr(self, "_plan_key", None) != key:
             dec = self.dec
             main = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale,
-                                   want_out=True, want_sums=True)
+                                   want_out=True, want_sums=True, loss_scale=scale)
             lo = self._thin_plan(slice(0, 2), u_local, nu, f, dirichlet, c, jac, scale) if (self.overlap and dec.rank > 0) else None
             hi = self._thin_plan(slice(-2, None), u_local, nu, f, dirichlet, c, jac, scale) if (self.overlap and dec.rank + 1 < dec.world) else None
             self._plan_key, self._plan = key, (main, lo, hi)
@@ -253,9 +253,6 @@ class SlabPoisson:
         scale = 1.0 / (B * dec.nel_global)
         main, plan_lo, plan_hi = self._plans(u_local, nu, f, dirichlet, c, jac, scale)
 
-        def local():
-            grad, sums = main.launch()
-            return sums[0], grad
 
         def parts():
             lo = hi = None
@@ -265,5 +262,18 @@ class SlabPoisson:
                 hi = plan_hi.launch()[0][:, :, 1] if plan_hi is not None else self._thin_part(slice(-2, None), 1, u_local, nu, f, dirichlet, c, jac, scale)
             return lo, hi
 
-        loss, grad = slab_energy_loss_and_grad(dec, local, B, self.group, parts if self.overlap else None, self.exchange)
-        return loss.to(torch.float32), grad
+        # same sequence as slab_energy_loss_and_grad, with the loss taken from the launch itself: the kernel writes
+        # energy_local / (B * nel_global) as float32, the all-reduce sums those shares (no clone / divide / cast kernels per step)
+        ex = self.exchange
+        started = False
+        if dec.world > 1 and self.overlap:
+            ex.start(*parts())
+            started = True
+        grad, _, loss = main.launch()
+        if dec.world > 1:
+            work = dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if not started:
+                ex.start(grad[:, :, 0] if dec.rank > 0 else None, grad[:, :, -1] if dec.rank + 1 < dec.world else None)
+            ex.finish(grad)
+            work.wait()
+        return loss, grad
