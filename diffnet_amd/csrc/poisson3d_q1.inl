@@ -442,7 +442,7 @@ extern "C" int dn_debug_stamps(void* dst, size_t bytes) { return (int)hipMemcpyF
 #endif
 
 template <int NGP, int E, bool VEC, int FL, bool UW, bool T16>
-__global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP == 2) ? DN_Q1W_WAVES_E1 : DN_Q1W_WAVES)) poisson3d_q1w_kernel(const PoissonParams p, const int chunks_x, const int tiles_y,
+__global__ void __launch_bounds__(256, NGP == 4 ? 2 : (T16 ? (NGP == 2 ? DN_Q1W_WAVES_T16 : 3) : ((E == 1 && NGP == 2) ? DN_Q1W_WAVES_E1 : DN_Q1W_WAVES))) poisson3d_q1w_kernel(const PoissonParams p, const int chunks_x, const int tiles_y,
                                                                             const int strips_z) {
     static_assert(!T16 || E == 1, "T16 is the one-element-per-thread form");
     constexpr int NW = E;
@@ -880,13 +880,13 @@ __global__ void __launch_bounds__(256, T16 ? DN_Q1W_WAVES_T16 : ((E == 1 && NGP 
 #define DN_TAB_VGPR 0             // 1: 1-D tables in vector registers (103 VGPRs, 4 waves): measured equal (profiles/r2_prio3d.txt), off
 #endif
 #ifndef DN_Q1N_WAVES
-#define DN_Q1N_WAVES 5
+#define DN_Q1N_WAVES 5            // 2 x 2 x 2 points: <= 96 VGPRs.  The 3- and 4-point rules get 3 / 2 waves per SIMD (<= 168 / 256 VGPRs): at 5 they spilled 100-500 bytes of scratch per thread
 #endif
 #ifndef DN_PRIO3D
 #define DN_PRIO3D 0               // 1 / 2: static / rotating wave priorities per workgroup: measured equal (profiles/r2_prio3d.txt), off
 #endif
 template <int NGP, int FL, bool UW>
-__global__ void __launch_bounds__(256, DN_Q1N_WAVES) poisson3d_q1n_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
+__global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 : 2)) poisson3d_q1n_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
     constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, BC_U8C = (FL & FL3_BC_U8C) != 0;
     constexpr int NMASK = !BC_U8C ? 0 : ((FL & FL3_BC_ONE) ? 1 : 2);
     // FL3_E1G: the stiffness part of the energy is not summed Gauss point by Gauss point but taken from the finished nodal values:
