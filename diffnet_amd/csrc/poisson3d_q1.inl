@@ -13,7 +13,7 @@
 
 namespace dn {
 
-enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8, FL3_BC_U8C = 16, FL3_BC_ONE = 32, FL3_E1G = 64 };   // FL3_BC_U8C: uint8 masks with constant values only; FL3_BC_ONE (node-owner form): exactly one of them
+enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8, FL3_BC_U8C = 16, FL3_BC_ONE = 32, FL3_E1G = 64, FL3_BC_F32 = 128 };   // FL3_BC_F32 (node-owner form, with FL3_BC_U8C): the constant-value masks are fp32 images (> 0.5), the reference's format   // FL3_BC_U8C: uint8 masks with constant values only; FL3_BC_ONE (node-owner form): exactly one of them
 
 template <int NGP, int E>
 struct PlaneState3D {
@@ -442,7 +442,7 @@ extern "C" int dn_debug_stamps(void* dst, size_t bytes) { return (int)hipMemcpyF
 #endif
 
 template <int NGP, int E, bool VEC, int FL, bool UW, bool T16>
-__global__ void __launch_bounds__(256, NGP == 4 ? 2 : (T16 ? (NGP == 2 ? DN_Q1W_WAVES_T16 : 3) : ((E == 1 && NGP == 2) ? DN_Q1W_WAVES_E1 : DN_Q1W_WAVES))) poisson3d_q1w_kernel(const PoissonParams p, const int chunks_x, const int tiles_y,
+__global__ void __launch_bounds__(256, NGP == 4 ? 2 : (T16 ? (NGP == 2 ? ((FL & (FL3_BC | FL3_FGP)) ? 4 : DN_Q1W_WAVES_T16) : 3) : ((E == 1 && NGP == 2) ? ((FL & (FL3_BC | FL3_FGP)) ? 4 : DN_Q1W_WAVES_E1) : DN_Q1W_WAVES))) poisson3d_q1w_kernel(const PoissonParams p, const int chunks_x, const int tiles_y,
                                                                             const int strips_z) {
     static_assert(!T16 || E == 1, "T16 is the one-element-per-thread form");
     constexpr int NW = E;
@@ -889,6 +889,7 @@ template <int NGP, int FL, bool UW>
 __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 : 2)) poisson3d_q1n_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
     constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, BC_U8C = (FL & FL3_BC_U8C) != 0;
     constexpr int NMASK = !BC_U8C ? 0 : ((FL & FL3_BC_ONE) ? 1 : 2);
+    constexpr bool MASK_F32 = (FL & FL3_BC_F32) != 0;
     // FL3_E1G: the stiffness part of the energy is not summed Gauss point by Gauss point but taken from the finished nodal values:
     // sum_a u_a out_a = alpha * sum W nu |grad u|^2 - beta * sum W f u  (u = sum_a u_a N_a), one FMA per node instead of 15 per element
     constexpr bool E1G = (FL & FL3_E1G) != 0;     // uint8 mask arrays read per node (compile-time: no load in a uniform branch)
@@ -958,10 +959,11 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
     const uint8_t* mask8[2];
     mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);      // an absent condition re-reads the other one and is
     mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);      // ignored: no load inside a wave-uniform branch
+    const float* mask32[2] = {reinterpret_cast<const float*>(mask8[0]), reinterpret_cast<const float*>(mask8[1])};
 
     // with one condition, slot 0 of mask8 / bcval is the one that is present
     const float bcval[2] = {NMASK == 1 ? (has_mask[0] ? p.bc[0].value : p.bc[1].value) : p.bc[0].value, p.bc[1].value};
-    struct RawNodes { float u[2], n[2], f[2]; uint8_t m[2][2]; };       // [0] own node, [1] halo node
+    struct RawNodes { float u[2], n[2], f[2]; uint8_t m[2][2]; float mf[2][2]; };       // [0] own node, [1] halo node
     auto plane_request = [&](int zreq, RawNodes& W) {
         const unsigned zoff = (unsigned)min(zreq, p.nz - 1) * npl;
         const unsigned o[2] = {zoff + own_off, zoff + halo_off};
@@ -972,7 +974,10 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
             if constexpr (HAS_F) W.f[h] = ld_at<float>(sb.f, o[h]);
             if constexpr (BC_U8C) {
 #pragma unroll
-                for (int k = 0; k < NMASK; ++k) W.m[h][k] = ld_at<uint8_t>(mask8[k], o[h]);
+                for (int k = 0; k < NMASK; ++k) {
+                    if constexpr (MASK_F32) W.mf[h][k] = ld_at<float>(mask32[k], o[h]);
+                    else W.m[h][k] = ld_at<uint8_t>(mask8[k], o[h]);
+                }
             }
         }
     };
@@ -984,7 +989,7 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
             if constexpr (BC_U8C) {
 #pragma unroll
                 for (int k = 0; k < NMASK; ++k) {
-                    const bool set = (NMASK == 1 || has_mask[k]) && W.m[h][k] != 0;
+                    const bool set = (NMASK == 1 || has_mask[k]) && (MASK_F32 ? W.mf[h][k] > 0.5f : W.m[h][k] != 0);
                     uu = set ? bcval[k] : uu;
                     keep = set ? 0.f : keep;
                 }
@@ -1248,16 +1253,45 @@ static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hip
     hipLaunchKernelGGL((poisson3d_q1w_kernel<NGP, E, VEC, FL, false, false>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
 }
 
+// node-owner form with fp32 mask images (constant values); only instantiated for one element per thread and nodal / absent forcing
+template <int NGP, int E, bool VEC, int FL>
+static void launch3_f32n(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
+    if constexpr (E == 1 && (FL & FL3_FGP) == 0) {
+        const dim3 grid((unsigned)((long long)g.chunks * g.tiles * g.strips * batch)), block(16, 16);
+        constexpr int F2 = FL | FL3_BC_U8C | FL3_BC_F32, F1 = F2 | FL3_BC_ONE;
+        const bool one = (pp.bc[0].mask != nullptr) != (pp.bc[1].mask != nullptr);
+        bool unit = NGP == 2;
+        for (int i = 0; i < NGP; ++i) unit = unit && pp.T.w[i] == 1.0f;
+        if constexpr (NGP == 2) {
+            if (unit) {
+                if (one) hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, F1, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+                else hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, F2, true>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+                return;
+            }
+        }
+        if (one) hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, F1, false>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+        else hipLaunchKernelGGL((poisson3d_q1n_kernel<NGP, F2, false>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
+    } else {
+        launch3_one<NGP, E, VEC, FL | FL3_BC>(pp, g, batch, s);
+    }
+}
+
 template <int NGP, int E, bool VEC>
 static void launch3_flags(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
     const int f = pp.fgp ? 2 : (pp.f ? 1 : 0);
     const bool bc = pp.bc[0].mask || pp.bc[1].mask;
-    bool u8c = bc;
-    for (int k = 0; k < 2; ++k)
+    bool u8c = bc, f32c = bc;                        // all conditions uint8 / all fp32 images, constant values
+    for (int k = 0; k < 2; ++k) {
         if (pp.bc[k].mask && (!pp.bc[k].mask_is_u8 || pp.bc[k].field)) u8c = false;
+        if (pp.bc[k].mask && (pp.bc[k].mask_is_u8 || pp.bc[k].field)) f32c = false;
+    }
+    // fp32 images with constant values (the reference's masks): the node-owner form reads them as one dword per node; everything else
+    // with fp32 masks or value fields goes through the generic form of the T16 kernel
+    const bool f32n = f32c && E == 1 && !pp.fgp && g.TX == 16 && g.TY == 16 && config(CFG_Q1_3D_T16) == nullptr;
 #define DN_L3(FLAGS)                                                                   \
     (!bc ? launch3_one<NGP, E, VEC, (FLAGS)>(pp, g, batch, s)                          \
          : u8c ? launch3_one<NGP, E, VEC, (FLAGS) | FL3_BC_U8C>(pp, g, batch, s)       \
+         : f32n ? launch3_f32n<NGP, E, VEC, (FLAGS)>(pp, g, batch, s)                  \
                : launch3_one<NGP, E, VEC, (FLAGS) | FL3_BC>(pp, g, batch, s))
     if (pp.nu) {
         if (f == 0) DN_L3(FL3_NU);
