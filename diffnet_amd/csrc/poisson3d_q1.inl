@@ -40,321 +40,9 @@ struct PlaneState3D {
 #define DN_PRIO_ROT3D 0
 #endif
 
-// NT: workgroup size the kernel is compiled for (256, 512 or 1024 threads).  Larger workgroups exist to make the in-plane
-// tile taller: the tile seam costs one recomputed thread row out of TY, and rows as wide as the mesh leave TY = 256 / TX
-// small (TX = 64 -> 4 rows = 33 % redundant work; 128 -> 2 rows = 100 %).  1024 threads need <= 128 VGPRs.
-template <int NGP, int E, bool VEC, int FL, int NT>
-__global__ void __launch_bounds__(NT, NT == 256 ? DN_Q1_3D_WAVES : 4) poisson3d_q1m_kernel(const PoissonParams p, const int chunks_x,
-                                                                                             const int tiles_y, const int strips_z) {
-    constexpr int NW = E;
-    constexpr int G = NGP * NGP * NGP;
-    constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, FGP = (FL & FL3_FGP) != 0;
-    constexpr bool BC_U8C = (FL & FL3_BC_U8C) != 0, BC_ANY = (FL & (FL3_BC | FL3_BC_U8C)) != 0;
-    const int TX = blockDim.x, TY = blockDim.y;
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int tid = ty * TX + tx;
-    // 1-D grid with an XCD-aware decode (cdna_hip_programming.md T1): workgroups are dealt round-robin to the 8 XCDs, each
-    // with its own L2.  In-plane neighbours share 2 of their TY + 1 node rows and z-neighbours one plane, so every XCD gets a
-    // contiguous range of the logical order (chunk fastest, then tile, strip, sample): the halo of a tile is then read
-    // from HBM once instead of once per XCD.  The remap is a bijection for any grid size.
-    unsigned lid = blockIdx.x;
-#ifndef DN_NO_XCD_MAP
-    {
-        const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
-        lid = xcd * base + min(xcd, rem) + idx;
-    }
-#endif
-    const int chunk = (int)(lid % (unsigned)chunks_x);
-    lid /= (unsigned)chunks_x;
-    const int tile = (int)(lid % (unsigned)tiles_y);
-    lid /= (unsigned)tiles_y;
-    const int strip = (int)(lid % (unsigned)strips_z), b = (int)(lid / (unsigned)strips_z);
-    const int q = chunk * (TX - 1) + tx;
-    const int ex0 = q * E, x0 = ex0;
-    const int ey = tile * (TY - 1) + ty;          // element row == lower node row of this thread
-    const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);
-    const unsigned npl = (unsigned)(p.nx * p.ny);
-    const int64_t nps = (int64_t)npl * p.nz;
-    const unsigned epl = (unsigned)(p.nelx * p.nely);
-    const unsigned eps = epl * (unsigned)p.nelz;
-    const SampleBases sb = sample_bases(p, b, nps);
-    const float* fgp = FGP ? p.fgp + (p.f_batched ? (int64_t)b * eps * G : 0) : nullptr;
-    const int R = p.rows_per_strip;
-    const int ez_own = strip * R;
-    const int ez_begin = ez_own > 0 ? ez_own - 1 : 0;
-    const int ez_end = min(ez_own + R, p.nelz);
-    const bool row_ok = ey < p.nely;              // thread has real elements
-    const bool noderow_ok = ey < p.ny;            // thread's lower node row exists
-
-    // hand-over slots: [parity][slot][thread]; 0 = right (row 0, n = E), 1..E = up (row 1, n < E), E+1 = up-right
-    __shared__ float xch[2][NW + 2][NT];
-    __shared__ double red[NT / 64 + 1];
-    __shared__ int last_flag;
-
-    PlaneState3D<NGP, E> SA, SB;
-    float cU[E][NGP][NGP], cX[E][NGP], cY[E][NGP];      // carried cotangents of the lower plane's stage values
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        SA.keep[e] = SB.keep[e] = 1.f;
-#pragma unroll
-        for (int j = 0; j < NGP; ++j) {
-            cX[e][j] = cY[e][j] = 0.f;
-#pragma unroll
-            for (int i = 0; i < NGP; ++i) { cU[e][j][i] = 0.f; SA.VN[e][j][i] = SB.VN[e][j][i] = 1.f; SA.VF[e][j][i] = SB.VF[e][j][i] = 0.f; }
-        }
-    }
-
-    // Every thread loads its two node rows itself (row ey+1 is also loaded by the next thread row; the duplicate is served
-    // by L1/L2).  Staging the in-plane node tile through LDS was measured 8-15 % slower at 128^3 / 256^3 (profiles/README.md:
-    // a second barrier per plane, and the kernel is not load-instruction bound) and is not in the tree any more.
-    // Holding the next plane's loads in registers one layer ahead was measured too: 115 -> 156 VGPRs, 8-17 % slower.
-    struct Pending { int z; };
-    auto issue_plane = [&](int z, Pending& pd) { pd.z = z; };
-    auto plane_stage = [&](Pending& pd, PlaneState3D<NGP, E>& S) {
-#ifndef DN_ABLATE_MEM3D
-        const int z = min(pd.z, p.nz - 1);
-#else                                      // timing experiment only: every plane re-reads the strip's first plane (cache hits)
-        const int z = ez_begin;
-#endif
-        float ru[2][NW + 1], rn[2][NW + 1], rf[2][NW + 1];
-        BcRaw<NW> braw[2];
-        uint8_t m8[2][2][NW + 1];
-        unsigned rowoff[2];
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-            const int y = min(ey + jb, p.ny - 1);       // clamped: rows beyond the domain only feed skipped elements
-            rowoff[jb] = (unsigned)z * npl + (unsigned)y * (unsigned)p.nx;
-            load_seg<NW, VEC>(sb.u, rowoff[jb], x0, p.nx, ru[jb]);
-            if constexpr (HAS_NU) load_seg<NW, VEC>(sb.nu, rowoff[jb], x0, p.nx, rn[jb]);
-            if constexpr (HAS_F) load_seg<NW, VEC>(sb.f, rowoff[jb], x0, p.nx, rf[jb]);
-            if constexpr (BC_U8C) {
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    if (sb.mask[k] != nullptr) load_seg<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff[jb], x0, p.nx, m8[jb][k]);
-            } else if constexpr (BC_ANY) {
-                bc_issue<NW, VEC>(p, sb, rowoff[jb], x0, braw[jb]);
-            }
-        }
-        if constexpr (BC_U8C) {            // uint8 masks, constant values: one compare + select per node and condition
-#pragma unroll
-            for (int n = 0; n < NW; ++n) S.keep[n] = 1.f;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (sb.mask[k] != nullptr) {
-                    const float val = p.bc[k].value;
-#pragma unroll
-                    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                        for (int n = 0; n <= NW; ++n) {
-                            const bool set = m8[jb][k][n] != 0;
-                            ru[jb][n] = set ? val : ru[jb][n];
-                            if (jb == 0 && n < NW) S.keep[n] = set ? 0.f : S.keep[n];
-                        }
-                }
-            }
-        } else if constexpr (BC_ANY) {
-            float k1[NW];
-            bc_apply<NW>(p, sb, braw[0], ru[0], S.keep);
-            bc_apply<NW>(p, sb, braw[1], ru[1], k1);
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const float dx0 = ru[0][e + 1] - ru[0][e], dx1 = ru[1][e + 1] - ru[1][e];
-#pragma unroll
-            for (int i = 0; i < NGP; ++i) {
-                const float t0 = fmaf(p.T.b[i][1], dx0, ru[0][e]);
-                S.VY[e][i] = fmaf(p.T.b[i][1], dx1, ru[1][e]) - t0;
-#pragma unroll
-                for (int j = 0; j < NGP; ++j) S.VU[e][j][i] = fmaf(p.T.b[j][1], S.VY[e][i], t0);
-            }
-#pragma unroll
-            for (int j = 0; j < NGP; ++j) S.VX[e][j] = fmaf(p.T.b[j][1], dx1 - dx0, dx0);
-            if constexpr (HAS_NU) {
-                const float d0 = rn[0][e + 1] - rn[0][e], d1 = rn[1][e + 1] - rn[1][e];
-#pragma unroll
-                for (int i = 0; i < NGP; ++i) {
-                    const float t0 = fmaf(p.T.b[i][1], d0, rn[0][e]);
-                    const float dy = fmaf(p.T.b[i][1], d1, rn[1][e]) - t0;
-#pragma unroll
-                    for (int j = 0; j < NGP; ++j) S.VN[e][j][i] = fmaf(p.T.b[j][1], dy, t0);
-                }
-            }
-            if constexpr (HAS_F) {
-                const float d0 = rf[0][e + 1] - rf[0][e], d1 = rf[1][e + 1] - rf[1][e];
-#pragma unroll
-                for (int i = 0; i < NGP; ++i) {
-                    const float t0 = fmaf(p.T.b[i][1], d0, rf[0][e]);
-                    const float dy = fmaf(p.T.b[i][1], d1, rf[1][e]) - t0;
-#pragma unroll
-                    for (int j = 0; j < NGP; ++j) S.VF[e][j][i] = fmaf(p.T.b[j][1], dy, t0);
-                }
-            }
-        }
-    };
-
-    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
-    int par = 0;
-
-    // in-plane transpose (y then x) of the cotangents of one plane's stage values -> contributions to the 2 x (E+1) nodes
-    auto plane_transpose = [&](int e, const float (&tU)[NGP][NGP], const float (&tX)[NGP], const float (&tY)[NGP], float (&o)[2][NW + 1]) {
-        float s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < NGP; ++i) {
-            float s = 0.f, t = 0.f;
-#pragma unroll
-            for (int j = 0; j < NGP; ++j) { s += tU[j][i]; t = fmaf(p.T.b[j][1], tU[j][i], t); }
-            const float c1 = t + tY[i], c0 = s - c1;            // cot of the x-lerped rows tv1[i], tv0[i]
-            s0 += c0; t0 = fmaf(p.T.b[i][1], c0, t0);
-            s1 += c1; t1 = fmaf(p.T.b[i][1], c1, t1);
-        }
-        float sX = 0.f, d1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NGP; ++j) { sX += tX[j]; d1 = fmaf(p.T.b[j][1], tX[j], d1); }
-        const float g01 = t0 + (sX - d1), g11 = t1 + d1;
-        o[0][e + 1] += g01; o[0][e] += s0 - g01;
-        o[1][e + 1] += g11; o[1][e] += s1 - g11;
-    };
-
-    // Emit node plane z, row ey, nodes x0..x0+E-1 from o (+ the neighbours' hand-overs).
-    auto emit_plane = [&](const float (&o)[2][NW + 1], const float (&keep)[NW], int z, bool owned_plane) {
-#ifndef DN_ABLATE_XCH3D                    // timing experiment only: drop the neighbour hand-over and its barrier
-        xch[par][0][tid] = o[0][NW];
-#pragma unroll
-        for (int n = 0; n < NW; ++n) xch[par][1 + n][tid] = o[1][n];
-        xch[par][NW + 1][tid] = o[1][NW];
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-        if (owned_plane && owner && noderow_ok) {
-            float v[NW];
-#pragma unroll
-            for (int n = 0; n < NW; ++n) {
-                float t = o[0][n];
-                if (ty > 0) t += xch[par][1 + n][tid - TX];
-                if (n == 0) {
-                    if (tx > 0) t += xch[par][0][tid - 1];
-                    if (tx > 0 && ty > 0) t += xch[par][NW + 1][tid - TX - 1];
-                }
-                t *= keep[n];
-                sq_acc = fmaf(t, t, sq_acc);
-                v[n] = t * p.out_scale;
-            }
-#ifndef DN_ABLATE_STORE3D
-            if (sb.out) store_seg<NW, VEC>(sb.out, (unsigned)z * npl + (unsigned)ey * (unsigned)p.nx, x0, p.nx, v);
-#else
-            if (sb.out && v[0] == 123.456f) store_seg<NW, VEC>(sb.out, (unsigned)z * npl + (unsigned)ey * (unsigned)p.nx, x0, p.nx, v);
-#endif
-        }
-        par ^= 1;
-    };
-
-    auto layer = [&](int ez, const PlaneState3D<NGP, E>& L, const PlaneState3D<NGP, E>& U) {
-        const bool own_layer = ez >= ez_own;
-        const float cnt = (own_layer && owner) ? 1.f : 0.f;
-        float o[2][NW + 1], le1 = 0.f, le2 = 0.f;
-#pragma unroll
-        for (int n = 0; n <= NW; ++n) o[0][n] = o[1][n] = 0.f;
-        if (row_ok) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                if (ex0 + e < p.nelx) {       // also a scheduling fence between the element streams (see the 2-D kernel)
-                    float fg[G];
-                    if constexpr (FGP) {
-                        const unsigned eo = (unsigned)ez * epl + (unsigned)ey * (unsigned)p.nelx + (unsigned)(ex0 + e);
-#pragma unroll
-                        for (int gi = 0; gi < G; ++gi) fg[gi] = fgp[eo + (unsigned)gi * eps];
-                    }
-                    float lU[NGP][NGP], uU[NGP][NGP], lX[NGP], uX[NGP], lY[NGP], uY[NGP], e1, e2;
-#ifndef DN_ABLATE_COMPUTE
-                    q1_layer_3d<NGP, FGP>(p.T, L.VU[e], U.VU[e], L.VX[e], U.VX[e], L.VY[e], U.VY[e], L.VN[e], U.VN[e], L.VF[e], U.VF[e],
-                                          fg, lU, uU, lX, uX, lY, uY, e1, e2);
-#else                                      // timing experiment only
-#pragma unroll
-                    for (int j = 0; j < NGP; ++j) {
-                        lX[j] = L.VX[e][j]; uX[j] = U.VX[e][j]; lY[j] = L.VY[e][j]; uY[j] = U.VY[e][j];
-#pragma unroll
-                        for (int i = 0; i < NGP; ++i) { lU[j][i] = L.VU[e][j][i] + U.VN[e][j][i]; uU[j][i] = U.VU[e][j][i] + U.VF[e][j][i]; }
-                    }
-                    e1 = lX[0]; e2 = uX[0];
-#endif
-                    le1 += e1;
-                    le2 += e2;
-#pragma unroll
-                    for (int j = 0; j < NGP; ++j) {
-                        lX[j] += cX[e][j]; lY[j] += cY[e][j];
-                        cX[e][j] = uX[j]; cY[e][j] = uY[j];
-#pragma unroll
-                        for (int i = 0; i < NGP; ++i) { lU[j][i] += cU[e][j][i]; cU[e][j][i] = uU[j][i]; }
-                    }
-                    plane_transpose(e, lU, lX, lY, o);
-                }
-            }
-        }
-        e1_acc = fmaf(cnt, le1, e1_acc);
-        e2_acc = fmaf(cnt, le2, e2_acc);
-        emit_plane(o, L.keep, ez, own_layer);
-    };
-
-    Pending pd;
-    issue_plane(ez_begin, pd);
-    plane_stage(pd, SA);
-    issue_plane(ez_begin + 1, pd);
-#if DN_NGP == 2 && !defined(DN_NO_PINGPONG3D)
-    // two layers per trip with the roles of the two plane states swapped: no state copy at the end of a layer
-    // (-1..3 % at 2x2x2 points; the larger rules do not have the registers for the doubled loop body)
-    {
-        int ez = ez_begin;
-        for (; ez + 1 < ez_end; ez += 2) {
-            plane_stage(pd, SB);
-            issue_plane(ez + 2, pd);
-            layer(ez, SA, SB);
-            plane_stage(pd, SA);
-            issue_plane(ez + 3, pd);
-            layer(ez + 1, SB, SA);
-        }
-        if (ez < ez_end) {
-            plane_stage(pd, SB);
-            layer(ez, SA, SB);
-            SA = SB;
-        }
-    }
-#else
-    for (int ez = ez_begin; ez < ez_end; ++ez) {
-#if DN_PRIO_ROT3D
-        switch ((ez_end - ez) & 3) {       // progress-dependent wave priority (see the 2-D kernel)
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
-        }
-#endif
-        plane_stage(pd, SB);               // plane ez+1 (loads issued one layer ago)
-#ifndef DN_NO_PREFETCH3D
-        issue_plane(ez + 2, pd);           // prefetch: lands while this layer is computed (the emit barrier is LDS-only)
-#endif
-        layer(ez, SA, SB);
-        SA = SB;
-#ifdef DN_NO_PREFETCH3D
-        issue_plane(ez + 2, pd);
-#endif
-    }
-#endif
-    if (ez_end == p.nelz) {       // the last strip owns the top boundary plane: only the layer below contributes
-        float o[2][NW + 1];
-#pragma unroll
-        for (int n = 0; n <= NW; ++n) o[0][n] = o[1][n] = 0.f;
-        if (row_ok) {
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if (ex0 + e < p.nelx) plane_transpose(e, cU[e], cX[e], cY[e], o);
-        }
-        emit_plane(o, SA.keep, p.nz - 1, true);
-    }
-
-    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, TX * TY, red, &last_flag);
-}
-
 // =============================================================================================================
-// Second-generation kernel (default): same mapping, hand-over and reductions, ~1/3 fewer VALU instructions per element.
+// Second-generation kernel (the round-1 kernel it replaced -- poisson3d_q1m_kernel, ~1/3 more VALU instructions per element -- is no longer
+// in the tree; its numbers stay in profiles/r1_*): same mapping, hand-over and reductions.
 //   * coefficient planes are staged WEIGHTED (w_j w_i nu, w_j w_i f) together with their in-plane sums A[j], B[i], once per
 //     plane; the layer arithmetic (q1_layer_3d_w) works on raw differences and applies 1/h^2, alpha and the user scale
 //     once per element; carried cotangents are folded into the layer's own fused multiply-adds;
@@ -452,7 +140,11 @@ __global__ void __launch_bounds__(256, NGP == 4 ? 2 : (T16 ? (NGP == 2 ? ((FL & 
     const int TX = blockDim.x, TY = blockDim.y;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * TX + tx;
-    unsigned lid = blockIdx.x;                    // XCD-aware decode, see poisson3d_q1m_kernel
+    // 1-D grid with an XCD-aware decode (cdna_hip_programming.md T1): workgroups are dealt round-robin to the 8 XCDs, each with its
+    // own L2.  In-plane neighbours share node rows and z-neighbours one plane, so every XCD gets a contiguous range of the logical
+    // order (chunk fastest, then tile, strip, sample): the halo of a tile is then read from HBM once instead of once per XCD.  The
+    // remap is a bijection for any grid size.
+    unsigned lid = blockIdx.x;
     {
         const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
         lid = xcd * base + min(xcd, rem) + idx;
@@ -897,7 +589,7 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
     constexpr int E = 1, NW = 1;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int tid = ty * 16 + tx;
-    unsigned lid = blockIdx.x;                    // XCD-aware decode, see poisson3d_q1m_kernel
+    unsigned lid = blockIdx.x;                    // XCD-aware decode, see poisson3d_q1w_kernel
     {
         const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
         lid = xcd * base + min(xcd, rem) + idx;
@@ -1203,10 +895,6 @@ extern "C" int dn_debug_occupancy_q1n(void) {
 template <int NGP, int E, bool VEC, int FL>
 static void launch3_one(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
     const dim3 grid((unsigned)((long long)g.chunks * g.tiles * g.strips * batch)), block(g.TX, g.TY);
-    if (config(CFG_Q1_3D_V1) != nullptr) {             // first-generation kernel, kept for A/B runs
-        hipLaunchKernelGGL((poisson3d_q1m_kernel<NGP, E, VEC, FL, 256>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips);
-        return;
-    }
     bool unit = true;                                   // the exact 2-point rule: all weights 1
     for (int i = 0; i < NGP; ++i) unit = unit && pp.T.w[i] == 1.0f;
     if constexpr (E == 1 && (FL & (FL3_FGP | FL3_BC)) == 0) {
@@ -1308,10 +996,6 @@ static void launch3_flags(const PoissonParams& pp, const Geom3D& g, int batch, h
 #define DN_CAT2(a, b) a##b
 #define DN_CAT(a, b) DN_CAT2(a, b)
 int DN_CAT(launch_poisson3d_q1_g, DN_NGP)(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s) {
-#if DN_NGP == 2
-    if (g.E == 2 && vec) { launch3_flags<DN_NGP, 2, true>(pp, g, batch, s); return 0; }
-    if (g.E == 2) { launch3_flags<DN_NGP, 2, false>(pp, g, batch, s); return 0; }
-#endif
     if (g.E == 1) { launch3_flags<DN_NGP, 1, false>(pp, g, batch, s); return 0; }
     return DN_E_UNSUPPORTED;
 }
