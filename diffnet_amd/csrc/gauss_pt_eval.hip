@@ -333,6 +333,100 @@ __global__ void __launch_bounds__(256) gpe_bwd_tiled_kernel(const float* __restr
     }
 }
 
+// Marching adjoint for 3-D Q1 (standard layout, any number G of tables): the scheme of the fused 3-D kernel without the physics.
+// A workgroup owns 16 x 16 elements of a plane (tiles step by 15) and marches over R element planes (+ one recomputed plane below the
+// strip); a thread reads its element's G values once per plane (coalesced dwords), forms the 8 nodal contributions sum_g tab[g][a] v_g
+// (table entries through scalar loads: uniform index), carries the four of the upper plane in registers and hands the in-plane ones
+// over to the right / upper / upper-right neighbour (ds_bpermute + one LDS slot, one barrier per plane).  Every Gauss-point value is
+// read once (the tiled kernel re-reads 35 % of them and gathers the nodes with per-node index arithmetic): 128^3 x 2, G = 8: 80 -> ~45 us.
+// Summation order per node is fixed (own element, left, lower, then the plane below): deterministic.
+__device__ __forceinline__ float gpe_from_left(float v, int from, float nf) {
+    return nf * __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, v)));
+}
+
+template <bool G8>            // G8: exactly 8 tables (the 2 x 2 x 2 rule): the next plane's 8 values are in flight while this plane is reduced
+__global__ void __launch_bounds__(256) gpe_bwd_march3d_q1_kernel(const float* __restrict__ gout, const float* __restrict__ tables,
+                                                                  float* __restrict__ gin, const GpeGeom g, const int chunks_x,
+                                                                  const int tiles_y, const int strips_z, const int R) {
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 16 + tx;
+    unsigned lid = blockIdx.x;
+    {   // XCD-aware decode (workgroups are dealt round-robin to the 8 XCDs): every XCD gets a contiguous range of the logical order, so
+        // x-neighbouring tiles -- which share every 128-byte line of a 64-byte tile row -- meet in one L2
+        const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
+        lid = xcd * base + min(xcd, rem) + idx;
+    }
+    const int chunk = (int)(lid % (unsigned)chunks_x); lid /= (unsigned)chunks_x;
+    const int tile = (int)(lid % (unsigned)tiles_y); lid /= (unsigned)tiles_y;
+    const int strip = (int)(lid % (unsigned)strips_z), b = (int)(lid / (unsigned)strips_z);
+    const int ex = chunk * 15 + tx, ey = tile * 15 + ty;                 // element == its lower-left node
+    const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);
+    const bool node_ok = ex < g.n[0] && ey < g.n[1];
+    const float okf = (ex < g.nel[0] && ey < g.nel[1]) ? 1.f : 0.f;       // elements beyond the mesh: clamped loads, zero weight
+    const unsigned epl = (unsigned)(g.nel[0] * g.nel[1]), eps = epl * (unsigned)g.nel[2];
+    const unsigned npl = (unsigned)(g.n[0] * g.n[1]);
+    const float* src = gout + (size_t)b * g.G * eps;
+    float* dst = gin + (size_t)b * npl * g.n[2];
+    const unsigned eoff = (unsigned)min(ey, g.nel[1] - 1) * (unsigned)g.nel[0] + (unsigned)min(ex, g.nel[0] - 1);
+    const unsigned noff = (unsigned)ey * (unsigned)g.n[0] + (unsigned)ex;
+    const int ez_own = strip * R, ez_begin = ez_own > 0 ? ez_own - 1 : 0, ez_end = min(ez_own + R, g.nel[2]);
+    __shared__ float xch[2][256];
+    const int from_left = (int)(((unsigned)tid - 1u) & 63u) << 2;
+    const float nfirst = tx > 0 ? 1.f : 0.f;
+    int par = 0;
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};          // contributions of the plane below to this plane's nodes (i, j) = [j * 2 + i]
+
+    auto emit = [&](const float (&o)[4], int z, bool owned_plane) {      // o: this element's share of its four nodes in node plane z
+        const float left = gpe_from_left(o[1], from_left, nfirst);
+        xch[par][tid] = o[2] + gpe_from_left(o[3], from_left, nfirst);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float t = o[0] + left;
+        if (ty > 0) t += xch[par][tid - 16];
+        par ^= 1;
+        if (owned_plane && owner && node_ok) dst[(size_t)z * npl + noff] = t;
+    };
+
+    float vn[8];
+    if constexpr (G8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vn[k] = src[(size_t)k * eps + (size_t)ez_begin * epl + eoff];
+    }
+    for (int ez = ez_begin; ez < ez_end; ++ez) {
+        const float* pe = src + (size_t)ez * epl + eoff;
+        float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (G8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = vn[k];
+            const size_t nxt = (size_t)min(ez + 1, g.nel[2] - 1) * epl + eoff;          // beyond the strip: re-read the last plane (unused)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vn[k] = src[(size_t)k * eps + nxt];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* tp = tables + k * 8;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) c[a] = fmaf(tp[a], v[k], c[a]);
+            }
+        } else
+        for (int g0 = 0; g0 < g.G; g0 += 4) {        // four Gauss-point planes in flight (they are megabytes apart)
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = pe[(size_t)min(g0 + k, g.G - 1) * eps];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool live = g0 + k < g.G;
+                const float* tp = tables + min(g0 + k, g.G - 1) * 8;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) c[a] = fmaf(live ? tp[a] : 0.f, v[k], c[a]);
+            }
+        }
+        float o[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { o[a] = fmaf(okf, c[a], carry[a]); carry[a] = okf * c[4 + a]; }
+        emit(o, ez, ez >= ez_own);
+    }
+    if (ez_end == g.nel[2]) emit(carry, g.n[2] - 1, true);                // the last strip owns the top node plane
+}
+
 // Standard-layout assembly: all candidate loads first, then added in ascending local id (upper element = local 0 first),
 // the order of the reference's sliced "+=" lines.
 template <int NSD, int NB>
@@ -500,6 +594,22 @@ extern "C" int dn_gauss_pt_eval_bwd(const float* grad_out, const float* tables, 
     const size_t lds_t = sizeof(float) * (size_t)nbt * ((G + 3) & ~3);
     if (stride == nbf - 1 && lds_t <= 64 * 1024 && (int64_t)g.nel[0] * g.nel[1] * g.nel[2] * G < (1ll << 31) &&
         (int64_t)g.n[0] * g.n[1] * g.n[2] < (1ll << 31)) {
+    if (nsd == 3 && nbf == 2 && g.n[0] >= 2 && config(CFG_GPE_GATHER) == nullptr && config(CFG_GPE_TILED) == nullptr) {
+        // 3-D Q1: marching adjoint (every value read once).  Strip height: >= 4 workgroups per CU where the mesh allows it
+        // one thread column / row per NODE column / row (the closing one has no element of its own), tiles overlap by one thread
+        const int chunks = g.n[0] <= 16 ? 1 : (g.n[0] - 1 + 14) / 15, tiles = g.n[1] <= 16 ? 1 : (g.n[1] - 1 + 14) / 15;
+        int R = 32;
+        while (R > 8 && (int64_t)chunks * tiles * batch * ((g.nel[2] + R - 1) / R) < 2560) R /= 2;
+        if (R > g.nel[2]) R = g.nel[2];
+        const int strips = (g.nel[2] + R - 1) / R;
+        const int64_t nblk = (int64_t)chunks * tiles * strips * batch;
+        if (nblk < (1ll << 31)) {
+            if (G == 8) hipLaunchKernelGGL(gpe_bwd_march3d_q1_kernel<true>, dim3((unsigned)nblk), dim3(16, 16), 0, s, grad_out, tables, grad_in, g, chunks, tiles, strips, R);
+            else hipLaunchKernelGGL(gpe_bwd_march3d_q1_kernel<false>, dim3((unsigned)nblk), dim3(16, 16), 0, s, grad_out, tables, grad_in, g, chunks, tiles, strips, R);
+            DN_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     {   // tiled element-centric adjoint where its LDS tile fits (all 2-D cases, 3-D Q1 / Q2)
         const int S = nbf - 1;
         const size_t tile_floats = (size_t)nbt * (nsd == 2 ? 1024 : 2048);       // contrib[NB^nsd][tile elements]

@@ -54,3 +54,31 @@ def test_3d_energy_from_nodal_values_equals_the_gauss_point_sum():
             _lib.config_set("Q1_3D_E1SUM", "")
         assert torch.equal(ga, gb)
         np.testing.assert_allclose(float(la), float(lb), rtol=3e-6)
+
+
+@pytest.mark.parametrize("sizes,ngp,B", [((17, 23, 29), 2, 2), ((33, 18, 16), 3, 1), ((16, 16, 40), 2, 3), ((5, 4, 3), 2, 1)])
+def test_3d_q1_marching_adjoint_equals_the_tiled_adjoint(sizes, ngp, B):
+    """gauss_pt_eval VJP in 3-D Q1: the marching kernel (every Gauss-point value read once) against the tiled LDS kernel
+    (dn_config_set("GPE_TILED")) on ragged, multi-tile, multi-strip meshes; both against autograd of the oracle's conv formulation."""
+    from diffnet_amd import _lib
+    from oracle.fem_oracle import Oracle
+    kw = dict(nsd=3, domain_sizes=sizes, domain_lengths=(1.0, 1.3, 0.7), domain_size=sizes[0], ngp_1d=ngp)
+    m, o = module(kw), Oracle(**kw)
+    u = seeded((B, 1, sizes[2], sizes[1], sizes[0]), 5)
+    for name in ("N_gp", "dN_x_gp", "dN_z_gp"):
+        ur = u.clone().requires_grad_(True)
+        y = o.ev(ur, name)
+        cot = seeded(tuple(y.shape), 6)
+        (ref,) = torch.autograd.grad(y, ur, cot)
+        fn = {"N_gp": m.gauss_pt_evaluation, "dN_x_gp": m.gauss_pt_evaluation_der_x, "dN_z_gp": m.gauss_pt_evaluation_der_z}[name]
+        got = {}
+        for tiled in ("", "1"):
+            _lib.config_set("GPE_TILED", tiled)
+            try:
+                ug = cu(u).requires_grad_(True)
+                (g,) = torch.autograd.grad(fn(ug), ug, cu(cot))
+            finally:
+                _lib.config_set("GPE_TILED", "")
+            got[tiled] = g
+            close(g, ref.numpy(), rtol=1e-5, arel=2e-6, msg=f"{name} tiled={tiled!r}")
+        close(got[""], got["1"].cpu().numpy(), rtol=2e-6, arel=2e-6)
