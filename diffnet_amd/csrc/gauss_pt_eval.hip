@@ -243,6 +243,11 @@ __global__ void __launch_bounds__(256) gpe_bwd_tiled_kernel(const float* __restr
     extern __shared__ float contrib[];                                          // [NBT][TZ][TY][TX]
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                     // 32 x 8 threads
     unsigned t = blockIdx.x;
+    {   // XCD-aware decode: x-neighbouring tiles share cache lines of every element row (rows are not line-aligned); a contiguous range of
+        // the logical tile order per XCD lets them meet in one L2
+        const unsigned nwg = gridDim.x, xcd = t & 7u, idx = t >> 3, base = nwg >> 3, rem = nwg & 7u;
+        t = xcd * base + min(xcd, rem) + idx;
+    }
     const int tix = (int)(t % (unsigned)tiles_x); t /= (unsigned)tiles_x;
     const int tiy = (int)(t % (unsigned)tiles_y); t /= (unsigned)tiles_y;
     const int tiz = (int)(t % (unsigned)tiles_z);
