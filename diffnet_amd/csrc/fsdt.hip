@@ -73,12 +73,26 @@ __device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        // on the critical path of the whole launch: the partials of all three sums are requested eight at a time before any is added
+        // (one L2 round trip per 24 loads instead of per load; same per-thread order of additions: bitwise the same sums)
+        double e3[3] = {0.0, 0.0, 0.0};
+        for (int i0 = tid; i0 < nblocks; i0 += nthreads * 8) {
+            double v[3][8];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = i0 + j * nthreads;
+                    v[k][j] = __hip_atomic_load(&p.part[(size_t)k * nblocks + (i < nblocks ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e3[k] += (i0 + j * nthreads < nblocks) ? v[k][j] : 0.0;
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            double e = 0.0;
-            for (int i = tid; i < nblocks; i += nthreads)
-                e += __hip_atomic_load(&p.part[(size_t)k * nblocks + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            e = block_sum(e, red, tid, nthreads);
+            const double e = block_sum(e3[k], red, tid, nthreads);
             if (tid == 0) p.sumsq[k] = e;
         }
         if (tid == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
