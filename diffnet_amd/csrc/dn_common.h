@@ -41,6 +41,23 @@ __device__ __forceinline__ double block_sum(double v, double* scratch, int tid, 
     return r;
 }
 
+// Two block sums in one pass (one LDS exchange, two barriers instead of four); results valid in thread 0.  `scratch` holds
+// >= 2 * blockDim / 64 doubles.  Same order of additions as two block_sum calls.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* scratch, int tid, int nthreads) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = tid & (DN_WAVE - 1), wave = tid / DN_WAVE;
+    const int nw = (nthreads + DN_WAVE - 1) / DN_WAVE;
+    if (lane == 0) { scratch[wave] = a; scratch[nw + wave] = b; }
+    __syncthreads();
+    double ra = 0.0, rb = 0.0;
+    if (tid == 0) {
+        for (int w = 0; w < nw; ++w) { ra += scratch[w]; rb += scratch[nw + w]; }
+    }
+    __syncthreads();
+    a = ra; b = rb;
+}
+
 template <int N>
 struct VecT;
 template <>

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256, NGP == 4 ? 2 : (T16 ? (NGP == 2 ? ((FL & 
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
 #endif
     __shared__ float xch[2][T16 ? 1 : NW + 2][256];
-    __shared__ double red[256 / 64 + 1];
+    __shared__ double red[2 * (256 / 64)];      // block_sum2: two sums per wave
     __shared__ int last_flag;
 
     PlaneW<NGP, E> SA, SB;
@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
 #endif
     __shared__ float4 rec[2][17 * 17];            // [plane parity][node row * 17 + node column] = {u after Dirichlet, nu, f, keep}
     __shared__ float xch[2][256];
-    __shared__ double red[256 / 64 + 1];
+    __shared__ double red[2 * (256 / 64)];      // block_sum2: two sums per wave
     __shared__ int last_flag;
 
     // in-plane offsets (nodes, clamped into the mesh) of the node this thread owns and of the halo node it fetches

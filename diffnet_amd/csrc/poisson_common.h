@@ -124,8 +124,8 @@ __device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, fl
                                             double* red, int* flag, double escale = 1.0) {
     const int nblocks = gridDim.x * gridDim.y * gridDim.z;
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const double es = block_sum(escale * ((double)p.T.c * (double)e1 - (double)e2), red, tid, nthreads);
-    const double ss = block_sum((double)sq, red, tid, nthreads);
+    double es = escale * ((double)p.T.c * (double)e1 - (double)e2), ss = (double)sq;
+    block_sum2(es, ss, red, tid, nthreads);
     if (tid == 0) {
         // write-through (sc1) 8-byte stores + drain instead of an agent-scope release fence: a release is a
         // `buffer_wbl2` of the whole XCD L2, i.e. every workgroup would wait for everybody's freshly written
@@ -154,27 +154,27 @@ __device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, fl
         }
         __syncthreads();
         // the last arriver's loop sits on the critical path of the whole launch (every other workgroup has finished): eight partials of
-        // each sum are requested before the first is added (one L2 round trip per 8 instead of per 1; 2048 workgroups x 128 threads:
-        // 2 trips instead of 16).  Same per-thread order of additions as the plain loop: bitwise the same sums.
+        // each sum are requested before the first is added (one L2 round trip per 16 partials instead of per 1; 2048 workgroups x 128
+        // threads: 1 trip instead of 16).  Same per-thread order of additions as the plain loop: bitwise the same sums.
         double e = 0.0, s = 0.0;
-        for (int i0 = tid; i0 < nblocks; i0 += nthreads * 8) {
-            double ve[8], vs[8];
+        constexpr int NB_ = 16;                       // partials of each sum in flight per thread
+        for (int i0 = tid; i0 < nblocks; i0 += nthreads * NB_) {
+            double ve[NB_], vs[NB_];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < NB_; ++k) {
                 const int i = i0 + k * nthreads;
                 const int ic = i < nblocks ? i : 0;
                 ve[k] = __hip_atomic_load(&p.part_energy[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 vs[k] = __hip_atomic_load(&p.part_sumsq[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < NB_; ++k) {
                 const bool ok = i0 + k * nthreads < nblocks;
                 e += ok ? ve[k] : 0.0;
                 s += ok ? vs[k] : 0.0;
             }
         }
-        e = block_sum(e, red, tid, nthreads);
-        s = block_sum(s, red, tid, nthreads);
+        block_sum2(e, s, red, tid, nthreads);
         if (tid == 0) {
             if (p.energy) *p.energy = e;
             if (p.sumsq) *p.sumsq = s;
