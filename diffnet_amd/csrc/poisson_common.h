@@ -133,16 +133,21 @@ __device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, fl
         __hip_atomic_store(&p.part_energy[blk], es, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&p.part_sumsq[blk], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int nshard = nblocks < DN_NSHARD ? nblocks : DN_NSHARD;
-        const int shard = blk % nshard;
-        const unsigned in_shard = (unsigned)((nblocks - shard + nshard - 1) / nshard);
-        unsigned* sc = p.counter + 16 * (1 + shard);              // shard counters: one per 64-B line
         int last = 0;
-        const unsigned prev = __hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == in_shard - 1) {
-            __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned prev2 = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (prev2 == (unsigned)(nshard - 1)) ? 1 : 0;
+        if (nblocks <= DN_NSHARD) {              // few workgroups: one counter, one atomic round trip on the launch's critical path
+            const unsigned prev = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (prev == (unsigned)(nblocks - 1)) ? 1 : 0;
+        } else {
+            const int nshard = DN_NSHARD;
+            const int shard = blk % nshard;
+            const unsigned in_shard = (unsigned)((nblocks - shard + nshard - 1) / nshard);
+            unsigned* sc = p.counter + 16 * (1 + shard);              // shard counters: one per 64-B line
+            const unsigned prev = __hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == in_shard - 1) {
+                __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned prev2 = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = (prev2 == (unsigned)(nshard - 1)) ? 1 : 0;
+            }
         }
         *flag = last;
     }
