@@ -182,7 +182,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=400,
+                    help="untimed steps before the timed ones.  Default 400 (about 20 ms of load): between about 1.3 and 10 ms after the "
+                         "GPU leaves idle the launch runs 10-15 %% slower (power-management transient, tools/ramp2d.py, "
+                         "profiles/r2_ramp2d.txt); 400 steps put the default run past it")
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ngp", type=int, default=3)
@@ -283,14 +286,19 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # one pair of HIP events on the launch stream around the K timed launches (two records in total, none between the launches)
+    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
+    region[0].record()
     for _ in range(args.steps):
         step()
+    region[1].record()
     drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    region_ms = region[0].elapsed_time(region[1]) / args.steps
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -298,8 +306,19 @@ def main():
 
     # dominant-kernel time: HIP events on the launch stream around each dn_poisson_apply (ONE kernel: the fused
     # Poisson kernel, whose last workgroup also does the fixed-order final reduction), K launches
+    # launches, each between its own pair of events (a pair costs the launch about 2 us: 2000 launches back to back complete one every
+    # 47.5 us, tools/overlap_check.py).  A short run (the driver's is 5 + 20 steps, 1.3 ms of load) would put these launches into the
+    # power-management transient 1.3-10 ms after load onset (tools/ramp2d.py: 55-58 us instead of 49.6), which says nothing about the
+    # kernel; SETTLE untimed launches first carry the GPU past it.  The transient is reported as roofline.kernel_avg_ms_first_launches.
     from diffnet_amd import ops
-    K = min(args.steps, 100)
+    K, SETTLE = 100, 400
+    first = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in first:
+        a.record()
+        plans[0].launch()
+        b.record()
+    for _ in range(SETTLE):
+        plans[0].launch()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     scale = 1.0 / (B * m.geom.nelem_total)
     for a, b in evs:            # the same prepared launch as the timed steps (no allocation between the events)
@@ -355,6 +374,9 @@ def main():
                          "kernel": "poisson fused kernel (one launch per dn_poisson_apply)", "kernel_avg_ms": kern_avg_ms,
                          "kernel_median_ms": kern_med_ms, "kernel_min_ms": kern_ms[0], "kernel_max_ms": kern_ms[-1],
                          "frac_at_median": alg_bytes / (kern_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
+                         "kernel_avg_ms_first_launches": sum(a.elapsed_time(b) for a, b in first) / len(first),
+                         "timed_region_ms_per_launch": region_ms,
+                         "frac_over_timed_region": alg_bytes / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_median_us_by_mask_format": bc_forms_us},
         }
         if not args.no_cpu and world == 1:
