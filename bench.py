@@ -197,7 +197,8 @@ def main():
                     help="strong-scaling variant (not the default metric run): ONE 3-D mesh of --size^3 nodes cut into z-slabs over "
                          "the ranks (diffnet_amd/slab.py): per step one 8-byte all-reduce + one node-layer exchange per interior face")
     ap.add_argument("--slab-size", type=int, default=256, help="mesh of the slab leg appended to the default run (0 = skip)")
-    ap.add_argument("--slab-steps", type=int, default=50)
+    ap.add_argument("--slab-steps", type=int, default=100)
+    ap.add_argument("--slab-warmup", type=int, default=300, help="untimed steps of the slab leg (past the load-onset transient: profiles/r2_ramp3d.txt)")
     ap.add_argument("--slab-batch", type=int, default=1, help="samples of the slab leg's mesh (BASELINE configs[3] is parametric: the reference trains it with batch 8)")
     ap.add_argument("--slab-timeout", type=float, default=180.0, help="watchdog of the slab leg, seconds")
     args = ap.parse_args()
@@ -399,7 +400,7 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            slab = slab_leg(args, rank, world, dev, dist, args.slab_size, args.slab_batch, 2, args.slab_steps, 10)
+            slab = slab_leg(args, rank, world, dev, dist, args.slab_size, args.slab_batch, 2, args.slab_steps, args.slab_warmup)
             if rank == 0:
                 out["slab_3d"] = slab
         except Exception as e:                       # noqa: BLE001 -- reported, not hidden: the line says what failed

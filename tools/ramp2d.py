@@ -3,15 +3,23 @@
 The driver's bench run is 5 + 20 launches (about 1.3 ms of GPU time), so the first milliseconds are what it sees."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diffnet_amd import BoxFaces, DiffNet2DFEM, ops
+from diffnet_amd import BoxFaces, DiffNet2DFEM, DiffNet3DFEM, ops
 dev = torch.device("cuda:0")
-m = DiffNet2DFEM(None, domain_size=512, ngp_1d=3).to(dev)
-shape = (64, 1, 512, 512)
+# usage: ramp2d.py [nsd n ngp B]   (default: the bench workload, 2 512 3 64)
+nsd, n, ngp, B = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (2, 512, 3, 64)
+m = (DiffNet3DFEM if nsd == 3 else DiffNet2DFEM)(None, domain_size=n, ngp_1d=ngp, nsd=nsd).to(dev)
+shape = (B, 1, *m.geom.node_shape)
 g = torch.Generator().manual_seed(1)
 u, nu, f = (torch.rand(shape, generator=g).to(dev) for _ in range(3))
 nu += 0.5
-scale = 1.0 / (64 * m.geom.nelem_total)
-pl = ops.PoissonPlan(m.geom, u, nu, f, None, [(BoxFaces(), 0.0)], alpha=2.0, beta=1.0, c=1.0, wscale=1.0, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
+scale = 1.0 / (B * m.geom.nelem_total)
+if nsd == 2:
+    cond = [(BoxFaces(), 0.0)]
+else:
+    bc = torch.zeros(shape, dtype=torch.uint8, device=dev)
+    bc[..., 0] = 1; bc[..., -1] = 1
+    cond = [(bc, 0.0)]
+pl = ops.PoissonPlan(m.geom, u, nu, f, None, cond, alpha=2.0, beta=1.0, c=1.0, wscale=1.0, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
 torch.cuda.synchronize()
 
 
@@ -31,7 +39,7 @@ def series(n, label):
     print(f"{label}: us per launch by launch index: " + "  ".join(row), flush=True)
 
 
-series(3000, "cold process")
+series(3000 if nsd == 2 else 1600, "cold process")
 series(400, "right after     ")
 for idle in (0.001, 0.01, 0.1, 1.0):
     time.sleep(idle)
