@@ -53,7 +53,8 @@ struct CfRow {
 #define DN_CF_NT_COEF 0           // 1: non-temporal vector loads for nu and f (profiles/r2_ab2d_nt.txt)
 #endif
 #ifndef DN_CF_PF
-#define DN_CF_PF 0                // 1: software-pipelined rows (row k + 2 in flight while layer k is computed); measured equal (profiles/r2_2d_ab.txt), off: 79 instead of 102 VGPRs
+#define DN_CF_PF 0                // 1 / 2: software-pipelined rows (one / two raw rows in flight while a layer is computed).  Steady state, box condition
+                                  // (profiles/r2_plan2d_steady.txt): default plan 46.9 us, PF=1 48.1, PF=2 50.6; strips of 32 rows 54.5 / 48.9 / 46.3.  Off: 79 VGPRs
 #endif
 
 #ifdef DN_STAMP2D
@@ -343,7 +344,39 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     fstage(RA);
     int ey = ey_begin;
     bool odd = false;
-#if DN_CF_PF
+#if DN_CF_PF == 2
+    {
+        // software pipeline, two raw rows ahead: W0 / W1 hold rows k + 1 and k + 2 while layer k - 1 runs.  Rows past the strip's last one
+        // are re-reads of that row (cache hits, no HBM traffic; a wave-uniform branch around the loads would drain the pipeline)
+        CfRow<E> W0, W1;
+        auto consume = [&](CfRow<E>& r, const CfRow<E>& W) {
+            r = W;
+            row_bc(r);
+            fstage(r);
+        };
+        row_issue(min(ey_begin + 1, ey_end), W0);
+        row_issue(min(ey_begin + 2, ey_end), W1);
+        for (; ey + 1 < ey_end; ey += 2) {
+            set_prio(ey);
+            consume(RB, W0);
+            row_issue(min(ey + 3, ey_end), W0);
+            flush_store();
+            layer(ey, RA, RB, carryA, carryB);
+            consume(RA, W1);
+            row_issue(min(ey + 4, ey_end), W1);
+            flush_store();
+            layer(ey + 1, RB, RA, carryB, carryA);
+        }
+        if (ey < ey_end) {
+            set_prio(ey);
+            consume(RB, W0);
+            flush_store();
+            layer(ey, RA, RB, carryA, carryB);
+            odd = true;
+        }
+        flush_store();
+    }
+#elif DN_CF_PF
     {
         // software pipeline: W holds the raw row k + 2 while layer k runs; consume = Dirichlet select + copy into the row state
         CfRow<E> W;
@@ -352,15 +385,15 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
             row_bc(r);
             fstage(r);
         };
-        row_issue(ey_begin + 1, W);
+        row_issue(min(ey_begin + 1, ey_end), W);
         for (; ey + 1 < ey_end; ey += 2) {
             set_prio(ey);
             consume(RB);
-            row_issue(ey + 2, W);
+            row_issue(min(ey + 2, ey_end), W);
             flush_store();
             layer(ey, RA, RB, carryA, carryB);
             consume(RA);
-            row_issue(ey + 3, W);
+            row_issue(min(ey + 3, ey_end), W);
             flush_store();
             layer(ey + 1, RB, RA, carryB, carryA);
         }

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 tag=$1; tu=$2; flags=$3
 mkdir -p variants/obj
 obj=variants/obj/${tag}_${tu%.hip}.o
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize --offload-arch=gfx950 -w $flags -c diffnet_amd/csrc/$tu -o $obj
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize -mllvm -amdgpu-sdwa-peephole=0 --offload-arch=gfx950 -w $flags -c diffnet_amd/csrc/$tu -o $obj
 objs=""
 for o in diffnet_amd/build/*.o; do
   if [ "$(basename $o)" == "${tu%.hip}.o" ]; then objs="$objs $obj"; else objs="$objs $o"; fi
