@@ -52,6 +52,9 @@ struct CfRow {
 #ifndef DN_CF_NT_COEF
 #define DN_CF_NT_COEF 0           // 1: non-temporal vector loads for nu and f (profiles/r2_ab2d_nt.txt)
 #endif
+#ifndef DN_CF_REV
+#define DN_CF_REV 1               // neighbouring strips march in opposite directions and share an XCD (see the kernel): the rows two strips share
+#endif                            // are fetched from HBM once.  0: every strip upwards, workgroups in dispatch order
 #ifndef DN_CF_PF
 #define DN_CF_PF 0                // 1 / 2: software-pipelined rows (one / two raw rows in flight while a layer is computed).  Steady state, box condition
                                   // (profiles/r2_plan2d_steady.txt): default plan 46.9 us, PF=1 48.1, PF=2 50.6; strips of 32 rows 54.5 / 48.9 / 46.3.  Off: 79 VGPRs
@@ -74,7 +77,18 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     constexpr bool BC_ANY = (FL & (CF_BC | CF_BC_U8C | CF_BC_PACKED)) != 0, BC_U8C = (FL & CF_BC_U8C) != 0, BC_PACKED = (FL & CF_BC_PACKED) != 0;
     const int T = blockDim.x;
     const int tid = threadIdx.x;
+#if DN_CF_REV
+    // Workgroup -> (chunk, strip, sample) so that NEIGHBOURING strips run on the same XCD (one L2) at the same time: the dispatcher
+    // hands consecutive workgroups (x fastest, then y, z) to consecutive XCDs; XCD k takes the k-th contiguous range of strips.
+    unsigned lid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    {
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
+        lid = xcd * base + min(xcd, rem) + idx;
+    }
+    const int chunk = (int)(lid % gridDim.x), strip = (int)((lid / gridDim.x) % gridDim.y), b = (int)(lid / (gridDim.x * gridDim.y));
+#else
     const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+#endif
     const int q = chunk * (T - 1) + tid;  // logical thread column (chunks overlap by one thread)
     const int ex0 = q * E;
     const int x0 = ex0;
@@ -82,9 +96,21 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     const int64_t nps = (int64_t)p.nx * p.ny;
     const SampleBases sb = sample_bases(p, b, nps);
     const int R = p.rows_per_strip;
-    const int ey_own = strip * R;
-    const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;
-    const int ey_end = min(ey_own + R, p.nely);
+    // The strip owns the node rows [sb0, sc0) (the last strip also the top row of the domain) and the element layers between them; it
+    // also computes the layer below its first row (the seam: that row's other half), so it reads the node rows sb0 - 1 .. sc0.
+    // DN_CF_REV: odd strips march DOWNWARDS, in the mirrored row coordinate y' = nely - y (the element is mirror-symmetric: the rule's
+    // moments of b and of 1 - b are the same numbers, so the same formulas apply with lower / upper rows exchanged).  An even strip and
+    // the odd one above it then read the two rows they share at the same time (both at their end), the odd strip and the even one above
+    // it both at their start: with the strips of a pair on one XCD the second read is an L2 hit instead of HBM traffic.
+    const int sb0 = strip * R, sc0 = min(sb0 + R, p.nely);
+    const bool rev = DN_CF_REV && (strip & 1);
+    const int ysgn = rev ? -1 : 1, yoff = rev ? p.nely : 0;                  // physical row of the logical row y: ysgn * y + yoff
+    // logical layers [ey_begin, ey_end); energy counted for layers e_from <= ey <= e_until, rows stored for ey >= r_from
+    const int ey_begin = rev ? p.nely - sc0 : (sb0 > 0 ? sb0 - 1 : 0);
+    const int ey_end = rev ? (sb0 > 0 ? p.nely - sb0 + 1 : p.nely) : sc0;
+    const int r_from = rev ? (sc0 == p.nely ? ey_begin : ey_begin + 1) : sb0;
+    const int e_from = rev ? 0 : sb0, e_until = rev ? p.nely - 1 - sb0 : p.nely;
+    const bool top_row = rev ? sb0 == 0 : sc0 == p.nely;                     // the strip also finishes the last logical row (no layer above it)
 
     __shared__ float xch[2][256];
     __shared__ double red[8];
@@ -145,7 +171,8 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         else load_seg<NW, VEC>(base, rowoff, x0, p.nx, dst);
     };
     auto row_issue = [&](int yr, CfRow<E>& r) {
-        const unsigned rowoff = (unsigned)min(yr, p.ny - 1) * (unsigned)p.nx;
+        const int yp = ysgn * min(yr, p.ny - 1) + yoff;
+        const unsigned rowoff = (unsigned)yp * (unsigned)p.nx;
         lseg(sb.u, rowoff, r.u);
 #if DN_CF_NT_COEF
         if constexpr (HAS_NU) load_seg_stream<NW, VEC>(sb.nu, rowoff, x0, p.nx, r.n);
@@ -155,7 +182,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         if constexpr (HAS_F) lseg(sb.f, rowoff, r.f);
 #endif
         if constexpr (BC_PACKED) {
-            packed_issue(min(yr, p.ny - 1), r);
+            packed_issue(yp, r);
         } else if constexpr (BC_U8C) {
             // both mask slots are loaded unconditionally (an absent one re-reads the other and is ignored): a load inside a
             // wave-uniform branch makes the compiler wait vmcnt(0) where the branch joins, which would drain the pipelined rows
@@ -233,7 +260,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
             sq_acc = st ? fmaf(t, t, sq_acc) : sq_acc;       // nodes beyond the domain receive no contribution: t == 0
             pend_v[n] = t * p.out_scale;
         }
-        pend_row = (unsigned)yr * (unsigned)p.nx;
+        pend_row = (unsigned)(ysgn * yr + yoff) * (unsigned)p.nx;
         pend_st = st && sb.out != nullptr;
         if (!DN_CF_PF) flush_store();
     };
@@ -267,7 +294,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     // one element layer between the lower row L (Dirichlet applied) and the freshly landed upper row U; cin holds the
     // contributions of the layer below to L's nodes, cout receives this layer's contributions to U's nodes
     auto layer = [&](int ey, const CfRow<E>& L, CfRow<E>& U, const float (&cin)[NW + 1], float (&cout)[NW + 1]) {
-        const bool own_layer = ey >= ey_own;
+        const bool own_layer = ey >= e_from && ey <= e_until;
         const float cnt = (own_layer && col_owner) ? 1.f : 0.f;
         if (!DN_CF_PF) { row_bc(U); fstage(U); }
         float o[NW + 1], le1 = 0.f, le2 = 0.f;
@@ -321,7 +348,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         }
         e1_acc = fmaf(cnt, le1, e1_acc);
         e2_acc = fmaf(cnt, le2, e2_acc);
-        emit_row(o, L.keep, ey, own_layer);
+        emit_row(o, L.keep, ey, ey >= r_from);
     };
 
     auto set_prio = [&](int e) {
@@ -421,7 +448,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         odd = true;
     }
 #endif
-    if (ey_end == p.nely) {       // the last strip owns the top boundary row of the domain: only the layer below contributes
+    if (top_row) {                // the last logical row of the domain: only the layer below it contributes
         float o[NW + 1], keep[NW];
 #pragma unroll
         for (int n = 0; n <= NW; ++n) o[n] = odd ? carryB[n] : carryA[n];
