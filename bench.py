@@ -34,6 +34,48 @@ ALG_BYTES_PER_NODE = 16        # read u, nu, f + write grad_u, f
 PIPE = 4                       # loss all-reduces in flight (N > 1)
 
 
+def timed_pairs(launch, n):
+    """Duration of n launches, each between its own pair of HIP events recorded on the current (launch) stream.  The events are
+    created with hipEventDisableSystemFence -- HIP's flag for events "only being used to measure timing", which skips the system-scope
+    cache write-back / invalidate a default event performs when it is recorded: with default events (torch.cuda.Event) that fence is
+    charged to the launch between them, 1.8 us here (tools/event_cost.py, profiles/r2_event_cost.txt: 49.4 us per launch between default
+    events, 47.6 between these, 47.1-48.1 per launch over 100 launches between ONE pair).  Returns (list of ms, kind of event used);
+    falls back to torch.cuda.Event when the HIP runtime torch loaded cannot be reached through ctypes."""
+    import ctypes
+    try:
+        path = next(ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64.so" in ln)       # the instance torch runs on
+        hip = ctypes.CDLL(path)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        evs = []
+        for _ in range(2 * n):
+            e = ctypes.c_void_p()
+            if hip.hipEventCreateWithFlags(ctypes.byref(e), ctypes.c_uint(0x20000000)) != 0:           # hipEventDisableSystemFence
+                raise OSError("hipEventCreateWithFlags")
+            evs.append(e)
+    except (StopIteration, OSError, AttributeError):
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in pairs:
+            a.record()
+            launch()
+            b.record()
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in pairs], "torch.cuda.Event (hipEventDefault)"
+    for i in range(n):
+        hip.hipEventRecord(evs[2 * i], stream)
+        launch()
+        hip.hipEventRecord(evs[2 * i + 1], stream)
+    torch.cuda.synchronize()
+    out = []
+    for i in range(n):
+        ms = ctypes.c_float()
+        if hip.hipEventElapsedTime(ctypes.byref(ms), evs[2 * i], evs[2 * i + 1]) != 0:
+            raise RuntimeError("hipEventElapsedTime failed")
+        out.append(ms.value)
+    for e in evs:
+        hip.hipEventDestroy(e)
+    return out, "hipEventDisableSystemFence"
+
+
 def make_inputs(shape, dev, seed):
     g = torch.Generator().manual_seed(seed)
     u = torch.rand(shape, generator=g)
@@ -307,27 +349,24 @@ def main():
 
     # dominant-kernel time: HIP events on the launch stream around each dn_poisson_apply (ONE kernel: the fused
     # Poisson kernel, whose last workgroup also does the fixed-order final reduction), K launches
-    # launches, each between its own pair of events (a pair costs the launch about 2 us: 2000 launches back to back complete one every
-    # 47.5 us, tools/overlap_check.py).  A short run (the driver's is 5 + 20 steps, 1.3 ms of load) would put these launches into the
+    # launches, each between its own pair of timing-only events (timed_pairs above).  A short run (the driver's is 5 + 20 steps, 1.3 ms of load) would put these launches into the
     # power-management transient 1.3-10 ms after load onset (tools/ramp2d.py: 55-58 us instead of 49.6), which says nothing about the
     # kernel; SETTLE untimed launches first carry the GPU past it.  The transient is reported as roofline.kernel_avg_ms_first_launches.
     from diffnet_amd import ops
     K, SETTLE = 100, 400
-    first = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-    for a, b in first:
-        a.record()
-        plans[0].launch()
-        b.record()
+    first_ms, _ = timed_pairs(plans[0].launch, 20)
     for _ in range(SETTLE):
         plans[0].launch()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     scale = 1.0 / (B * m.geom.nelem_total)
-    for a, b in evs:            # the same prepared launch as the timed steps (no allocation between the events)
+    kern_ms, event_kind = timed_pairs(plans[0].launch, K)      # the same prepared launch as the timed steps (no allocation between the events)
+    kern_ms.sort()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    for a, b in evs:            # the same between default events (what earlier rounds reported)
         a.record()
         plans[0].launch()
         b.record()
     torch.cuda.synchronize()
-    kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    default_ev_ms = sum(a.elapsed_time(b) for a, b in evs) / K
     bc_forms_us = {}
     if args.nsd == 2 and rank == 0:          # the same launch with the condition held in the other formats (median of 30, informational)
         for name, mk in forms.items():
@@ -335,13 +374,7 @@ def main():
                                                                    out_scale=scale0, want_out=True, want_sums=True, loss_scale=scale0)
             for _ in range(5):
                 pl.launch()
-            ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
-            for a, b in ev2:
-                a.record()
-                pl.launch()
-                b.record()
-            torch.cuda.synchronize()
-            bc_forms_us[name] = round(sorted(a.elapsed_time(b) for a, b in ev2)[15] * 1e3, 2)
+            bc_forms_us[name] = round(sorted(timed_pairs(pl.launch, 30)[0])[15] * 1e3, 2)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
     kern_med_ms = kern_ms[len(kern_ms) // 2]
     alg_bytes = ALG_BYTES_PER_NODE * B * m.geom.nnode_total
@@ -375,7 +408,9 @@ def main():
                          "kernel": "poisson fused kernel (one launch per dn_poisson_apply)", "kernel_avg_ms": kern_avg_ms,
                          "kernel_median_ms": kern_med_ms, "kernel_min_ms": kern_ms[0], "kernel_max_ms": kern_ms[-1],
                          "frac_at_median": alg_bytes / (kern_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
-                         "kernel_avg_ms_first_launches": sum(a.elapsed_time(b) for a, b in first) / len(first),
+                         "kernel_avg_ms_first_launches": sum(first_ms) / len(first_ms),
+                         "events": event_kind + " pair around each of %d launches, after %d untimed ones" % (K, SETTLE),
+                         "kernel_avg_ms_default_events": default_ev_ms,
                          "timed_region_ms_per_launch": region_ms,
                          "frac_over_timed_region": alg_bytes / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_median_us_by_mask_format": bc_forms_us},
