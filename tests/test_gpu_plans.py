@@ -82,3 +82,38 @@ def test_3d_q1_marching_adjoint_equals_the_tiled_adjoint(sizes, ngp, B):
             got[tiled] = g
             close(g, ref.numpy(), rtol=1e-5, arel=2e-6, msg=f"{name} tiled={tiled!r}")
         close(got[""], got["1"].cpu().numpy(), rtol=2e-6, arel=2e-6)
+
+
+@pytest.mark.parametrize("n,ngp,B", [(2, 2, 1), (3, 3, 2), (5, 2, 3), (18, 3, 2), (33, 2, 1), (64, 3, 2)])
+def test_2d_paired_strips_any_strip_height(n, ngp, B):
+    """The closed-form 2-D kernel runs neighbouring strips in opposite directions (odd strips in the mirrored row coordinate).  Which
+    rows and layers a strip owns must not depend on its direction: every strip height -- one layer per strip, heights that do not
+    divide the mesh, one strip for the whole mesh, odd and even strip counts -- gives the per-point kernel's loss and gradient."""
+    from diffnet_amd import BoxFaces, _lib, ops
+    m = module(dict(domain_size=n, ngp_1d=ngp))
+    shape = (B, 1, n, n)
+    u, nu, f = cu(seeded(shape, 21)), cu(seeded(shape, 22) + 0.5), cu(seeded(shape, 23))
+    bc = boundary_mask((1,) + shape[1:]).to(torch.uint8).to(dev())
+    src = (seeded(shape, 24) < 0.05).to(torch.uint8).to(dev())
+    conds = {"none": [], "box": [(BoxFaces("all"), 0.0)], "u8 x2": [(src, 1.0), (bc, 0.0)]}
+    ref = {}
+    _lib.config_set("Q1_RULE_KERNEL", "1")
+    try:
+        for name, d in conds.items():
+            ref[name] = m.energy_loss_and_grad(u, nu, f, dirichlet=d, c=0.7)
+    finally:
+        _lib.config_set("Q1_RULE_KERNEL", "")
+    try:
+        for R in (1, 2, 3, 5, 7, 16, 64):
+            for E in (2, 4) if n % 4 == 0 else (2,):
+                _lib.config_set("PLAN2D", f"64,{E},{R}")
+                ops._POISSON_WS_BYTES.clear()                      # the workspace size depends on the launch plan
+                for name, d in conds.items():
+                    loss, grad = m.energy_loss_and_grad(u, nu, f, dirichlet=d, c=0.7)
+                    l0, g0 = ref[name]
+                    np.testing.assert_allclose(float(loss), float(l0), rtol=3e-6, err_msg=f"R={R} E={E} {name}")
+                    scale = float(g0.abs().max()) + 1e-30
+                    assert float((grad - g0).abs().max()) <= 1e-5 * scale, f"R={R} E={E} {name}"
+    finally:
+        _lib.config_set("PLAN2D", "")
+        ops._POISSON_WS_BYTES.clear()
