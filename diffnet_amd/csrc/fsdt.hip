@@ -385,6 +385,10 @@ static FsdtGeom fsdt_plan(const dn_mesh* m) {
     const long long per_strip = (long long)g.chunks * m->batch * (g.T / 64);
     int R = 32;
     while (R > 4 && per_strip * fs_ceil_div(nely, R) < 4096) R /= 2;
+    // fewer than 2 waves per SIMD even at 4 rows (1025^2 Q2, one sample: 1152 waves): 2-row strips -- a SIMD with a single wave issues
+    // a VALU instruction every ~4.7 cycles, with two every ~2.4, which outweighs the second recomputed layer (32.7 -> 28.9 us;
+    // from 2 samples on 4 rows win: profiles/r2_fsdt_plans_steady.txt)
+    if (R == 4 && nely >= 2 && per_strip * fs_ceil_div(nely, 4) < 2048) R = 2;
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = fs_ceil_div(nely, g.R);
