@@ -53,8 +53,10 @@ struct CfRow {
 #define DN_CF_NT_COEF 0           // 1: non-temporal vector loads for nu and f (profiles/r2_ab2d_nt.txt)
 #endif
 #ifndef DN_CF_REV
-#define DN_CF_REV 1               // neighbouring strips march in opposite directions and share an XCD (see the kernel): the rows two strips share
-#endif                            // are fetched from HBM once.  0: every strip upwards, workgroups in dispatch order
+#define DN_CF_REV 0               // 1: neighbouring strips march in opposite directions and share an XCD (see the kernel): the rows two strips share
+#endif                            // are fetched once (measured traffic 1.09x -> 1.002x of the algorithmic bytes).  Faster when one batch is re-evaluated and
+                                  // its arrays partly live in the Infinity Cache (45.4 vs 47.5 us), SLOWER when every launch streams from HBM (different
+                                  // batches in rotation: 59.5 vs 56.4 us, profiles/r2_rotate_variants.txt) -- off.  0: every strip upwards, dispatch order
 #ifndef DN_CF_PF
 #define DN_CF_PF 0                // 1 / 2: software-pipelined rows (one / two raw rows in flight while a layer is computed).  Steady state, box condition
                                   // (profiles/r2_plan2d_steady.txt): default plan 46.9 us, PF=1 48.1, PF=2 50.6; strips of 32 rows 54.5 / 48.9 / 46.3.  Off: 79 VGPRs

@@ -12,5 +12,5 @@ python - <<PY
 import json
 for f in ("r2_final_bench","bench_driver_args"):
     d=json.loads(open("gpurun_out/%s.json"%f).readlines()[-1]); r=d["roofline"]
-    print(f, d["value"], d["ms_per_step"], r["frac"], r["kernel_avg_ms"], r["kernel_median_ms"], r["timed_region_ms_per_launch"], r["frac_over_timed_region"], r["kernel_median_us_by_mask_format"])
+    print(f, d["value"], d["ms_per_step"], r["frac"], r["kernel_avg_ms"], r["kernel_median_ms"], r["timed_region_ms_per_launch"], r["frac_over_timed_region_one_batch"], r["one_batch_kernel_median_us_by_mask_format"])
 PY
