@@ -13,8 +13,9 @@ fields already resident in HBM: 2-D Q1, 512 x 512 nodes, 3 x 3 Gauss points, B s
 scaling: each rank owns its own batch shard, like the reference's DDP; the only exchange is the all-reduce
 of the scalar loss).  metric = elements * gauss_pts / s summed over ranks.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (HIP-event time of the dominant kernel vs the HBM
-peak of MI355X_MICROARCH.md) and `cpu_baseline` (the CPU oracle = port of the reference formulation, timed
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (time of the dominant kernel between timing-only HIP events,
+taken over four DIFFERENT batches in rotation so that no launch finds its arrays in the Infinity Cache, vs the HBM peak of
+MI355X_MICROARCH.md; the timed steps themselves re-evaluate one batch, whose kernel time is reported beside it) and `cpu_baseline` (the CPU oracle = port of the reference formulation, timed
 on this box's host cores on a bounded sample of the same workload).
 """
 import argparse
