@@ -13,10 +13,16 @@ fields already resident in HBM: 2-D Q1, 512 x 512 nodes, 3 x 3 Gauss points, B s
 scaling: each rank owns its own batch shard, like the reference's DDP; the only exchange is the all-reduce
 of the scalar loss).  metric = elements * gauss_pts / s summed over ranks.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (time of the dominant kernel between timing-only HIP events,
-taken over four DIFFERENT batches in rotation so that no launch finds its arrays in the Infinity Cache, vs the HBM peak of
-MI355X_MICROARCH.md; the timed steps themselves re-evaluate one batch, whose kernel time is reported beside it) and `cpu_baseline` (the CPU oracle = port of the reference formulation, timed
-on this box's host cores on a bounded sample of the same workload).
+Every launch of the run -- warm-up, timed steps, roofline -- goes through NROT DIFFERENT batches in rotation (own input, mask and
+output arrays each): a training loop never re-reads the same u, and one batch's 268 MB of arrays is about the size of the 256 MB
+Infinity Cache, so re-evaluating ONE batch is cache-assisted (round 2: 47 vs 57 us).  `value`, `ms_per_step` and `roofline` are
+therefore one regime, streaming from HBM; the one-batch kernel time is a side field.  The Dirichlet mask is held as a general
+per-sample mask array (one bit per node, diffnet_amd.PackedMask); the geometry-derived form is a side field.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (time of the dominant kernel between timing-only HIP events over the
+rotation vs the HBM peak of MI355X_MICROARCH.md, plus `stream_ceiling`: a plain 3-read / 1-write streaming kernel over the same
+arrays), `cpu_baseline` (the CPU oracle = port of the reference formulation, timed on this box's host cores on a bounded sample
+of the same workload), `configs` (device time of every BASELINE.json config) and `slab_3d` (configs[3] over the same ranks).
 """
 import argparse
 import json
@@ -207,7 +213,7 @@ def slab_leg(args, rank, world, dev, dist, n, B, ngp, steps, warmup):
             "scaling": "strong", "dtype": "f32", "data": "synthetic",
             "hbm_frac_of_all_gpus": alg / (dt / steps) / 1e9 / (HBM_PEAK_GBS * world),
             "config": {"workload": f"3-D Poisson energy loss + gradient, Q1, ONE {n}^3 mesh x batch {B}, {ngp}^3 Gauss pts, z-slabs over "
-                                   f"{world} rank(s): 8-byte loss all-reduce + interface-layer exchange per step, overlapped with the slab "
+                                   f"{world} rank(s): 4-byte loss all-reduce + interface-layer exchange per step, overlapped with the slab "
                                    "kernel (BASELINE.json configs[3])",
                        "nodes": [n, n, n], "parallelism": f"slab x{world}"}}
 
@@ -219,6 +225,159 @@ def slab_main(args, rank, world, dev, dist):
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# device time of every BASELINE.json config (appended to the line as "configs")
+# ------------------------------------------------------------------------------------------------------------------------------
+_SLEEP_CYC_PER_US = [None]
+
+
+def device_us(fn, n=40, warm=3, settle_s=0.04):
+    """Device time per call of `fn` in steady state.  40 ms of load first (between 1.3 and 10 ms after the GPU leaves idle every kernel
+    runs 10-25 % slower, tools/ramp2d.py); then n calls enqueued behind a blocker kernel that outlasts the host's enqueue work, between
+    one pair of events -- or, for calls whose host side is slower than the device (several launches + torch ops per call), the n calls
+    captured into ONE HIP graph whose replay is timed.  Returns (device_us, host_us)."""
+    if _SLEEP_CYC_PER_US[0] is None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000); torch.cuda.synchronize()
+        a.record(); torch.cuda._sleep(10_000_000); b.record(); torch.cuda.synchronize()
+        _SLEEP_CYC_PER_US[0] = 10_000_000 / (a.elapsed_time(b) * 1e3)
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < settle_s:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    host_us = (time.perf_counter() - t0) / n * 1e6
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if host_us > 60.0:
+        try:
+            graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(graph):
+                for _ in range(n):
+                    fn()
+            graph.replay()
+            torch.cuda.synchronize()
+            a.record()
+            graph.replay()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / n * 1e3, host_us
+        except Exception:                      # not capturable: fall through to the blocker
+            torch.cuda.synchronize()
+    torch.cuda._sleep(int(_SLEEP_CYC_PER_US[0] * host_us * n * 3.0) + 1000)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3, host_us
+
+
+def config_rows(dev, budget_s=90.0):
+    """One row per BASELINE.json config (and the batch sizes SURVEY 8(d) names): us per evaluation of the loss + gradient in steady
+    state, fraction of the HBM peak on the config's algorithmic bytes, work units per second.  Inputs larger
+    than 64 MB rotate over several sets of arrays (no Infinity-Cache help).  Public API calls (the cached prepared launches of
+    diffnet_amd.fem / elasticity), not hand-prepared plans."""
+    from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM
+    t_start = time.perf_counter()
+    rows = []
+
+    def add(name, us, host, alg_bytes, units, note=None):
+        r = {"name": name, "us_per_eval": round(us, 2), "host_us_per_call": round(host, 1), "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4),
+             "units_per_s": units / us * 1e6}
+        if note:
+            r["note"] = note
+        rows.append(r)
+
+    def poisson(name, nsd, n, ngp, B, c, nsets=1):
+        if time.perf_counter() - t_start > budget_s:
+            return
+        cls = DiffNet3DFEM if nsd == 3 else DiffNet2DFEM
+        m = cls(None, domain_size=n, ngp_1d=ngp, nsd=nsd).to(dev)
+        shape = (B, 1, *m.geom.node_shape)
+        sets = [make_inputs(shape, dev, 7 + k) for k in range(nsets)]
+        outs = [torch.empty(shape, device=dev) for _ in range(nsets)]
+        turn = [0]
+
+        def fn():
+            k = turn[0]
+            turn[0] = (k + 1) % nsets
+            u, nu, f, bc = sets[k]
+            return m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=c, out=outs[k])
+
+        us, host = device_us(fn)
+        add(name, us, host, ALG_BYTES_PER_NODE * B * m.geom.nnode_total, B * m.geom.nelem_total * m.geom.ngp_total,
+            f"{nsets} sets of arrays in rotation" if nsets > 1 else None)
+
+    def fsdt(name, n, B):
+        if time.perf_counter() - t_start > budget_s:
+            return
+        from diffnet_amd.elasticity import fsdt_loss
+        m = DiffNet2DFEM(None, domain_size=n, fem_basis_deg=2, ngp_1d=3).to(dev)
+        shape = (B, 1, n, n)
+        g = torch.Generator().manual_seed(2)
+        fields = [torch.rand(shape, generator=g).to(dev).requires_grad_(True) for _ in range(3)]
+        bc = torch.zeros(shape, device=dev)
+        bc[..., 0] = 1; bc[..., -1] = 1; bc[..., 0, :] = 1; bc[..., -1, :] = 1
+
+        def fn():
+            loss = sum(fsdt_loss(m, *fields, bc))
+            torch.autograd.grad(loss, fields)
+
+        us, host = device_us(fn)
+        add(name, us, host, 68 * B * n * n, B * m.geom.nelem_total * m.geom.ngp_total, "residual norms + gradient: two launches + glue")
+
+    def unet(name, n, B):
+        if time.perf_counter() - t_start > budget_s:
+            return
+        from diffnet_amd.networks.unets import UNet
+        torch.manual_seed(0)
+        net = UNet(2, 1).to(dev)
+        fem = DiffNet2DFEM(net, domain_size=n, ngp_1d=3).to(dev)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        u0, nu, f, bc = make_inputs((B, 1, n, n), dev, 11)
+        x = torch.cat([nu, bc.float()], 1)
+
+        def fn():
+            opt.zero_grad(set_to_none=True)
+            loss = fem.energy_loss(net(x), nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+            loss.backward()
+            opt.step()
+
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = 10
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / k * 1e6
+        add(name, us, us, ALG_BYTES_PER_NODE * B * n * n, B * fem.geom.nelem_total * fem.geom.ngp_total,
+            "whole training step (UNet forward + FEM loss + backward + Adam), wall clock; frac counts the FEM bytes only")
+
+    poisson("cfg1 2-D 64^2 Q1 2x2 B=1 energy c=1/2", 2, 64, 2, 1, 0.5)
+    poisson("cfg2 2-D 512^2 Q1 3x3 B=1", 2, 512, 3, 1, 1.0)
+    poisson("cfg2 2-D 512^2 Q1 3x3 B=16", 2, 512, 3, 16, 1.0, nsets=4)
+    poisson("cfg2 2-D 512^2 Q1 3x3 B=64 (uint8 mask images, public API)", 2, 512, 3, 64, 1.0, nsets=4)
+    poisson("cfg3 3-D 128^3 Q1 2x2x2 B=1 energy c=1/2", 3, 128, 2, 1, 0.5)
+    poisson("cfg4 3-D 256^3 Q1 2x2x2 B=1 (whole mesh on one GPU)", 3, 256, 2, 1, 1.0, nsets=4)
+    fsdt("cfg5 FSDT plate 1025^2 nodes (512^2 Q2 elements) 3x3 B=1", 1025, 1)
+    fsdt("cfg5 FSDT plate 1025^2 Q2 3x3 B=8", 1025, 8)
+    unet("cfg2 UNet(2->1) + FEM loss training step, 512^2 B=16", 512, 16)
+    return rows
 
 
 def main():
@@ -234,11 +393,12 @@ def main():
     ap.add_argument("--ngp", type=int, default=3)
     ap.add_argument("--nsd", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config leg (\"configs\")")
     ap.add_argument("--bc", default="auto", choices=["auto", "bits", "u8", "f32", "box"],
-                    help="how the Dirichlet condition is held (auto: box faces for 2-D, uint8 image for 3-D)")
+                    help="how the Dirichlet condition is held (auto: one bit per node for 2-D, uint8 image for 3-D: general mask arrays)")
     ap.add_argument("--slab", action="store_true",
                     help="strong-scaling variant (not the default metric run): ONE 3-D mesh of --size^3 nodes cut into z-slabs over "
-                         "the ranks (diffnet_amd/slab.py): per step one 8-byte all-reduce + one node-layer exchange per interior face")
+                         "the ranks (diffnet_amd/slab.py): per step one 4-byte all-reduce + one node-layer exchange per interior face")
     ap.add_argument("--slab-size", type=int, default=256, help="mesh of the slab leg appended to the default run (0 = skip)")
     ap.add_argument("--slab-steps", type=int, default=100)
     ap.add_argument("--slab-warmup", type=int, default=300, help="untimed steps of the slab leg (past the load-onset transient: profiles/r2_ramp3d.txt)")
@@ -270,45 +430,48 @@ def main():
     if args.slab:
         return slab_main(args, rank, world, dev, dist)
 
-    from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM
+    from diffnet_amd import BoxFaces, DiffNet2DFEM, DiffNet3DFEM, PackedMask, _lib
+    from diffnet_amd import ops as _ops
     kw = dict(domain_size=args.size, ngp_1d=args.ngp, nsd=args.nsd)
     cls = DiffNet3DFEM if args.nsd == 3 else DiffNet2DFEM
     m = cls(None, **kw).to(dev)
     B = args.batch
     shape = (B, 1, *m.geom.node_shape)
-    u, nu, f, bc = make_inputs(shape, dev, 42 + rank)
     c = 1.0
     units_per_step = B * m.geom.nelem_total * m.geom.ngp_total
-    # The Dirichlet condition of BASELINE.md section 3 ("mask on all boundary faces") in the form the dataset keeps it in HBM:
-    #   bits  one bit per node (diffnet_amd.PackedMask: packed once when the dataset is placed on the device; any mask)
-    #   u8    one byte per node [default]   f32  the reference's fp32 image           box  derived from the geometry, no array
-    from diffnet_amd import BoxFaces, PackedMask
-    bc_form = args.bc if args.bc != "auto" else ("box" if args.nsd == 2 else "u8")
-    # auto: BASELINE.md section 3 prescribes the condition "on all boundary faces", which is the box boundary the reference builds as an image
-    # (IBN_2D.py:69-73); the kernel derives it from the geometry.  The same launch with the mask held as one bit per node (a general mask
-    # array: 0-2 us slower depending on the box), as a uint8 or as the reference's fp32 image is timed below and reported in
-    # roofline.one_batch_kernel_median_us_by_mask_format (the 3-D kernels read uint8 images).
-    forms = {"u8": lambda: [(bc, 0.0)], "f32": lambda: [(bc.float(), 0.0)], "bits": lambda: [(PackedMask.pack(bc), 0.0)],
-             "box": lambda: [(BoxFaces("all"), 0.0)]}
-    dirichlet = forms[bc_form]()
+    scale0 = 1.0 / (B * m.geom.nelem_total)
+    # NROT batches in rotation, each with its own u, nu, f, mask and output arrays.  With N > 1 also: PIPE + 1 of them, so that a loss
+    # whose all-reduce is still in flight is never overwritten by a later launch.
+    NROT = 4 if dist is None else PIPE + 1
+    sets = [make_inputs(shape, dev, 1000 * k + 42 + rank) for k in range(NROT)]
+    # The Dirichlet condition of BASELINE.md section 3 ("mask on all boundary faces") as the dataset keeps it in HBM:
+    #   bits  one bit per node, per sample (diffnet_amd.PackedMask: packed once when the dataset is placed on the device; ANY mask) [default]
+    #   u8    one byte per node     f32  the reference's fp32 image     box  no array: derived from the geometry (this workload only)
+    bc_form = args.bc if args.bc != "auto" else ("bits" if args.nsd == 2 else "u8")
+    forms = {"u8": lambda bc: [(bc, 0.0)], "f32": lambda bc: [(bc.float(), 0.0)], "bits": lambda bc: [(PackedMask.pack(bc), 0.0)],
+             "box": lambda bc: [(BoxFaces("all"), 0.0)]}
+
+    def make_plans(form):
+        # the prepared form of m.energy_loss_and_grad(u, nu, f, dirichlet, c) (diffnet_amd.ops.PoissonPlan: argument structs, outputs and
+        # workspace set up once, one ctypes call per launch)
+        return [_ops.PoissonPlan(m.geom, u, nu, f, None, forms[form](bc), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale0,
+                                 want_out=True, want_sums=True, loss_scale=scale0) for (u, nu, f, bc) in sets]
+
+    rot = make_plans(bc_form)
+    turn = [0]
     pending = []
 
-    # The step is the prepared form of m.energy_loss_and_grad(u, nu, f, dirichlet, c) (diffnet_amd.ops.PoissonPlan: argument structs,
-    # outputs and workspace set up once, one ctypes call per launch), PIPE + 1 of them in rotation so that a loss whose all-reduce is
-    # still in flight is never overwritten by a later launch.
-    from diffnet_amd import ops as _ops
-    scale0 = 1.0 / (B * m.geom.nelem_total)
-    plans = [_ops.PoissonPlan(m.geom, u, nu, f, None, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale0,
-                              want_out=True, want_sums=True, loss_scale=scale0) for _ in range(PIPE + 1 if dist is not None else 1)]
-    turn = [0]
+    def launch_rot():
+        k = turn[0]
+        turn[0] = (k + 1) % NROT
+        return rot[k].launch()
 
     def step():
-        grad, _, loss = plans[turn[0]].launch()
-        turn[0] = (turn[0] + 1) % len(plans)
+        grad, _, loss = launch_rot()
         if dist is not None:
             # the path's only exchange step: all-reduce of the 4-byte loss (RCCL).  Issued asynchronously so that the
             # next evaluation's kernel does not queue behind the collective; waited PIPE steps later (a small-message
-            # all-reduce over xGMI is latency-bound at tens of microseconds, comparable to one 75 us step) and drained
+            # all-reduce over xGMI is latency-bound at tens of microseconds, comparable to one step) and drained
             # before the timed region closes, i.e. every step's loss IS reduced inside the timed region.
             if backend == "nccl":                          # mean over ranks inside the collective: no extra launch per step
                 work = dist.all_reduce(loss, op=dist.ReduceOp.AVG, async_op=True)
@@ -348,44 +511,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
-    # dominant-kernel time: HIP events on the launch stream around each dn_poisson_apply (ONE kernel: the fused
-    # Poisson kernel, whose last workgroup also does the fixed-order final reduction), K launches
-    # launches, each between its own pair of timing-only events (timed_pairs above).  A short run (the driver's is 5 + 20 steps, 1.3 ms of load) would put these launches into the
-    # power-management transient 1.3-10 ms after load onset (tools/ramp2d.py: 55-58 us instead of 49.6), which says nothing about the
-    # kernel; SETTLE untimed launches first carry the GPU past it.  The transient is reported as roofline.kernel_avg_ms_first_launches.
-    from diffnet_amd import ops
-    K, SETTLE, NROT = 100, 400, 4
-    first_ms, _ = timed_pairs(plans[0].launch, 20)
-    for _ in range(SETTLE):
-        plans[0].launch()
-    scale = 1.0 / (B * m.geom.nelem_total)
-    same_ms, event_kind = timed_pairs(plans[0].launch, K)      # the same prepared launch as the timed steps (no allocation between the events)
-    same_ms.sort()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    for a, b in evs:            # the same between default events (what earlier rounds reported)
-        a.record()
-        plans[0].launch()
-        b.record()
-    torch.cuda.synchronize()
-    default_ev_ms = sum(a.elapsed_time(b) for a, b in evs) / K
-    # The timed steps re-evaluate ONE batch, as the contract defines a step -- and its 268 MB of arrays are about the size of the 256 MB
-    # Infinity Cache, so a launch finds part of its input there from the launch before (tools/rotate_batches.py: 46.3 us per launch on one
-    # batch, 58.4 us on 2, 4 or 8 batches in rotation).  The ROOFLINE is about HBM: its kernel time is taken over NROT different batches
-    # in rotation (own input and output arrays each), where no launch finds its data in a cache; the one-batch time is reported beside it.
-    rot = [plans[0]]
-    for k in range(1, NROT):
-        uk, nuk, fk, _ = make_inputs(shape, dev, 1000 * k + 42 + rank)
-        rot.append(_ops.PoissonPlan(m.geom, uk, nuk, fk, None, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale0,
-                                    want_out=True, want_sums=True, loss_scale=scale0))
-    rot_turn = [0]
-
-    def launch_rot():
-        rot[rot_turn[0]].launch()
-        rot_turn[0] = (rot_turn[0] + 1) % NROT
-
+    # dominant-kernel time: timing-only HIP events on the launch stream around each dn_poisson_apply (ONE kernel: the fused Poisson
+    # kernel, whose last workgroup also does the fixed-order final reduction), K launches over the rotation, each between its own pair
+    # (timed_pairs above).  A short run (the driver's is 5 + 20 steps, 1.3 ms of load) would put these launches into the power-management
+    # transient 1.3-10 ms after load onset (tools/ramp2d.py), which says nothing about the kernel; SETTLE untimed launches first carry
+    # the GPU past it.  The transient is reported as roofline.kernel_avg_ms_first_launches.
+    K, SETTLE = 100, 400
+    first_ms, _ = timed_pairs(launch_rot, 20)
     for _ in range(SETTLE):
         launch_rot()
-    kern_ms, _ = timed_pairs(launch_rot, K)
+    kern_ms, event_kind = timed_pairs(launch_rot, K)
     kern_ms.sort()
     rot_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     rot_region[0].record()
@@ -393,15 +528,55 @@ def main():
         launch_rot()
     rot_region[1].record()
     torch.cuda.synchronize()
-    rot_region_ms = rot_region[0].elapsed_time(rot_region[1]) / (2 * K)
+    steady_region_ms = rot_region[0].elapsed_time(rot_region[1]) / (2 * K)
+    # side fields: the same launch re-evaluating ONE batch (Infinity-Cache assisted: what rounds 1 and 2 reported as the step), and the
+    # rotation with the mask held in the other formats (median of 40)
+    for _ in range(50):
+        rot[0].launch()
+    same_ms = sorted(timed_pairs(rot[0].launch, K)[0])
     bc_forms_us = {}
-    if args.nsd == 2 and rank == 0:          # the same launch with the condition held in the other formats (median of 30, informational)
-        for name, mk in forms.items():
-            pl = plans[0] if name == bc_form else _ops.PoissonPlan(m.geom, u, nu, f, None, mk(), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0,
-                                                                   out_scale=scale0, want_out=True, want_sums=True, loss_scale=scale0)
-            for _ in range(5):
-                pl.launch()
-            bc_forms_us[name] = round(sorted(timed_pairs(pl.launch, 30)[0])[15] * 1e3, 2)
+    if args.nsd == 2 and rank == 0:
+        for name in forms:
+            pls = rot if name == bc_form else make_plans(name)
+            t = [0]
+
+            def go():
+                pls[t[0]].launch()
+                t[0] = (t[0] + 1) % NROT
+
+            for _ in range(20):
+                go()
+            bc_forms_us[name] = round(sorted(timed_pairs(go, 40)[0])[20] * 1e3, 2)
+            del pls
+    # stream ceiling: a plain streaming kernel (dn_probe_stream: out = a * b + c, 16-byte vectors) over the SAME arrays and rotation --
+    # three arrays read once, one written once; best of its forms / cache policies
+    stream = None
+    if rank == 0:
+        import ctypes
+        fn = _lib.lib().dn_probe_stream
+        nfl = sets[0][0].numel()
+        best = None
+        for mode in (0, 1, 4, 5, 8, 9, 7):
+            t = [0]
+
+            def go():
+                u, nu, f, _ = sets[t[0]]
+                rc = fn(u.data_ptr(), nu.data_ptr(), f.data_ptr(), rot[t[0]].result[0].data_ptr(), nfl, mode,
+                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                if rc:
+                    raise RuntimeError(f"dn_probe_stream rc={rc}")
+                t[0] = (t[0] + 1) % NROT
+
+            for _ in range(40):
+                go()
+            ms = sorted(timed_pairs(go, 60)[0])
+            avg = sum(ms) / len(ms)
+            if best is None or avg < best[0]:
+                best = (avg, mode, ms[len(ms) // 2])
+        for _ in range(8):
+            launch_rot()          # the probe wrote into the gradient arrays: leave them as the operator writes them
+        torch.cuda.synchronize()
+        stream = best
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
     kern_med_ms = kern_ms[len(kern_ms) // 2]
     alg_bytes = ALG_BYTES_PER_NODE * B * m.geom.nnode_total
@@ -419,52 +594,78 @@ def main():
     out = None
     if rank == 0:
         value = units_per_step * world * args.steps / dt
+        mask_note = {'bits': 'held as one bit per node and sample (a general mask array)', 'u8': 'held as a uint8 image', 'f32': 'held as an fp32 image',
+                     'box': 'derived from the geometry (no array)'}[bc_form]
         out = {
             "metric": "elements*gauss_pts/sec (FEM loss+grad)", "value": value, "unit": "elements*gauss_pts/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.nsd}-D Poisson energy loss + gradient wrt u, Q1, {args.size}^{args.nsd} nodes, "
                                    f"{args.ngp}^{args.nsd} Gauss pts, batch {B}/GPU, nu+f nodal fields, Dirichlet mask on all boundary faces "
-                                   + {'bits': 'held as one bit per node', 'u8': 'held as a uint8 image', 'f32': 'held as an fp32 image', 'box': 'derived from the geometry (no array)'}[bc_form] + ", "
-                                   "fused single pass (BASELINE.json configs[1] mesh)"
+                                   + mask_note + f", fused single pass (BASELINE.json configs[1] mesh); every step evaluates the next of {NROT} "
+                                   "different batches in rotation (inputs stream from HBM, no Infinity-Cache re-use between steps)"
                                    + ("; 2-D Q1 element evaluated in closed form: the rule's sums as polynomials of its moments, same value "
                                       "as the per-point sum (dn_config_set(\"Q1_RULE_KERNEL\") runs the per-point kernel)" if args.nsd == 2 else ""),
-                       "batch_per_gpu": B, "nodes": list(m.geom.node_shape), "parallelism": f"batch-sharded x{world}"},
+                       "batch_per_gpu": B, "nodes": list(m.geom.node_shape), "parallelism": f"batch-sharded x{world}",
+                       "batches_in_rotation": NROT, "mask_format": bc_form},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "poisson fused kernel (one launch per dn_poisson_apply)", "kernel_avg_ms": kern_avg_ms,
                          "kernel_median_ms": kern_med_ms, "kernel_min_ms": kern_ms[0], "kernel_max_ms": kern_ms[-1],
                          "frac_at_median": alg_bytes / (kern_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
-                         "batches": "%d different batches in rotation (no launch finds its arrays in the Infinity Cache)" % NROT,
-                         "rotating_batches_ms_per_launch_back_to_back": rot_region_ms,
-                         "value_rotating_batches": units_per_step / (rot_region_ms * 1e-3),
+                         "batches": "%d different batches in rotation, as in the timed steps" % NROT,
+                         "steady_ms_per_launch_back_to_back": steady_region_ms,
+                         "value_steady": units_per_step / (steady_region_ms * 1e-3),
+                         "stream_ceiling": None if stream is None else {
+                             "what": "dn_probe_stream: plain 3-read / 1-write fp32 streaming kernel over the same arrays and rotation",
+                             "avg_ms": stream[0], "median_ms": stream[2], "mode": stream[1], "GBps": alg_bytes / (stream[0] * 1e-3) / 1e9,
+                             "frac_of_peak": alg_bytes / (stream[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_over_stream": kern_avg_ms / stream[0]},
                          "one_batch_kernel_avg_ms": sum(same_ms) / len(same_ms), "one_batch_kernel_median_ms": same_ms[len(same_ms) // 2],
                          "frac_one_batch": alg_bytes / (sum(same_ms) / len(same_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "cache_note": "the timed steps re-evaluate one batch (268 MB of arrays, the size of the 256 MB Infinity Cache): "
-                                       "part of a launch's input is found there from the launch before; achieved / frac are taken on "
-                                       "different batches in rotation instead, the one-batch kernel time is one_batch_kernel_avg_ms",
+                         "cache_note": "one_batch_*: the same launch re-evaluating ONE batch finds part of its 268 MB of arrays in the 256 MB "
+                                       "Infinity Cache; not a regime a training loop is in, reported for comparison with rounds 1-2 only",
                          "kernel_avg_ms_first_launches": sum(first_ms) / len(first_ms),
                          "events": event_kind + " pair around each of %d launches, after %d untimed ones" % (K, SETTLE),
-                         "kernel_avg_ms_default_events": default_ev_ms,
                          "timed_region_ms_per_launch": region_ms,
-                         "frac_over_timed_region_one_batch": alg_bytes / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "one_batch_kernel_median_us_by_mask_format": bc_forms_us},
+                         "frac_over_timed_region": alg_bytes / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "rotation_kernel_median_us_by_mask_format": bc_forms_us},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, c)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if not args.no_configs and world == 1 and args.nsd == 2 and args.size == 512:
+            del rot, sets
+            torch.cuda.empty_cache()
+            try:
+                out["configs"] = config_rows(dev)
+            except Exception as e:                      # noqa: BLE001 -- the headline above is complete; say what failed
+                out["configs"] = {"error": f"{type(e).__name__}: {e}"[:400]}
 
     # strong-scaling leg of BASELINE configs[3] in the same run (all ranks take part): one 256^3 mesh cut into z-slabs.  The headline
     # measurement above is complete at this point; the leg runs under a watchdog so that a failure or a hang in its point-to-point
-    # exchange (first exercised over RCCL on the driver's multi-GPU node) still leaves the ONE JSON line, with the reason in "slab_3d".
+    # exchange (first exercised over RCCL on the driver's multi-GPU node) still leaves the ONE JSON line, with the reason in
+    # "slab_3d.error" -- which is what a reader must check: the process then ends with status 0 because the headline is complete
+    # (status 1 only if the line could not be printed).  `emitted` makes sure exactly one line is printed, whoever gets there first.
     if args.slab_size and args.nsd == 2 and args.size == 512:
         import threading
+        emit_lock, emitted = threading.Lock(), [False]
+
+        def emit():
+            with emit_lock:
+                if emitted[0]:
+                    return True
+                emitted[0] = True
+                try:
+                    if rank == 0:
+                        print(json.dumps(out), flush=True)
+                    return True
+                except Exception:
+                    return False
 
         def give_up():
             if rank == 0:
                 out["slab_3d"] = {"error": f"slab leg did not finish within {args.slab_timeout} s (n_gpus={world})"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(0 if emit() else 1)
 
         dog = threading.Timer(args.slab_timeout, give_up)
         dog.daemon = True
@@ -474,12 +675,13 @@ def main():
             if rank == 0:
                 out["slab_3d"] = slab
         except Exception as e:                       # noqa: BLE001 -- reported, not hidden: the line says what failed
+            dog.cancel()
             if rank == 0:
                 out["slab_3d"] = {"error": f"{type(e).__name__}: {e}"[:500]}
-                print(json.dumps(out), flush=True)
-            os._exit(0)                              # peers may be stuck in a collective: no orderly teardown (their watchdogs end them)
+            os._exit(0 if emit() else 1)             # peers may be stuck in a collective: no orderly teardown (their watchdogs end them)
         dog.cancel()
-    if rank == 0:
+        emit()
+    elif rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DN_LIB_PATH") or os.path.join(HERE, "libdiffnet_hip.so")     # DN_LIB_PATH: a variant build (tools/variant_build.sh)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE"}
 
@@ -60,6 +60,7 @@ SYMBOLS = {
     "dn_build_info": (C.c_char_p, []),
     "dn_config_set": (C.c_int, [C.c_char_p, C.c_char_p]),
     "dn_config_get": (C.c_char_p, [C.c_char_p]),
+    "dn_probe_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "dn_poisson_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
     "dn_poisson_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnPoissonArgs), C.c_void_p]),
     "dn_gauss_pt_eval_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,
@@ -160,6 +161,10 @@ def config_set(key, value):
     rc = lib().dn_config_set(key.encode(), (value or "").encode())
     if rc != 0:
         raise DiffNetHipError(f"dn_config_set: unknown switch {key!r} or value too long")
+    import sys
+    ops = sys.modules.get(__package__ + ".ops")
+    if ops is not None:
+        ops.call_cache_clear()      # launch plans (and with them workspace sizes) may have changed
 
 
 def config_get(key):

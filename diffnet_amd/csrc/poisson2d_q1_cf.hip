@@ -15,6 +15,7 @@
 // carries the lower node row (raw nodal values) and the layer-below contributions to that row's nodes; two rows per loop
 // trip with the two raw rows / carry sets swapping roles (no copies); node shared with the right neighbour through LDS.
 #include <cstdlib>
+#include <type_traits>
 
 #define DN_NT_STORES 1            // the gradient rows are written once and never re-read by the launch: 54.3 -> 52.8 us (profiles/r2_ab2d_nt.txt)
 #include "poisson_common.h"
@@ -62,6 +63,14 @@ struct CfRow {
                                   // (profiles/r2_plan2d_steady.txt): default plan 46.9 us, PF=1 48.1, PF=2 50.6; strips of 32 rows 54.5 / 48.9 / 46.3.  Off: 79 VGPRs
 #endif
 
+#ifndef DN_CF_W
+#define DN_CF_W 4                 // sub-strips CHAINED per workgroup in launches that fill the chip (plan2d, poisson_fused.hip): W x 2 waves march W
+#endif                            // neighbouring strips; a strip takes the row it shares with the strip below / above through LDS instead of re-reading
+                                  // it from HBM and recomputing the seam layer: a workgroup of W strips of R rows reads W R + 2 rows instead of W (R + 2)
+constexpr int CF_TS = 128;        // threads per chained sub-strip (two waves: 128 x 4 elements = one 512-node row segment)
+constexpr int CF_NSLOT = 64;      // hand-over slots between the two waves of a sub-strip: one per emitted row, never reused (R + 3 <= 64)
+constexpr unsigned CF_SPIN_MAX = 1u << 20;   // bound of every LDS flag poll (a protocol error ends in wrong numbers, which the parity tests catch, not in a hung GPU)
+
 #ifdef DN_STAMP2D
 // Diagnostic build only (tools/clock2d.py): shader-clock ticks (s_memtime) and constant-100-MHz ticks (s_memrealtime) of every workgroup's
 // lifetime -> the clock the kernel really ran at (the MI355X lowers it under load: profiles/r2_clock_under_load.txt)
@@ -69,16 +78,19 @@ __device__ unsigned long long dn_stamp2d_buf[8192 * 2];
 extern "C" int dn_debug_stamps2d(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dn_stamp2d_buf), bytes); }
 #endif
 
-template <int E, bool VEC, int FL>
-__global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(const PoissonParams p) {
+template <int E, bool VEC, int FL, int W>
+__global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(const PoissonParams p) {
 #ifdef DN_STAMP2D
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int NW = E;
     constexpr bool HAS_NU = (FL & CF_NU) != 0, HAS_F = (FL & CF_F) != 0;
     constexpr bool BC_ANY = (FL & (CF_BC | CF_BC_U8C | CF_BC_PACKED)) != 0, BC_U8C = (FL & CF_BC_U8C) != 0, BC_PACKED = (FL & CF_BC_PACKED) != 0;
-    const int T = blockDim.x;
-    const int tid = threadIdx.x;
+    static_assert(W == 1 || (!DN_CF_REV && !DN_CF_PF), "chained sub-strips: plain upward march only");
+    // W > 1: the workgroup holds W sub-strips of CF_TS threads each; sub (wave-uniform) is this thread's sub-strip
+    const int T = W > 1 ? CF_TS : (int)blockDim.x;
+    const int sub = W > 1 ? (int)threadIdx.x / CF_TS : 0;
+    const int tid = W > 1 ? (int)threadIdx.x - sub * CF_TS : (int)threadIdx.x;
 #if DN_CF_REV
     // Workgroup -> (chunk, strip, sample) so that NEIGHBOURING strips run on the same XCD (one L2) at the same time: the dispatcher
     // hands consecutive workgroups (x fastest, then y, z) to consecutive XCDs; XCD k takes the k-th contiguous range of strips.
@@ -89,8 +101,11 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     }
     const int chunk = (int)(lid % gridDim.x), strip = (int)((lid / gridDim.x) % gridDim.y), b = (int)(lid / (gridDim.x * gridDim.y));
 #else
-    const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+    const int chunk = blockIdx.x, strip = (int)blockIdx.y * W + sub, b = blockIdx.z;
 #endif
+    const bool active = W == 1 || strip < p.nstrips;                         // the last workgroup of a sample may hold fewer than W strips
+    const bool chain_dn = W > 1 && sub > 0;                                  // the strip below is in this workgroup
+    const bool chain_up = W > 1 && sub + 1 < W && strip + 1 < p.nstrips;     // the strip above is
     const int q = chunk * (T - 1) + tid;  // logical thread column (chunks overlap by one thread)
     const int ex0 = q * E;
     const int x0 = ex0;
@@ -108,15 +123,40 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     const bool rev = DN_CF_REV && (strip & 1);
     const int ysgn = rev ? -1 : 1, yoff = rev ? p.nely : 0;                  // physical row of the logical row y: ysgn * y + yoff
     // logical layers [ey_begin, ey_end); energy counted for layers e_from <= ey <= e_until, rows stored for ey >= r_from
-    const int ey_begin = rev ? p.nely - sc0 : (sb0 > 0 ? sb0 - 1 : 0);
+    const int ey_begin = rev ? p.nely - sc0 : ((sb0 > 0 && !chain_dn) ? sb0 - 1 : sb0);     // chain_dn: no seam layer, the carry comes from the strip below
     const int ey_end = rev ? (sb0 > 0 ? p.nely - sb0 + 1 : p.nely) : sc0;
     const int r_from = rev ? (sc0 == p.nely ? ey_begin : ey_begin + 1) : sb0;
     const int e_from = rev ? 0 : sb0, e_until = rev ? p.nely - 1 - sb0 : p.nely;
     const bool top_row = rev ? sb0 == 0 : sc0 == p.nely;                     // the strip also finishes the last logical row (no layer above it)
 
     __shared__ float xch[2][256];
-    __shared__ double red[8];
+    __shared__ double red[W > 1 ? 4 * W : 8];
     __shared__ int last_flag;
+    // W > 1 -- hand-overs inside the workgroup, all through LDS words guarded by flags (no workgroup barrier: the sub-strips, and the two
+    // waves of a sub-strip, run at their own pace; a producer never waits for a consumer, so there is no cycle of waits):
+    //   cf_edge / cf_xflag   per emitted row, wave 0 of a sub-strip -> wave 1: the contribution to the node the two waves share
+    //   cf_seam / cf_sflag   once per strip: the strip above publishes its first node row (Dirichlet applied, forcing x-staged) for the
+    //                        last layer of the strip below [0 .. 3 NW + 2]; the strip below answers with that layer's contributions
+    //                        to this row [3 NW + 3 .. 4 NW + 3]; the strip above parks its own half of the row meanwhile [4 NW + 4 ..]
+    constexpr int CW = W > 1 ? W : 2, SEAM_WORDS = 6 * (E + 1);
+    __shared__ float cf_edge[W > 1 ? W : 1][W > 1 ? CF_NSLOT : 1];
+    __shared__ unsigned cf_xflag[W > 1 ? W : 1];
+    __shared__ float cf_seam[CW - 1][W > 1 ? SEAM_WORDS : 1][W > 1 ? CF_TS : 1];
+    __shared__ unsigned cf_sflag[CW - 1][2][2];          // [seam][0: row published, 1: carry published][wave of the sub-strip]
+    const int lane = tid & 63, wv = tid >> 6;
+    unsigned seq = 0u;                                   // rows handed over so far (same count in both waves of a sub-strip)
+    if constexpr (W > 1) {
+        static_assert(CF_TS == 128, "two waves per sub-strip");
+        if (threadIdx.x < (unsigned)W) cf_xflag[threadIdx.x] = 0u;
+        if (threadIdx.x < 4u * (W - 1)) (&cf_sflag[0][0][0])[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    auto spin_until = [&](volatile unsigned* flag, unsigned want) {       // wave-uniform poll of an LDS word
+        for (unsigned n = 0; n < CF_SPIN_MAX; ++n) {
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)*flag) >= want) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
 
     const bool has_mask[2] = {sb.mask[0] != nullptr, sb.mask[1] != nullptr};
     const uint8_t* mask8[2];
@@ -251,10 +291,27 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         pend_st = false;
     };
     auto emit_row = [&](const float (&o)[NW + 1], const float (&keep)[NW], int yr, bool owned_row) {
-        xch[par][tid] = o[NW];
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS-only barrier (loads stay in flight)
-        const float left = (tid > 0) ? xch[par][tid - 1] : 0.f;
-        par ^= 1;
+        float left;
+        if constexpr (W > 1) {
+            // inside a wave: lane l takes o[NW] of lane l - 1 (ds_bpermute); across the two waves: one LDS word per row + a row counter
+            const float up = __shfl_up(o[NW], 1, 64);
+            volatile float* ve = &cf_edge[sub][seq & (CF_NSLOT - 1)];
+            volatile unsigned* vf = &cf_xflag[sub];
+            float edge = 0.f;
+            if (wv == 0) {
+                if (lane == 63) { *ve = o[NW]; *vf = seq + 1u; }          // LDS executes a wave's accesses in order: value before counter
+            } else {
+                spin_until(vf, seq + 1u);
+                edge = *ve;
+            }
+            left = lane > 0 ? up : edge;
+            ++seq;
+        } else {
+            xch[par][tid] = o[NW];
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS-only barrier (loads stay in flight)
+            left = (tid > 0) ? xch[par][tid - 1] : 0.f;
+            par ^= 1;
+        }
         const bool st = owned_row && col_owner;
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
@@ -295,10 +352,11 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
 
     // one element layer between the lower row L (Dirichlet applied) and the freshly landed upper row U; cin holds the
     // contributions of the layer below to L's nodes, cout receives this layer's contributions to U's nodes
-    auto layer = [&](int ey, const CfRow<E>& L, CfRow<E>& U, const float (&cin)[NW + 1], float (&cout)[NW + 1]) {
+    // fresh: U has just landed from HBM (Dirichlet select and forcing x-stage still to do); not fresh: U came finished from the strip above
+    auto layer = [&](auto fresh, int ey, const CfRow<E>& L, CfRow<E>& U, const float (&cin)[NW + 1], float (&cout)[NW + 1]) {
         const bool own_layer = ey >= e_from && ey <= e_until;
         const float cnt = (own_layer && col_owner) ? 1.f : 0.f;
-        if (!DN_CF_PF) { row_bc(U); fstage(U); }
+        if (!DN_CF_PF && decltype(fresh)::value) { row_bc(U); fstage(U); }
         float o[NW + 1], le1 = 0.f, le2 = 0.f;
 #pragma unroll
         for (int n = 0; n <= NW; ++n) { o[n] = cin[n]; cout[n] = 0.f; }
@@ -350,7 +408,47 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         }
         e1_acc = fmaf(cnt, le1, e1_acc);
         e2_acc = fmaf(cnt, le2, e2_acc);
-        emit_row(o, L.keep, ey, ey >= r_from);
+        if (W > 1 && chain_dn && ey == sb0) {
+            // the strip's first row still lacks the contributions of the layer below it, which the strip below computes at its very end:
+            // park this half in LDS (each thread re-reads its own words) and finish the row after the march
+            volatile float* s0 = &cf_seam[W > 1 ? sub - 1 : 0][0][tid];
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) s0[(4 * NW + 4 + n) * CF_TS] = o[n];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) s0[(5 * NW + 5 + n) * CF_TS] = L.keep[n];
+        } else {
+            emit_row(o, L.keep, ey, ey >= r_from);
+        }
+    };
+    // chained strips: row / carry hand-over with the neighbouring strip of the workgroup.  Thread t of one strip talks to thread t of the
+    // other, which sits in the wave of the same number: one flag per wave and direction
+    auto publish_row = [&](const CfRow<E>& r) {
+        volatile float* s0 = &cf_seam[W > 1 ? sub - 1 : 0][0][tid];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) {
+            s0[n * CF_TS] = r.u[n];
+            if constexpr (HAS_NU) s0[(NW + 1 + n) * CF_TS] = r.n[n];
+            if constexpr (FMASS) s0[(2 * NW + 2 + n) * CF_TS] = r.g[n];
+            else if constexpr (HAS_F) s0[(2 * NW + 2 + n) * CF_TS] = r.f[n];
+        }
+        if (lane == 0) *(volatile unsigned*)&cf_sflag[W > 1 ? sub - 1 : 0][0][wv] = 1u;
+    };
+    auto fetch_row = [&](CfRow<E>& r) {
+        spin_until(&cf_sflag[sub][0][wv], 1u);
+        volatile float* s0 = &cf_seam[sub][0][tid];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) {
+            r.u[n] = s0[n * CF_TS];
+            if constexpr (HAS_NU) r.n[n] = s0[(NW + 1 + n) * CF_TS];
+            if constexpr (FMASS) r.g[n] = s0[(2 * NW + 2 + n) * CF_TS];
+            else if constexpr (HAS_F) r.f[n] = s0[(2 * NW + 2 + n) * CF_TS];
+        }
+    };
+    auto publish_carry = [&](const float (&c)[NW + 1]) {
+        volatile float* s0 = &cf_seam[sub][0][tid];
+#pragma unroll
+        for (int n = 0; n <= NW; ++n) s0[(3 * NW + 3 + n) * CF_TS] = c[n];
+        if (lane == 0) *(volatile unsigned*)&cf_sflag[sub][1][wv] = 1u;
     };
 
     auto set_prio = [&](int e) {
@@ -364,6 +462,9 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
 #endif
     };
 
+    constexpr std::true_type FRESH{};
+    constexpr std::false_type LANDED{};
+    if (active) {                     // (a workgroup's unused sub-strips only join the final reduction)
     CfRow<E> RA, RB;
     float carryA[NW + 1], carryB[NW + 1];
 #pragma unroll
@@ -371,83 +472,95 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
     row_issue(ey_begin, RA);
     row_bc(RA);
     fstage(RA);
+    if constexpr (W > 1) {
+        if (chain_dn) publish_row(RA);
+    }
     int ey = ey_begin;
     bool odd = false;
 #if DN_CF_PF == 2
     {
-        // software pipeline, two raw rows ahead: W0 / W1 hold rows k + 1 and k + 2 while layer k - 1 runs.  Rows past the strip's last one
+        // software pipeline, two raw rows ahead: WR0 / WR1 hold rows k + 1 and k + 2 while layer k - 1 runs.  Rows past the strip's last one
         // are re-reads of that row (cache hits, no HBM traffic; a wave-uniform branch around the loads would drain the pipeline)
-        CfRow<E> W0, W1;
-        auto consume = [&](CfRow<E>& r, const CfRow<E>& W) {
-            r = W;
+        CfRow<E> WR0, WR1;
+        auto consume = [&](CfRow<E>& r, const CfRow<E>& WR) {
+            r = WR;
             row_bc(r);
             fstage(r);
         };
-        row_issue(min(ey_begin + 1, ey_end), W0);
-        row_issue(min(ey_begin + 2, ey_end), W1);
+        row_issue(min(ey_begin + 1, ey_end), WR0);
+        row_issue(min(ey_begin + 2, ey_end), WR1);
         for (; ey + 1 < ey_end; ey += 2) {
             set_prio(ey);
-            consume(RB, W0);
-            row_issue(min(ey + 3, ey_end), W0);
+            consume(RB, WR0);
+            row_issue(min(ey + 3, ey_end), WR0);
             flush_store();
-            layer(ey, RA, RB, carryA, carryB);
-            consume(RA, W1);
-            row_issue(min(ey + 4, ey_end), W1);
+            layer(FRESH, ey, RA, RB, carryA, carryB);
+            consume(RA, WR1);
+            row_issue(min(ey + 4, ey_end), WR1);
             flush_store();
-            layer(ey + 1, RB, RA, carryB, carryA);
+            layer(FRESH, ey + 1, RB, RA, carryB, carryA);
         }
         if (ey < ey_end) {
             set_prio(ey);
-            consume(RB, W0);
+            consume(RB, WR0);
             flush_store();
-            layer(ey, RA, RB, carryA, carryB);
+            layer(FRESH, ey, RA, RB, carryA, carryB);
             odd = true;
         }
         flush_store();
     }
 #elif DN_CF_PF
     {
-        // software pipeline: W holds the raw row k + 2 while layer k runs; consume = Dirichlet select + copy into the row state
-        CfRow<E> W;
+        // software pipeline: WR holds the raw row k + 2 while layer k runs; consume = Dirichlet select + copy into the row state
+        CfRow<E> WR;
         auto consume = [&](CfRow<E>& r) {
-            r = W;
+            r = WR;
             row_bc(r);
             fstage(r);
         };
-        row_issue(min(ey_begin + 1, ey_end), W);
+        row_issue(min(ey_begin + 1, ey_end), WR);
         for (; ey + 1 < ey_end; ey += 2) {
             set_prio(ey);
             consume(RB);
-            row_issue(min(ey + 2, ey_end), W);
+            row_issue(min(ey + 2, ey_end), WR);
             flush_store();
-            layer(ey, RA, RB, carryA, carryB);
+            layer(FRESH, ey, RA, RB, carryA, carryB);
             consume(RA);
-            row_issue(min(ey + 3, ey_end), W);
+            row_issue(min(ey + 3, ey_end), WR);
             flush_store();
-            layer(ey + 1, RB, RA, carryB, carryA);
+            layer(FRESH, ey + 1, RB, RA, carryB, carryA);
         }
         if (ey < ey_end) {
             set_prio(ey);
             consume(RB);
             flush_store();
-            layer(ey, RA, RB, carryA, carryB);
+            layer(FRESH, ey, RA, RB, carryA, carryB);
             odd = true;
         }
         flush_store();
     }
 #else
-    for (; ey + 1 < ey_end; ey += 2) {
+    const int n_main = chain_up ? ey_end - 1 : ey_end;         // chain_up: the strip's last layer takes its upper row from the strip above (LDS)
+    for (; ey + 1 < n_main; ey += 2) {
         set_prio(ey);
         row_issue(ey + 1, RB);
-        layer(ey, RA, RB, carryA, carryB);
+        layer(FRESH, ey, RA, RB, carryA, carryB);
         row_issue(ey + 2, RA);
-        layer(ey + 1, RB, RA, carryB, carryA);
+        layer(FRESH, ey + 1, RB, RA, carryB, carryA);
     }
-    if (ey < ey_end) {
+    if (ey < n_main) {
         set_prio(ey);
         row_issue(ey + 1, RB);
-        layer(ey, RA, RB, carryA, carryB);
+        layer(FRESH, ey, RA, RB, carryA, carryB);
         odd = true;
+        ++ey;
+    }
+    if constexpr (W > 1) {
+        if (chain_up) {               // ey == ey_end - 1
+            __builtin_amdgcn_s_setprio(0);
+            if (odd) { fetch_row(RA); layer(LANDED, ey, RB, RA, carryB, carryA); publish_carry(carryA); }
+            else { fetch_row(RB); layer(LANDED, ey, RA, RB, carryA, carryB); publish_carry(carryB); }
+        }
     }
 #endif
     if (top_row) {                // the last logical row of the domain: only the layer below it contributes
@@ -459,6 +572,20 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         emit_row(o, keep, p.ny - 1, true);
         flush_store();
     }
+    if constexpr (W > 1) {
+        if (chain_dn) {               // finish the strip's first row: parked half + the carry of the strip below
+            spin_until(&cf_sflag[sub - 1][1][wv], 1u);
+            volatile float* s0 = &cf_seam[sub - 1][0][tid];
+            float o[NW + 1], keep[NW];
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) o[n] = s0[(4 * NW + 4 + n) * CF_TS] + s0[(3 * NW + 3 + n) * CF_TS];
+#pragma unroll
+            for (int n = 0; n < NW; ++n) keep[n] = s0[(5 * NW + 5 + n) * CF_TS];
+            emit_row(o, keep, sb0, true);
+            flush_store();
+        }
+    }
+    }                                 // active
 
 #ifdef DN_STAMP2D
     if (tid == 0) {
@@ -469,12 +596,19 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_cf_kernel(co
         }
     }
 #endif
-    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, T, red, &last_flag);
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
 }
 
 template <int E, bool VEC, int FL>
 static void cf_launch_one(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
-    hipLaunchKernelGGL((poisson2d_q1_cf_kernel<E, VEC, FL>), dim3(g.chunks, g.strips, batch), dim3(g.T), 0, s, pp);
+    if constexpr (E == 4 && VEC && DN_CF_W > 1) {
+        if (g.W == DN_CF_W) {         // chained sub-strips (plan2d): W strips per workgroup
+            hipLaunchKernelGGL((poisson2d_q1_cf_kernel<E, VEC, FL, DN_CF_W>), dim3(g.chunks, (g.strips + DN_CF_W - 1) / DN_CF_W, batch),
+                               dim3(CF_TS * DN_CF_W), 0, s, pp);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((poisson2d_q1_cf_kernel<E, VEC, FL, 1>), dim3(g.chunks, g.strips, batch), dim3(g.T), 0, s, pp);
 }
 
 template <int E, bool VEC>
@@ -503,7 +637,10 @@ static void cf_launch_flags(const PoissonParams& pp, const Geom2D& g, int batch,
 #undef DN_CF
 }
 
+int poisson2d_q1_cf_chain() { return DN_CF_W > 1 && !DN_CF_REV && !DN_CF_PF ? DN_CF_W : 1; }       // what plan2d may put into Geom2D::W
+
 int launch_poisson2d_q1_cf(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s) {
+    if (g.W > 1 && !(g.W == poisson2d_q1_cf_chain() && g.E == 4 && vec && g.T == CF_TS && g.R + 3 <= CF_NSLOT)) return DN_E_BADARG;
     if (g.E == 4 && vec) { cf_launch_flags<4, true>(pp, g, batch, s); return 0; }
     if (g.E == 2 && vec) { cf_launch_flags<2, true>(pp, g, batch, s); return 0; }
     if (g.E == 2) { cf_launch_flags<2, false>(pp, g, batch, s); return 0; }

@@ -36,6 +36,7 @@ struct PoissonParams {
     int nx, ny, nz;        // nodes
     int nelx, nely, nelz;  // elements
     int rows_per_strip;    // element layers per strip along the marched axis
+    int nstrips;           // 2-D: strips per sample (chained launches: the last workgroup of a sample may hold fewer than W)
     int want_sums;
 };
 
@@ -286,7 +287,7 @@ __device__ __forceinline__ void bc_nodes(const PoissonParams& p, const SampleBas
     }
 }
 
-struct Geom2D { int T, E, chunks, strips, R; };
+struct Geom2D { int T, E, chunks, strips, R, W = 1; };     // W: strips chained per workgroup (closed-form Q1 kernel only)
 struct Geom3D { int TX, TY, E, chunks, tiles, strips, R; };
 
 // 2-D Q1 marching kernels are compiled one translation unit per NGP (poisson2d_q1_g{2,3,4}.hip)
@@ -295,6 +296,7 @@ int launch_poisson2d_q1_g3(const PoissonParams& pp, const Geom2D& g, int batch, 
 int launch_poisson2d_q1_g4(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
 // closed-form 2-D Q1 kernel (poisson2d_q1_cf.hip): any rule, nodal forcing
 int launch_poisson2d_q1_cf(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s);
+int poisson2d_q1_cf_chain();      // strips per workgroup the library's closed-form kernel was built to chain (1: none)
 // 3-D Q1 marching kernels likewise (poisson3d_q1_g{2,3,4}.hip)
 int launch_poisson3d_q1_g2(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);
 int launch_poisson3d_q1_g3(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);

@@ -193,6 +193,12 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = ceil_div(nely, g.R);
+    // Launches that fill the chip anyway (>= 4 waves per SIMD at the full strip height): chain W neighbouring strips per workgroup (closed-form
+    // Q1 kernel, poisson2d_q1_cf.hip) -- the same waves, but a workgroup reads W R + 2 node rows instead of W (R + 2) and recomputes one
+    // seam layer instead of W.  Smaller launches keep one strip per workgroup (more, independent workgroups).
+    const int cw = poisson2d_q1_cf_chain();
+    g.W = 1;
+    if (P == 1 && cw > 1 && g.E == 4 && g.T == 128 && g.R >= 8 && g.R + 3 <= 64 && g.strips >= cw && waves_per_strip * g.strips >= 4096) g.W = cw;
     return g;
 }
 
@@ -262,13 +268,15 @@ static Geom3D plan3d(const dn_mesh* m) {
 static Geom2D plan2d_env(const dn_mesh* m, int P, bool allow_e4 = true) {
     Geom2D g = plan2d(m, P, allow_e4);
     const char* e = config(CFG_PLAN2D);
-    int T, E, R;
-    if (e && sscanf(e, "%d,%d,%d", &T, &E, &R) == 3 && T >= 64 && T <= 256 && (E == 1 || E == 2 || E == 4) && R >= 1 &&
+    int T, E, R, W = 0;
+    if (e && sscanf(e, "%d,%d,%d,%d", &T, &E, &R, &W) >= 3 && T >= 64 && T <= 256 && (E == 1 || E == 2 || E == 4) && R >= 1 &&
         !(P == 1 && (E == 1 || (E == 4 && (m->nx % 4 != 0 || !allow_e4))))) {
         const int nely = (m->ny - 1) / P;
         g.T = T; g.E = E; g.R = R > nely ? nely : R;
         g.chunks = chunks_for((m->nx - 1) / (E * P) + 1, T);
         g.strips = ceil_div(nely, g.R);
+        const int cw = poisson2d_q1_cf_chain();        // "T,E,R,W": W = 1 (or absent) one strip per workgroup, W >= 2 the library's chain length where it applies
+        g.W = (W >= 2 && cw > 1 && P == 1 && E == 4 && T == 128 && g.R + 3 <= 64 && g.R >= 2) ? cw : 1;
     }
     return g;
 }
@@ -476,12 +484,14 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     if (m->nsd == 2) {
         const Geom2D g = plan2d_env(m, P, allow_e4);
         pp.rows_per_strip = g.R;
+        pp.nstrips = g.strips;
         const int NW = g.E * P;
         const bool vec = vec_ok(NW);
         rc = launch2d(pp, g, P, m->ngp, m->batch, vec, s);
     } else {
         const Geom3D g = plan3d_env(m);
         pp.rows_per_strip = g.R;
+        pp.nstrips = g.strips;
         const int NW = g.E;
         const bool vec = vec_ok(NW);
         switch (m->ngp) {

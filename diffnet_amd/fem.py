@@ -38,6 +38,8 @@ class FemGeometry:
         B, D, _ = Basis1D(deg).at_gauss(self.gpx_1d)
         self.basis, self.dbasis = B, D
         self._mesh = {}
+        # everything a launch takes from the geometry, as a hashable value (ops.poisson_apply keys its cached prepared calls on it)
+        self.key = (nsd, deg, ngp_1d, self.sizes, self.hs, tuple(float(x) for x in self.gpx_1d), tuple(float(x) for x in self.gpw_1d))
 
     def mesh_struct(self, batch):
         m = self._mesh.get(batch)

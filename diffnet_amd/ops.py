@@ -14,7 +14,9 @@ from . import _lib
 from ._lib import DnDirichlet, DnFsdtArgs, DnMesh, DnPoissonArgs, I32x3, DiffNetHipError
 
 
-def _require(t, name, ndim=None):
+def _require(t, name, ndim=None, strict=False):
+    """`strict` (prepared launches): the tensor itself must be usable -- a hidden .contiguous() copy would be read by every later
+    launch instead of the caller's (since updated) tensor."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
     if not t.is_cuda:
@@ -23,6 +25,8 @@ def _require(t, name, ndim=None):
         raise TypeError(f"{name} must be float32, got {t.dtype}")
     if ndim is not None and t.dim() != ndim:
         raise ValueError(f"{name} must have {ndim} dims, got shape {tuple(t.shape)}")
+    if strict and not t.is_contiguous():
+        raise DiffNetHipError(f"{name} is not contiguous: a prepared launch (PoissonPlan) keeps the pointers it was given; pass a contiguous tensor")
     return t.contiguous()
 
 
@@ -267,12 +271,110 @@ def _workspace(dev, nbytes):
     return ws
 
 
+# ---- one-shot calls: prepared launches cached behind the public API ------------------------------------------------------------
+# energy_loss / energy_loss_and_grad / residual* evaluate the operator on the same buffers step after step (a training loop's network
+# output lands in the same allocator block every iteration).  Validation and the argument structs of such a call are kept in a small
+# LRU keyed on everything they depend on -- pointers, shapes, condition forms, coefficients, stream -- so that a repeat costs the key,
+# the output allocations and one ctypes call instead of the full preparation (22 -> ~8 us of host time: small meshes are bounded by
+# the device, not by Python).  An entry holds NO reference to the caller's tensors (a pointer + shape is all a launch needs, and the
+# caller passes live tensors to every call); outputs are allocated fresh per call (a cached call never overwrites an earlier result).
+_CALL_CACHE = __import__("collections").OrderedDict()
+_CALL_CACHE_MAX = 16
+_CALL_STATS = {"hit": 0, "miss": 0, "uncached": 0}
+
+
+def _tkey(t):
+    """What a launch depends on for a tensor argument that is used as it is; None when it would need a conversion copy."""
+    if t is None:
+        return 0
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+        return None
+    return (t.data_ptr(), t.dtype, tuple(t.shape))
+
+
+def _call_key(geom, u, nu, f, f_gp, dl, scal, want_out, want_sums, out):
+    parts = [geom.key, u.device.index, torch.cuda.current_stream(u.device).cuda_stream, scal, want_out, want_sums]
+    for t in (u, nu, f, f_gp, out):
+        k = _tkey(t)
+        if k is None or (k != 0 and k[1] != torch.float32):
+            return None
+        parts.append(k)
+    for d in dl:
+        m, v = d.mask, d.value
+        if isinstance(m, PackedMask):
+            mk = ("bits", m.bits.data_ptr(), m.shape)
+        elif isinstance(m, BoxFaces):
+            mk = ("box", m.bits)
+        else:
+            mk = _tkey(m)
+            if mk is None or mk == 0 or mk[1] not in (torch.float32, torch.uint8):
+                return None
+        if isinstance(v, torch.Tensor):
+            vk = _tkey(v)
+            if vk is None or vk[1] != torch.float32 or len(vk[2]) != u.dim():
+                return None
+        else:
+            vk = float(v)
+        parts.append((mk, vk))
+    return tuple(parts)
+
+
 def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
                   out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None):
     """One launch of dn_poisson_apply.  Returns (out | None, sums | None) where sums is a float64 device
     tensor [energy, sum(out_unscaled^2)].  With `loss_scale` a third value is returned: the 0-dim float32 tensor
     energy * loss_scale written by the same launch.  See include/diffnet_hip.h for the operator definition."""
-    return PoissonPlan(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out).launch()
+    dl = _norm_dirichlet(dirichlet)
+    key = None
+    if isinstance(u, torch.Tensor) and u.is_cuda:
+        key = _call_key(geom, u, nu, f, f_gp, dl, (float(alpha), float(beta), float(c), float(wscale), float(out_scale),
+                                                   None if loss_scale is None else float(loss_scale)), want_out, want_sums, out)
+    if key is None:            # something needs a conversion copy (or is invalid: the full preparation says what)
+        _CALL_STATS["uncached"] += 1
+        return PoissonPlan(geom, u, nu, f, f_gp, dl, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out, strict=False).launch()
+    with _WS_LOCK:
+        ent = _CALL_CACHE.get(key)
+        if ent is not None:
+            _CALL_CACHE.move_to_end(key)
+    if ent is None:
+        _CALL_STATS["miss"] += 1
+        plan = PoissonPlan(geom, u, nu, f, f_gp, dl, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out, strict=True)
+        res = plan.launch()
+        # keep the structs, the workspace and the condition objects' own cached images; drop the caller's tensors and this call's outputs
+        plan.keep = [t for t in plan.keep if any(t is w for w in _WS.values())] + [d.mask for d in dl if not isinstance(d.mask, torch.Tensor)]
+        plan.result = None
+        plan.fresh = (want_out and out is None, want_sums, loss_scale is not None)
+        with _WS_LOCK:
+            _CALL_CACHE[key] = plan
+            while len(_CALL_CACHE) > _CALL_CACHE_MAX:
+                _CALL_CACHE.popitem(last=False)
+        return res
+    _CALL_STATS["hit"] += 1
+    a = ent.args
+    new_out, has_sums, has_loss = ent.fresh
+    o = out
+    if new_out:
+        o = torch.empty_like(u)
+        a.out = o.data_ptr()
+    sums = loss32 = None
+    if has_sums:
+        sums = torch.empty(2, dtype=torch.float64, device=u.device)
+        a.energy = sums.data_ptr()
+        a.sumsq = a.energy + 8
+    if has_loss:
+        loss32 = torch.empty((), dtype=torch.float32, device=u.device)
+        a.energy_f32 = loss32.data_ptr()
+    rc = ent._fn(ent._mesh_ref, ent._args_ref, C.c_void_p(key[2]))
+    if rc:
+        _lib.check(rc, "dn_poisson_apply")
+    return (o, sums, loss32) if has_loss else (o, sums)
+
+
+def call_cache_clear():
+    """Forget the cached prepared calls (after dn_config_set of a launch-plan switch: the workspace size depends on the plan)."""
+    with _WS_LOCK:
+        _CALL_CACHE.clear()
+    _POISSON_WS_BYTES.clear()
 
 
 class PoissonPlan:
@@ -282,9 +384,11 @@ class PoissonPlan:
     host-side preparation -- and for anything captured into a HIP graph.  Outputs are overwritten by every launch."""
 
     def __init__(self, geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
-                 out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None):
+                 out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None, strict=True):
+        # strict: every tensor argument must be usable as it is (contiguous float32 fields, float32 / uint8 mask images) -- a conversion
+        # would be a one-time copy that later launches keep reading after the caller has updated the original in place
         self.mesh, self.args, self.keep, self.result = _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale,
-                                                                        want_out, want_sums, loss_scale, out)
+                                                                        want_out, want_sums, loss_scale, out, strict=strict)
         self.device = u.device
         self.stream = torch.cuda.current_stream(u.device).cuda_stream      # the reduction workspace belongs to this stream
         self._fn = _lib.lib().dn_poisson_apply
@@ -300,10 +404,10 @@ class PoissonPlan:
         return self.result
 
 
-def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out):
+def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out, strict=False):
     """Validation + argument structs of one dn_poisson_apply call: (mesh, args, tensors to keep alive, result tuple)."""
     nsd = geom.nsd
-    u = _require(u, "u", nsd + 2)
+    u = _require(u, "u", nsd + 2, strict)
     B = u.shape[0]
     node_shape = tuple(geom.node_shape)            # (ny, nx) or (nz, ny, nx)
     if tuple(u.shape[1:]) != (1, *node_shape):
@@ -313,7 +417,7 @@ def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, ou
     args.u = u.data_ptr()
 
     def field(t, name, allow_gp=False):
-        t = _require(t, name, nsd + 2)
+        t = _require(t, name, nsd + 2, strict)
         if t.shape[0] not in (1, B):
             raise ValueError(f"{name} batch {t.shape[0]} does not broadcast to {B}")
         keep.append(t)
@@ -358,6 +462,9 @@ def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, ou
         m = _mask_image(m, u)
         if not isinstance(m, torch.Tensor) or not m.is_cuda:
             raise DiffNetHipError("Dirichlet mask must be a CUDA tensor")
+        if strict and (m.dtype == torch.bool or not m.is_contiguous()):
+            raise DiffNetHipError("PoissonPlan: a bool or non-contiguous Dirichlet mask would be converted into a one-time copy; pass a "
+                                  "contiguous float32 / uint8 image (or a PackedMask / BoxFaces)")
         if m.dtype == torch.bool:
             m = m.to(torch.uint8)
         if m.dtype not in (torch.float32, torch.uint8):
@@ -374,7 +481,9 @@ def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, ou
             v = d.value
             if v.dim() == nsd:
                 v = v[(None,) * 2]
-            v = _require(v.to(u.device) if not v.is_cuda else v, "Dirichlet value", nsd + 2)
+            if strict and not v.is_cuda:
+                raise DiffNetHipError("PoissonPlan: the Dirichlet value field must live on the GPU (a prepared launch would keep a one-time copy)")
+            v = _require(v.to(u.device) if not v.is_cuda else v, "Dirichlet value", nsd + 2, strict)
             if tuple(v.shape[1:]) != (1, *node_shape) or v.shape[0] not in (1, B):
                 raise ValueError("Dirichlet value field shape does not match u")
             keep.append(v)
@@ -502,7 +611,9 @@ def _fused(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, l
     """(out, sums, loss) of one dn_poisson_apply launch as the registered operator diffnet_mi::poisson_apply: differentiable
     wrt u through all three outputs (torch_ops._pa_backward), an ordinary node for torch.compile."""
     from . import torch_ops
-    return torch_ops.poisson_apply(u, nu, f, f_gp, *torch_ops.dirichlet_args(dirichlet, u), *torch_ops.geometry_args(geom),
+    compact = (geom.nsd == 2 and geom.deg == 1 and f_gp is None and _lib.lib().dn_config_get(b"Q1_RULE_KERNEL") in (None, b"") and
+               all(not isinstance(d.value, torch.Tensor) for d in dirichlet))
+    return torch_ops.poisson_apply(u, nu, f, f_gp, *torch_ops.dirichlet_args(dirichlet, u, compact), *torch_ops.geometry_args(geom),
                                    float(alpha), float(beta), float(c), float(wscale), float(out_scale), float(loss_scale))
 
 

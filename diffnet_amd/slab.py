@@ -9,8 +9,8 @@ neighbouring ranks (verified there against the oracle: p
 to the global module's because h is unchanged).
 
 Exchange steps per loss evaluation -- nothing else crosses GPUs:
-  * forward : one all-reduce(sum) of the local energy (8 bytes), asynchronous; the loss is sum / (B * nel_GLOBAL), not a
-    mean of per-rank means (slabs may differ by one layer);
+  * forward : one all-reduce(sum) of this rank's share of the loss (4 bytes: the kernel writes energy_local / (B * nel_GLOBAL) as fp32),
+    asynchronous; the loss is sum / (B * nel_GLOBAL), not a mean of per-rank means (slabs may differ by one layer);
   * backward: the gradient on an interface layer is the sum of both neighbours' contributions: one
     point-to-point exchange of a single node layer per interior face (256 KiB at 256^3), added in a fixed
     order (lower rank's part first) so both replicas are bitwise identical.  Each rank's own part comes from a thin
@@ -181,7 +181,7 @@ def slab_energy_loss_and_grad(dec, local_sum_and_grad, batch, group=None, interf
 class SlabPoisson:
     """Slab-parallel fused Poisson energy on the GPU: the per-rank FEM module + the two exchange steps.  Per evaluation:
     two thin launches (the element layer under each interior face -> this rank's part of the interface-layer gradient), the
-    layer exchange started on a side stream, the slab kernel on the main stream, the 8-byte loss all-reduce (asynchronous),
+    layer exchange started on a side stream, the slab kernel on the main stream, the 4-byte loss all-reduce (asynchronous),
     then one small add per face."""
 
     def __init__(self, nsd, sizes_xyz, lengths_xyz, rank, world, ngp_1d=2, group=None, device=None, overlap=True):
@@ -219,30 +219,59 @@ class SlabPoisson:
         the slab tensors (batch > 1: the cut would be a copy made per evaluation)."""
         from . import ops
         cut = lambda t: None if t is None else t[:, :, sl]
-        views = [cut(u), cut(nu), cut(f)] + [cut(x.mask) for x in ops._norm_dirichlet(dirichlet) if isinstance(x.mask, torch.Tensor)]
+        mcut = lambda mk: mk if mk.shape[2] <= 2 else cut(mk)          # (BoxFaces images are (1,1,*N): one sample, contiguous cuts)
+        views = [cut(u), cut(nu), cut(f)] + [mcut(x.mask) for x in ops._norm_dirichlet(dirichlet)]
         if any(v is not None and not v.is_contiguous() for v in views):
             return None
-        if any(not isinstance(x.mask, torch.Tensor) or isinstance(x.value, torch.Tensor) for x in ops._norm_dirichlet(dirichlet)):
+        if any(isinstance(x.value, torch.Tensor) for x in ops._norm_dirichlet(dirichlet)):
             return None
-        d = [ops.Dirichlet(cut(x.mask), x.value) for x in ops._norm_dirichlet(dirichlet)]
+        d = [ops.Dirichlet(mcut(x.mask), x.value) for x in ops._norm_dirichlet(dirichlet)]
         return ops.PoissonPlan(self.fem_thin.geom, cut(u), cut(nu), cut(f), None, d, alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale,
                                want_out=True, want_sums=False)
 
+    def _local_conditions(self, dirichlet, like):
+        """Dirichlet conditions in the form the slab launches take: tensor images of the LOCAL slab.  A PackedMask (given for the local
+        slab, like every other argument) is unpacked once; BoxFaces name faces of the GLOBAL box: the faces across the decomposed axis
+        exist on the outermost ranks only -- an interface between two ranks is not a boundary."""
+        from . import ops
+        out = []
+        slow = "xyz"[self.dec.nsd - 1]
+        for x in ops._norm_dirichlet(dirichlet):
+            m = x.mask
+            if isinstance(m, ops.PackedMask):
+                m = m.image()
+            elif isinstance(m, ops.BoxFaces):
+                local = ops.BoxFaces([])
+                local.bits = m.bits
+                if self.dec.rank > 0:
+                    local.bits &= ~ops.BoxFaces._BITS[slow + "lo"]
+                if self.dec.rank + 1 < self.dec.world:
+                    local.bits &= ~ops.BoxFaces._BITS[slow + "hi"]
+                m = local.image(like.shape[2:], like.device)
+            out.append(ops.Dirichlet(m, x.value))
+        return out
+
     def _plans(self, u_local, nu, f, dirichlet, c, jac, scale):
         """The step's launches prepared once per set of buffers (ops.PoissonPlan): at 256^3 over 8 ranks a rank's kernels take ~30 us,
-        the host-side preparation of three dn_poisson_apply calls ~75 us.  Re-prepared when a buffer, shape or coefficient changes."""
+        the host-side preparation of three dn_poisson_apply calls ~75 us.  Re-prepared when a buffer, shape or coefficient changes.
+        Returns (main, lo, hi, local conditions)."""
         from . import ops
         dl = ops._norm_dirichlet(dirichlet)
+        for name, t in (("u_local", u_local), ("nu", nu), ("f", f)) + tuple(("Dirichlet mask", x.mask) for x in dl) + tuple(("Dirichlet value", x.value) for x in dl):
+            if isinstance(t, torch.Tensor) and t.is_cuda and (not t.is_contiguous() or t.dtype == torch.bool):
+                # the prepared launches keep pointers: a hidden .contiguous() / .to(uint8) copy would go stale when the caller updates the original
+                raise ops.DiffNetHipError(f"SlabPoisson: {name} must be a contiguous float32 / uint8 tensor (SlabDecomposition.take() returns one)")
         key = (u_local.data_ptr(), tuple(u_local.shape), None if nu is None else nu.data_ptr(), None if f is None else f.data_ptr(),
                tuple((x.mask.data_ptr() if isinstance(x.mask, torch.Tensor) else id(x.mask),
                       x.value.data_ptr() if isinstance(x.value, torch.Tensor) else float(x.value)) for x in dl), float(c), float(jac))
         if getattr(self, "_plan_key", None) != key:
             dec = self.dec
-            main = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, dirichlet, alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale,
+            local = self._local_conditions(dl, u_local)
+            main = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, local, alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale,
                                    want_out=True, want_sums=True, loss_scale=scale)
-            lo = self._thin_plan(slice(0, 2), u_local, nu, f, dirichlet, c, jac, scale) if (self.overlap and dec.rank > 0) else None
-            hi = self._thin_plan(slice(-2, None), u_local, nu, f, dirichlet, c, jac, scale) if (self.overlap and dec.rank + 1 < dec.world) else None
-            self._plan_key, self._plan = key, (main, lo, hi)
+            lo = self._thin_plan(slice(0, 2), u_local, nu, f, local, c, jac, scale) if (self.overlap and dec.rank > 0) else None
+            hi = self._thin_plan(slice(-2, None), u_local, nu, f, local, c, jac, scale) if (self.overlap and dec.rank + 1 < dec.world) else None
+            self._plan_key, self._plan = key, (main, lo, hi, local)
         return self._plan
 
     def energy_loss_and_grad(self, u_local, nu=None, f=None, dirichlet=(), c=1.0, jac=1.0):
@@ -251,8 +280,7 @@ class SlabPoisson:
         B = u_local.shape[0]
         dec = self.dec
         scale = 1.0 / (B * dec.nel_global)
-        main, plan_lo, plan_hi = self._plans(u_local, nu, f, dirichlet, c, jac, scale)
-
+        main, plan_lo, plan_hi, dirichlet = self._plans(u_local, nu, f, dirichlet, c, jac, scale)      # conditions as local tensor images
 
         def parts():
             lo = hi = None

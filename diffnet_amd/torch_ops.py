@@ -171,7 +171,13 @@ def poisson_apply(u: torch.Tensor, nu: Optional[torch.Tensor], f: Optional[torch
     d = []
     for m, fld, v in ((mask0, field0, value0), (mask1, field1, value1)):
         if m is not None:
-            if m.dtype == torch.int32:          # bit-packed mask (ops.PackedMask.bits): (B|1, node rows, row_words)
+            if m.dtype == torch.int32:          # bit-packed mask (ops.PackedMask.bits): (B|1, node rows per sample, ceil(nx / 32))
+                rows = 1
+                for n in geom.node_shape[:-1]:
+                    rows *= int(n)
+                if m.dim() != 3 or m.shape[0] not in (1, u.shape[0]) or tuple(m.shape[1:]) != (rows, (int(geom.node_shape[-1]) + 31) // 32):
+                    raise TypeError(f"diffnet_mi::poisson_apply: an int32 mask is a bit-packed mask (ops.PackedMask.bits) of shape "
+                                    f"(B|1, {rows}, {(int(geom.node_shape[-1]) + 31) // 32}); got {tuple(m.shape)} -- mask images are float32, uint8 or bool")
                 m = _ops.PackedMask(m, (m.shape[0], 1, *geom.node_shape))
             d.append(_ops.Dirichlet(m, fld if fld is not None else v))
     out, sums, loss = _ops.poisson_apply(geom, u, nu, f, f_gp, d, alpha=alpha, beta=beta, c=c, wscale=wscale, out_scale=out_scale,
@@ -233,10 +239,11 @@ def geometry_args(geom):
     return geom.nsd, geom.deg, geom.ngp_1d, [int(s) for s in geom.sizes], [float(h) for h in geom.hs]
 
 
-def dirichlet_args(dirichlet, like=None):
+def dirichlet_args(dirichlet, like=None, compact=True):
     """(mask0, field0, value0, mask1, field1, value1) from up to two Dirichlet conditions.  The operator schema carries tensors
     only: a PackedMask travels as its int32 bit tensor, BoxFaces as the (cached) bit-packed image of the faces (`like`: the
-    nodal field, for its shape and device)."""
+    nodal field, for its shape and device).  compact=False (the call will not run a kernel that reads bits: 3-D, Q2/Q3, forcing at
+    the Gauss points): the cached uint8 images travel instead, so that nothing is unpacked per call."""
     out = []
     ds = list(dirichlet) + [None] * (2 - len(dirichlet))
     for d in ds:
@@ -245,13 +252,18 @@ def dirichlet_args(dirichlet, like=None):
             continue
         m = d.mask
         if isinstance(m, _ops.BoxFaces):
-            key = ("bits", tuple(like.shape[2:]), str(like.device))
-            pm = m._img.get(key)
-            if pm is None:
-                pm = m._img[key] = _ops.PackedMask.pack(m.image(like.shape[2:], like.device))
-            m = pm
+            if compact:
+                key = ("bits", tuple(like.shape[2:]), str(like.device))
+                pm = m._img.get(key)
+                if pm is None:
+                    pm = m._img[key] = _ops.PackedMask.pack(m.image(like.shape[2:], like.device))
+                m = pm
+            else:
+                m = m.image(like.shape[2:], like.device)
         if isinstance(m, _ops.PackedMask):
-            m = m.bits if not isinstance(d.value, torch.Tensor) else m.image()
+            m = m.bits if (compact and not isinstance(d.value, torch.Tensor)) else m.image()
+        elif isinstance(m, torch.Tensor) and m.dtype == torch.int32:
+            raise TypeError("Dirichlet mask images are float32, uint8 or bool; int32 tensors are reserved for bit-packed masks (wrap them in ops.PackedMask)")
         if isinstance(d.value, torch.Tensor):
             out += [m, d.value, 0.0]
         else:

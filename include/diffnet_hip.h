@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 6
+#define DN_ABI_VERSION 7
 
 #define DN_E_BADARG (-1)    /* null pointer / non-positive size / unsupported combination   */
 #define DN_E_UNSUPPORTED (-2) /* (nsd, degree, ngp) outside the compiled instantiations      */
@@ -33,9 +33,13 @@ extern "C" {
 /* Process-wide tuning / A-B switches (launch geometry overrides, kernel-variant selection).  They are NOT part of the
  * numerical contract: every setting yields the same results to rounding.  The table is initialised ONCE when the library
  * is loaded, from the environment variables DN_<KEY>; afterwards the environment is never read again (no getenv on the
- * launch path) and the only way to change a switch is this call.  Keys: "PLAN2D" ("T,E,R"), "PLAN3D" ("TX,TY,E,R"),
- * "PLAN_FSDT" ("T,R"), "Q1_RULE_KERNEL" (non-empty: per-Gauss-point 2-D Q1 kernels instead of the closed form),
- * "GPE_GATHER" (non-empty: per-node gather adjoint of gauss_pt_eval), "Q1_3D_V1" (non-empty: first-generation 3-D Q1 kernel).  value NULL or "" clears the switch.
+ * launch path) and the only way to change a switch is this call.  Keys (the table kKeys in csrc/dn_api.hip):
+ *   "PLAN2D" ("T,E,R[,W]": threads per strip, elements per thread, node rows per strip, W >= 2 = chain strips per workgroup
+ *   where the closed-form Q1 kernel can), "PLAN3D" ("TX,TY,E,R"), "PLAN_FSDT" ("T,R"),
+ *   "Q1_RULE_KERNEL" (non-empty: per-Gauss-point 2-D Q1 kernels instead of the closed form),
+ *   "GPE_GATHER" (non-empty: per-node gather adjoint of gauss_pt_eval), "GPE_TILED" (non-empty: tiled LDS adjoint instead of the
+ *   marching 3-D Q1 adjoint), "Q1_3D_T16" (non-empty: the 3-D Q1 kernel form in which every thread loads its own nodes),
+ *   "Q1_3D_E1SUM" (non-empty: 3-D stiffness energy summed Gauss point by Gauss point).  value NULL or "" clears the switch.
  * Returns 0, or DN_E_BADARG for an unknown key / over-long value.  Not thread-safe against concurrent launches.
  * No reference counterpart (the reference has no tuning surface). */
 int dn_config_set(const char *key, const char *value);
@@ -130,6 +134,13 @@ typedef struct dn_poisson_args {
 int dn_abi_version(void);
 /* Human-readable build info ("gfx950 hipcc <ver> ..."), static storage. */
 const char *dn_build_info(void);
+
+/* Measurement probe, no reference counterpart: out = a * b + c over n floats (n % 4 == 0, 16-byte aligned arrays) as a plain streaming
+ * kernel -- three arrays read once, one written once: the access mix of the fused energy loss + gradient without its halo rows, its
+ * reduction and its arithmetic.  bench.py runs it over the arrays of the timed launches and reports the rate as
+ * roofline.stream_ceiling.  mode: bit 0 non-temporal stores, bit 1 non-temporal loads, bits 2.. the form (0 one 16-byte vector per
+ * thread, 1 blocks of four vectors per thread, 2 the same with 2048 persistent workgroups). */
+int dn_probe_stream(const float *a, const float *b, const float *c, float *out, int64_t n, int32_t mode, void *stream);
 
 int64_t dn_poisson_workspace_bytes(const dn_mesh *mesh);
 int dn_poisson_apply(const dn_mesh *mesh, const dn_poisson_args *args, void *stream);

@@ -117,3 +117,50 @@ def test_2d_paired_strips_any_strip_height(n, ngp, B):
     finally:
         _lib.config_set("PLAN2D", "")
         ops._POISSON_WS_BYTES.clear()
+
+
+@pytest.mark.parametrize("sizes,ngp,B", [((8, 8), 2, 1), ((64, 64), 3, 2), ((64, 40), 2, 3), ((516, 37), 3, 1), ((512, 512), 3, 2)])
+def test_2d_chained_strips_equal_single_strips(sizes, ngp, B):
+    """Launches that fill the chip chain several neighbouring strips per workgroup (poisson2d_q1_cf.hip, W > 1): a strip takes the node row it
+    shares with its neighbour, and the neighbour's contributions to it, through LDS instead of re-reading the row and recomputing the
+    seam layer.  Forced here on small meshes for every strip height class -- strips of 2 rows, heights that do not divide the mesh, a
+    last workgroup with fewer strips than the chain, one strip only, two x-chunks -- with every coefficient / condition combination the
+    kernel is instantiated for; against one strip per workgroup (same kernel) and the per-point kernel."""
+    from diffnet_amd import BoxFaces, PackedMask, _lib, ops
+    kw = dict(nsd=2, domain_sizes=sizes, domain_lengths=(1.0, 0.8), domain_size=sizes[0], ngp_1d=ngp)
+    m = module(kw)
+    shape = (B, 1, sizes[1], sizes[0])
+    u, nu, f = cu(seeded(shape, 31)), cu(seeded(shape, 32) + 0.5), cu(seeded(shape, 33))
+    bc = boundary_mask((1,) + shape[1:]).to(torch.uint8).to(dev())
+    src = (seeded(shape, 34) < 0.05).to(torch.uint8).to(dev())
+    cases = {"none": (nu, f, []), "box": (nu, f, [(BoxFaces("all"), 0.0)]), "bits+box": (nu, f, [(PackedMask.pack(src), 1.0), (BoxFaces("all"), 0.0)]),
+             "u8 x2": (nu, f, [(src, 1.0), (bc, 0.0)]), "f32": (nu, f, [(bc.float(), 0.0)]), "no nu": (None, f, [(bc, 0.0)]),
+             "no f": (nu, None, [(PackedMask.pack(bc.expand(shape).contiguous()), 0.0)]), "bare": (None, None, [(BoxFaces("all"), 0.0)])}
+    ref = {}
+    _lib.config_set("Q1_RULE_KERNEL", "1")
+    try:
+        for name, (a, b, d) in cases.items():
+            if not any(isinstance(x[0], (BoxFaces, PackedMask)) for x in d):
+                ref[name] = m.energy_loss_and_grad(u, a, b, dirichlet=d, c=0.7)
+    finally:
+        _lib.config_set("Q1_RULE_KERNEL", "")
+    try:
+        for R in (2, 3, 5, 9, 16, 40, 61):
+            res = {}
+            for W in (1, 2):
+                _lib.config_set("PLAN2D", f"128,4,{R},{W}")
+                ops._POISSON_WS_BYTES.clear()
+                for name, (a, b, d) in cases.items():
+                    res[name, W] = m.energy_loss_and_grad(u, a, b, dirichlet=d, c=0.7)
+            for name in cases:
+                (l1, g1), (l2, g2) = res[name, 1], res[name, 2]
+                scale = float(g1.abs().max()) + 1e-30
+                np.testing.assert_allclose(float(l2), float(l1), rtol=2e-6, err_msg=f"R={R} {name}")
+                assert float((g2 - g1).abs().max()) <= 2e-6 * scale, f"R={R} {name}"
+                if name in ref:
+                    l0, g0 = ref[name]
+                    np.testing.assert_allclose(float(l2), float(l0), rtol=3e-6, err_msg=f"R={R} {name} vs per-point kernel")
+                    assert float((g2 - g0).abs().max()) <= 1e-5 * scale, f"R={R} {name} vs per-point kernel"
+    finally:
+        _lib.config_set("PLAN2D", "")
+        ops._POISSON_WS_BYTES.clear()

@@ -3,7 +3,7 @@
 steady-state rate of re-evaluating one batch comes from lines that survive in the 256 MB Infinity Cache from one launch to the next?"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diffnet_amd import BoxFaces, DiffNet2DFEM, _lib, ops
+from diffnet_amd import BoxFaces, DiffNet2DFEM, PackedMask, _lib, ops
 dev = torch.device("cuda:0")
 m = DiffNet2DFEM(None, domain_size=512, ngp_1d=3).to(dev)
 shape = (64, 1, 512, 512)
@@ -15,11 +15,15 @@ for k in range(8):
     u, nu, f = (torch.rand(shape, generator=g).to(dev) for _ in range(3))
     nu += 0.5
     sets.append((u, nu, f))
-# usage: rotate_batches.py [PLAN2D override]   (DN_LIB_PATH selects a variant build)
-if len(sys.argv) > 1:
+# usage: rotate_batches.py [PLAN2D override | default] [box | bits | u8]   (DN_LIB_PATH selects a variant build)
+if len(sys.argv) > 1 and sys.argv[1] != "default":
     _lib.config_set("PLAN2D", sys.argv[1])
+form = sys.argv[2] if len(sys.argv) > 2 else "box"
+bc = torch.zeros(shape, dtype=torch.uint8, device=dev)
+bc[..., 0] = 1; bc[..., -1] = 1; bc[..., 0, :] = 1; bc[..., -1, :] = 1
+cond = {"box": lambda: [(BoxFaces(), 0.0)], "bits": lambda: [(PackedMask.pack(bc.clone()), 0.0)], "u8": lambda: [(bc.clone(), 0.0)]}[form]
 for nb in ((1, 2, 4, 8, 1) if len(sys.argv) == 1 else (4, 1)):
-    plans = [ops.PoissonPlan(m.geom, *sets[k], None, [(BoxFaces(), 0.0)], **kw) for k in range(nb)]
+    plans = [ops.PoissonPlan(m.geom, *sets[k], None, cond(), **kw) for k in range(nb)]
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.04:
         for i in range(24):
@@ -34,4 +38,4 @@ for nb in ((1, 2, 4, 8, 1) if len(sys.argv) == 1 else (4, 1)):
         b.record()
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 2.5)
-    print(f"plan {sys.argv[1] if len(sys.argv) > 1 else 'default'}: {nb} batch(es) in rotation: us per launch, back to back: median {sorted(ts)[1]:.2f}  {[round(t, 2) for t in ts]}", flush=True)
+    print(f"lib={os.path.basename(os.environ.get('DN_LIB_PATH', 'default'))} plan {sys.argv[1] if len(sys.argv) > 1 else 'default'} bc={form}: {nb} batch(es) in rotation: us per launch, back to back: median {sorted(ts)[1]:.2f}  {[round(t, 2) for t in ts]}", flush=True)

@@ -1,16 +1,25 @@
 #!/bin/bash
-# Build a VARIANT of libdiffnet_hip.so locally (cross-compile): only the named translation unit is recompiled with the extra
-# flags, the other objects come from diffnet_amd/build/.  usage: tools/variant_build.sh <tag> <tu.hip> "<flags>"
-# -> variants/libdn_<tag>.so   (select it with DN_LIB_PATH=... in the tools/ timing scripts)
+# Build a VARIANT of libdiffnet_hip.so for A/B measurements: the listed sources (default: the 2-D closed-form kernel) are recompiled with
+# extra flags, everything else is taken from the objects of the default build (diffnet_amd/build/*.o).  The result goes to
+# variants/libdn_<name>.so (git-ignored, travels with gpurun); select it with DN_LIB_PATH.  Fails loudly.
+# usage: tools/variant_build.sh <name> "<flags>" [source.hip ...]
 set -e
 cd "$(dirname "$0")/.."
-tag=$1; tu=$2; flags=$3
-mkdir -p variants/obj
-obj=variants/obj/${tag}_${tu%.hip}.o
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize -mllvm -amdgpu-sdwa-peephole=0 --offload-arch=gfx950 -w $flags -c diffnet_amd/csrc/$tu -o $obj
+name=$1; flags=$2; shift 2
+srcs=${@:-poisson2d_q1_cf.hip}
+base="-O3 -std=c++17 -fPIC -ffp-contract=fast -fno-slp-vectorize --offload-arch=gfx950 -mllvm -amdgpu-sdwa-peephole=0 -Wall -Wno-unused-variable -Wno-unused-but-set-variable"
+mkdir -p variants/objs
 objs=""
-for o in diffnet_amd/build/*.o; do
-  if [ "$(basename $o)" == "${tu%.hip}.o" ]; then objs="$objs $obj"; else objs="$objs $o"; fi
+skip=""
+for s in $srcs; do
+    o=variants/objs/${name}_${s%.hip}.o
+    /opt/rocm/bin/hipcc $base $flags -c diffnet_amd/csrc/$s -o $o
+    objs="$objs $o"
+    skip="$skip ${s%.hip}.o"
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o variants/libdn_${tag}.so
-echo "built variants/libdn_${tag}.so [$flags]"
+for o in diffnet_amd/build/*.o; do
+    b=$(basename $o)
+    case " $skip " in *" $b "*) ;; *) objs="$objs $o";; esac
+done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o variants/libdn_${name}.so
+echo "built variants/libdn_${name}.so [$flags]"
