@@ -156,11 +156,17 @@ def check(rc, what):
     raise DiffNetHipError(f"{what}: hipError_t {rc}")
 
 
+# Python-side mirror of the switches (the library reads DN_<KEY> once at load, then only dn_config_set changes them): lets host code
+# that is traced by torch.compile look a switch up without a foreign call
+CONFIG_MIRROR = {k[3:]: v for k, v in os.environ.items() if k.startswith("DN_")}
+
+
 def config_set(key, value):
     """Set a tuning / A-B switch of the library (include/diffnet_hip.h: dn_config_set); "" or None clears it."""
     rc = lib().dn_config_set(key.encode(), (value or "").encode())
     if rc != 0:
         raise DiffNetHipError(f"dn_config_set: unknown switch {key!r} or value too long")
+    CONFIG_MIRROR[key] = value or ""
     import sys
     ops = sys.modules.get(__package__ + ".ops")
     if ops is not None:

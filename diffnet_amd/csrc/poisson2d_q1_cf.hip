@@ -71,6 +71,33 @@ constexpr int CF_TS = 128;        // threads per chained sub-strip (two waves: 1
 constexpr int CF_NSLOT = 64;      // hand-over slots between the two waves of a sub-strip: one per emitted row, never reused (R + 3 <= 64)
 constexpr unsigned CF_SPIN_MAX = 1u << 20;   // bound of every LDS flag poll (a protocol error ends in wrong numbers, which the parity tests catch, not in a hung GPU)
 
+// LDS hand-overs of the chained strips are spelled as inline asm: a `volatile` LDS access makes the compiler wait for EVERY outstanding
+// memory operation around it (s_waitcnt vmcnt(0) lgkmcnt(0): 237 of them in the first build of the chained kernel, i.e. the row loads
+// no longer overlapped anything, +5 us per launch).  The asm forms touch lgkmcnt only; LDS returns a wave's accesses in order.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void lds_st(unsigned a, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st(unsigned a, unsigned v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_ld_nowait(float& d, unsigned a) { asm volatile("ds_read_b32 %0, %1" : "=v"(d) : "v"(a) : "memory"); }
+__device__ __forceinline__ unsigned lds_ld_u(unsigned a) {
+    unsigned d;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(a) : "memory");
+    return d;
+}
+__device__ __forceinline__ float lds_ld(unsigned a) {
+    float d;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(a) : "memory");
+    return d;
+}
+// after a group of lds_ld_nowait: the wait, tied to the destinations so that no use of them is scheduled above it
+template <int N>
+__device__ __forceinline__ void lds_wait(float (&v)[N]) {
+    if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4])::"memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])::"memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
+    else { static_assert(N == 1, "lds_wait: 1..5 values"); asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0])::"memory"); }
+}
+
 #ifdef DN_STAMP2D
 // Diagnostic build only (tools/clock2d.py): shader-clock ticks (s_memtime) and constant-100-MHz ticks (s_memrealtime) of every workgroup's
 // lifetime -> the clock the kernel really ran at (the MI355X lowers it under load: profiles/r2_clock_under_load.txt)
@@ -89,7 +116,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     static_assert(W == 1 || (!DN_CF_REV && !DN_CF_PF), "chained sub-strips: plain upward march only");
     // W > 1: the workgroup holds W sub-strips of CF_TS threads each; sub (wave-uniform) is this thread's sub-strip
     const int T = W > 1 ? CF_TS : (int)blockDim.x;
-    const int sub = W > 1 ? (int)threadIdx.x / CF_TS : 0;
+    const int sub = W > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / CF_TS) : 0;       // wave-uniform: everything derived from it stays scalar
     const int tid = W > 1 ? (int)threadIdx.x - sub * CF_TS : (int)threadIdx.x;
 #if DN_CF_REV
     // Workgroup -> (chunk, strip, sample) so that NEIGHBOURING strips run on the same XCD (one L2) at the same time: the dispatcher
@@ -143,7 +170,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     __shared__ unsigned cf_xflag[W > 1 ? W : 1];
     __shared__ float cf_seam[CW - 1][W > 1 ? SEAM_WORDS : 1][W > 1 ? CF_TS : 1];
     __shared__ unsigned cf_sflag[CW - 1][2][2];          // [seam][0: row published, 1: carry published][wave of the sub-strip]
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned seq = 0u;                                   // rows handed over so far (same count in both waves of a sub-strip)
     if constexpr (W > 1) {
         static_assert(CF_TS == 128, "two waves per sub-strip");
@@ -151,9 +178,10 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
         if (threadIdx.x < 4u * (W - 1)) (&cf_sflag[0][0][0])[threadIdx.x] = 0u;
         __syncthreads();
     }
-    auto spin_until = [&](volatile unsigned* flag, unsigned want) {       // wave-uniform poll of an LDS word
+    auto spin_until = [&](const unsigned* flag, unsigned want) {          // wave-uniform poll of an LDS word
+        const unsigned fa = lds_addr(flag);
         for (unsigned n = 0; n < CF_SPIN_MAX; ++n) {
-            if ((unsigned)__builtin_amdgcn_readfirstlane((int)*flag) >= want) break;
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)lds_ld_u(fa)) >= want) break;
             __builtin_amdgcn_s_sleep(1);
         }
     };
@@ -295,14 +323,13 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
         if constexpr (W > 1) {
             // inside a wave: lane l takes o[NW] of lane l - 1 (ds_bpermute); across the two waves: one LDS word per row + a row counter
             const float up = __shfl_up(o[NW], 1, 64);
-            volatile float* ve = &cf_edge[sub][seq & (CF_NSLOT - 1)];
-            volatile unsigned* vf = &cf_xflag[sub];
+            const unsigned ea = lds_addr(&cf_edge[sub][seq & (CF_NSLOT - 1)]);
             float edge = 0.f;
             if (wv == 0) {
-                if (lane == 63) { *ve = o[NW]; *vf = seq + 1u; }          // LDS executes a wave's accesses in order: value before counter
+                if (lane == 63) { lds_st(ea, o[NW]); lds_st(lds_addr(&cf_xflag[sub]), seq + 1u); }     // LDS executes a wave's accesses in order: value before counter
             } else {
-                spin_until(vf, seq + 1u);
-                edge = *ve;
+                spin_until(&cf_xflag[sub], seq + 1u);
+                edge = lds_ld(ea);
             }
             left = lane > 0 ? up : edge;
             ++seq;
@@ -411,11 +438,11 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
         if (W > 1 && chain_dn && ey == sb0) {
             // the strip's first row still lacks the contributions of the layer below it, which the strip below computes at its very end:
             // park this half in LDS (each thread re-reads its own words) and finish the row after the march
-            volatile float* s0 = &cf_seam[W > 1 ? sub - 1 : 0][0][tid];
+            const unsigned s0 = lds_addr(&cf_seam[W > 1 ? sub - 1 : 0][0][tid]);
 #pragma unroll
-            for (int n = 0; n <= NW; ++n) s0[(4 * NW + 4 + n) * CF_TS] = o[n];
+            for (int n = 0; n <= NW; ++n) lds_st(s0 + (4 * NW + 4 + n) * CF_TS * 4, o[n]);
 #pragma unroll
-            for (int n = 0; n < NW; ++n) s0[(5 * NW + 5 + n) * CF_TS] = L.keep[n];
+            for (int n = 0; n < NW; ++n) lds_st(s0 + (5 * NW + 5 + n) * CF_TS * 4, L.keep[n]);
         } else {
             emit_row(o, L.keep, ey, ey >= r_from);
         }
@@ -423,32 +450,42 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     // chained strips: row / carry hand-over with the neighbouring strip of the workgroup.  Thread t of one strip talks to thread t of the
     // other, which sits in the wave of the same number: one flag per wave and direction
     auto publish_row = [&](const CfRow<E>& r) {
-        volatile float* s0 = &cf_seam[W > 1 ? sub - 1 : 0][0][tid];
+        const unsigned s0 = lds_addr(&cf_seam[W > 1 ? sub - 1 : 0][0][tid]);
 #pragma unroll
         for (int n = 0; n <= NW; ++n) {
-            s0[n * CF_TS] = r.u[n];
-            if constexpr (HAS_NU) s0[(NW + 1 + n) * CF_TS] = r.n[n];
-            if constexpr (FMASS) s0[(2 * NW + 2 + n) * CF_TS] = r.g[n];
-            else if constexpr (HAS_F) s0[(2 * NW + 2 + n) * CF_TS] = r.f[n];
+            lds_st(s0 + n * CF_TS * 4, r.u[n]);
+            if constexpr (HAS_NU) lds_st(s0 + (NW + 1 + n) * CF_TS * 4, r.n[n]);
+            if constexpr (FMASS) lds_st(s0 + (2 * NW + 2 + n) * CF_TS * 4, r.g[n]);
+            else if constexpr (HAS_F) lds_st(s0 + (2 * NW + 2 + n) * CF_TS * 4, r.f[n]);
         }
-        if (lane == 0) *(volatile unsigned*)&cf_sflag[W > 1 ? sub - 1 : 0][0][wv] = 1u;
+        if (lane == 0) lds_st(lds_addr(&cf_sflag[W > 1 ? sub - 1 : 0][0][wv]), 1u);
     };
     auto fetch_row = [&](CfRow<E>& r) {
         spin_until(&cf_sflag[sub][0][wv], 1u);
-        volatile float* s0 = &cf_seam[sub][0][tid];
+        const unsigned s0 = lds_addr(&cf_seam[sub][0][tid]);
 #pragma unroll
-        for (int n = 0; n <= NW; ++n) {
-            r.u[n] = s0[n * CF_TS];
-            if constexpr (HAS_NU) r.n[n] = s0[(NW + 1 + n) * CF_TS];
-            if constexpr (FMASS) r.g[n] = s0[(2 * NW + 2 + n) * CF_TS];
-            else if constexpr (HAS_F) r.f[n] = s0[(2 * NW + 2 + n) * CF_TS];
+        for (int n = 0; n <= NW; ++n) lds_ld_nowait(r.u[n], s0 + n * CF_TS * 4);
+        lds_wait(r.u);
+        if constexpr (HAS_NU) {
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) lds_ld_nowait(r.n[n], s0 + (NW + 1 + n) * CF_TS * 4);
+            lds_wait(r.n);
+        }
+        if constexpr (FMASS) {
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) lds_ld_nowait(r.g[n], s0 + (2 * NW + 2 + n) * CF_TS * 4);
+            lds_wait(r.g);
+        } else if constexpr (HAS_F) {
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) lds_ld_nowait(r.f[n], s0 + (2 * NW + 2 + n) * CF_TS * 4);
+            lds_wait(r.f);
         }
     };
     auto publish_carry = [&](const float (&c)[NW + 1]) {
-        volatile float* s0 = &cf_seam[sub][0][tid];
+        const unsigned s0 = lds_addr(&cf_seam[sub][0][tid]);
 #pragma unroll
-        for (int n = 0; n <= NW; ++n) s0[(3 * NW + 3 + n) * CF_TS] = c[n];
-        if (lane == 0) *(volatile unsigned*)&cf_sflag[sub][1][wv] = 1u;
+        for (int n = 0; n <= NW; ++n) lds_st(s0 + (3 * NW + 3 + n) * CF_TS * 4, c[n]);
+        if (lane == 0) lds_st(lds_addr(&cf_sflag[sub][1][wv]), 1u);
     };
 
     auto set_prio = [&](int e) {
@@ -575,12 +612,19 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     if constexpr (W > 1) {
         if (chain_dn) {               // finish the strip's first row: parked half + the carry of the strip below
             spin_until(&cf_sflag[sub - 1][1][wv], 1u);
-            volatile float* s0 = &cf_seam[sub - 1][0][tid];
-            float o[NW + 1], keep[NW];
+            const unsigned s0 = lds_addr(&cf_seam[sub - 1][0][tid]);
+            float o[NW + 1], cy[NW + 1], keep[NW];
 #pragma unroll
-            for (int n = 0; n <= NW; ++n) o[n] = s0[(4 * NW + 4 + n) * CF_TS] + s0[(3 * NW + 3 + n) * CF_TS];
+            for (int n = 0; n <= NW; ++n) lds_ld_nowait(o[n], s0 + (4 * NW + 4 + n) * CF_TS * 4);
+            lds_wait(o);
 #pragma unroll
-            for (int n = 0; n < NW; ++n) keep[n] = s0[(5 * NW + 5 + n) * CF_TS];
+            for (int n = 0; n <= NW; ++n) lds_ld_nowait(cy[n], s0 + (3 * NW + 3 + n) * CF_TS * 4);
+            lds_wait(cy);
+#pragma unroll
+            for (int n = 0; n < NW; ++n) lds_ld_nowait(keep[n], s0 + (5 * NW + 5 + n) * CF_TS * 4);
+            lds_wait(keep);
+#pragma unroll
+            for (int n = 0; n <= NW; ++n) o[n] += cy[n];
             emit_row(o, keep, sb0, true);
             flush_store();
         }

@@ -611,7 +611,7 @@ def _fused(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, l
     """(out, sums, loss) of one dn_poisson_apply launch as the registered operator diffnet_mi::poisson_apply: differentiable
     wrt u through all three outputs (torch_ops._pa_backward), an ordinary node for torch.compile."""
     from . import torch_ops
-    compact = (geom.nsd == 2 and geom.deg == 1 and f_gp is None and _lib.lib().dn_config_get(b"Q1_RULE_KERNEL") in (None, b"") and
+    compact = (geom.nsd == 2 and geom.deg == 1 and f_gp is None and not _lib.CONFIG_MIRROR.get("Q1_RULE_KERNEL") and
                all(not isinstance(d.value, torch.Tensor) for d in dirichlet))
     return torch_ops.poisson_apply(u, nu, f, f_gp, *torch_ops.dirichlet_args(dirichlet, u, compact), *torch_ops.geometry_args(geom),
                                    float(alpha), float(beta), float(c), float(wscale), float(out_scale), float(loss_scale))
