@@ -61,6 +61,7 @@ SYMBOLS = {
     "dn_config_set": (C.c_int, [C.c_char_p, C.c_char_p]),
     "dn_config_get": (C.c_char_p, [C.c_char_p]),
     "dn_probe_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dn_probe_march": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dn_poisson_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
     "dn_poisson_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnPoissonArgs), C.c_void_p]),
     "dn_gauss_pt_eval_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,

@@ -198,6 +198,43 @@ __device__ __forceinline__ void load_seg4_dpp(const T* __restrict__ base, unsign
     }
 }
 
+// load_seg4_dpp with the lane exchange over ds_bpermute (__shfl_down: 2-3 cycles of a shared SIMD where a DPP move costs 30-36, see
+// DESIGN.md section 4) and, optionally, the 16-byte row vector as a NON-TEMPORAL load.  In this form every byte of a row is requested
+// once per wave (plus one dword through the scalar cache for the wave's last lane): the precondition for non-temporal loads to pay
+// (tools/march_probe.py, profiles/r3_march_probe.txt: the access pattern alone 51.4 -> 47.9 us once nothing is re-read).
+template <bool NT, typename T>
+__device__ __forceinline__ void load_seg4_shfl(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[5]) {
+    const unsigned xl = (unsigned)min(x0, nx - 4);
+    const unsigned eidx = (unsigned)__builtin_amdgcn_readfirstlane((int)rowoff) +
+                          (unsigned)min(__builtin_amdgcn_readfirstlane(x0) + 256, nx - 1);
+    const bool lastlane = (threadIdx.x & 63u) == 63u;
+    if constexpr (sizeof(T) == 4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f* a = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(base) + (rowoff + xl) * 4u);
+        const v4f v = NT ? __builtin_nontemporal_load(a) : *a;
+        const T lastv = base[eidx];
+        float e = __shfl_down(v.x, 1, 64);
+        // the exchange must run with every lane active: pinned here, or the compiler sinks it into the `!lastlane` side of the select
+        // below, where lane 63 -- the source of lane 62 -- is masked off and ds_bpermute returns 0 for it
+        asm volatile("" : "+v"(e));
+        const float vf[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = reinterpret_cast<const T&>(vf[k]);
+        const float ef = lastlane ? reinterpret_cast<const float&>(lastv) : e;
+        dst[4] = reinterpret_cast<const T&>(ef);
+    } else {
+        static_assert(sizeof(T) == 1, "load_seg4_shfl: 1- or 4-byte elements");
+        const uint32_t w = ld_at<uint32_t>(base, rowoff + xl);
+        const uint32_t last = (uint32_t)base[eidx];
+        uint32_t sh = (uint32_t)__shfl_down((int)w, 1, 64);
+        asm volatile("" : "+v"(sh));          // as above: the exchange stays outside the divergent select
+        const uint32_t e = lastlane ? last : sh;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = (T)((w >> (8 * k)) & 0xffu);
+        dst[4] = (T)(e & 0xffu);
+    }
+}
+
 // Exactly NW consecutive nodes starting at x0 (clamped like load_seg, no shared +1 node).
 template <int NW, bool VEC, typename T>
 __device__ __forceinline__ void load_own(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[NW]) {

@@ -46,12 +46,18 @@ struct CfRow {
 
 #ifndef DN_CF_DPPX
 #define DN_CF_DPPX 0              // 1: E = 4 takes the shared node x0 + 4 over DPP from the neighbouring lane instead of a strided per-lane load; measured equal (profiles/r2_2d_ab.txt)
+#endif                            // 2: the same over ds_bpermute (load_seg4_shfl)
+#ifndef DN_CF_NT_LD
+#define DN_CF_NT_LD 0             // with DN_CF_DPPX == 2: 1 = non-temporal row loads of nu and f, 2 = of u as well
 #endif
 #ifndef DN_CF_FMASS
 #define DN_CF_FMASS 1
 #endif
 #ifndef DN_CF_NT_COEF
-#define DN_CF_NT_COEF 0           // 1: non-temporal vector loads for nu and f (profiles/r2_ab2d_nt.txt)
+#define DN_CF_NT_COEF 1           // 1: non-temporal vector loads for nu and f (read once per launch; the node shared with the right neighbour stays a plain
+                                  // load).  Round 2 measured it on ONE re-evaluated batch, where it gives up the Infinity-Cache hits (47 -> 53 us) and left
+                                  // it off; on batches in rotation -- every launch streams from HBM, the regime bench.py now times -- it wins: mask bits
+                                  // 58.3 -> 55.5 us, box 56.5 -> 56.0 (profiles/r3_rotate_nt.txt).  2: u as well (slower: 59.8)
 #endif
 #ifndef DN_CF_REV
 #define DN_CF_REV 0               // 1: neighbouring strips march in opposite directions and share an XCD (see the kernel): the rows two strips share
@@ -64,9 +70,10 @@ struct CfRow {
 #endif
 
 #ifndef DN_CF_W
-#define DN_CF_W 4                 // sub-strips CHAINED per workgroup in launches that fill the chip (plan2d, poisson_fused.hip): W x 2 waves march W
-#endif                            // neighbouring strips; a strip takes the row it shares with the strip below / above through LDS instead of re-reading
-                                  // it from HBM and recomputing the seam layer: a workgroup of W strips of R rows reads W R + 2 rows instead of W (R + 2)
+#define DN_CF_W 4                 // sub-strips CHAINED per workgroup where the launch plan asks for it ("PLAN2D" "T,E,R,W"; not the default, see plan2d in
+#endif                            // poisson_fused.hip): W x 2 waves march W neighbouring strips; a strip takes the row it shares with the strip below / above
+                                  // through LDS instead of re-reading it from HBM and recomputing the seam layer: a workgroup of W strips of R rows reads
+                                  // W R + 2 rows instead of W (R + 2)
 constexpr int CF_TS = 128;        // threads per chained sub-strip (two waves: 128 x 4 elements = one 512-node row segment)
 constexpr int CF_NSLOT = 64;      // hand-over slots between the two waves of a sub-strip: one per emitted row, never reused (R + 3 <= 64)
 constexpr unsigned CF_SPIN_MAX = 1u << 20;   // bound of every LDS flag poll (a protocol error ends in wrong numbers, which the parity tests catch, not in a hung GPU)
@@ -236,20 +243,28 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
         for (int k = 0; k < 2; ++k) r.bx[k] = (yc == ylo[k] || yc == yhi[k]) ? NBITS : boxx[k];
     };
 
-    auto lseg = [&](auto base, unsigned rowoff, auto& dst) {
-        if constexpr (E == 4 && VEC && DN_CF_DPPX) load_seg4_dpp(base, rowoff, x0, p.nx, dst);
+    auto lseg = [&](auto base, unsigned rowoff, auto& dst, auto nt) {
+        if constexpr (E == 4 && VEC && DN_CF_DPPX == 2) load_seg4_shfl<decltype(nt)::value>(base, rowoff, x0, p.nx, dst);
+        else if constexpr (E == 4 && VEC && DN_CF_DPPX) load_seg4_dpp(base, rowoff, x0, p.nx, dst);
         else load_seg<NW, VEC>(base, rowoff, x0, p.nx, dst);
     };
+    constexpr std::integral_constant<bool, (DN_CF_NT_LD >= 2)> NT_U{};
+    constexpr std::integral_constant<bool, (DN_CF_NT_LD >= 1)> NT_C{};
+    constexpr std::false_type NT_NO{};
     auto row_issue = [&](int yr, CfRow<E>& r) {
         const int yp = ysgn * min(yr, p.ny - 1) + yoff;
         const unsigned rowoff = (unsigned)yp * (unsigned)p.nx;
-        lseg(sb.u, rowoff, r.u);
+#if DN_CF_NT_COEF >= 2
+        load_seg_stream<NW, VEC>(sb.u, rowoff, x0, p.nx, r.u);
+#else
+        lseg(sb.u, rowoff, r.u, NT_U);
+#endif
 #if DN_CF_NT_COEF
         if constexpr (HAS_NU) load_seg_stream<NW, VEC>(sb.nu, rowoff, x0, p.nx, r.n);
         if constexpr (HAS_F) load_seg_stream<NW, VEC>(sb.f, rowoff, x0, p.nx, r.f);
 #else
-        if constexpr (HAS_NU) lseg(sb.nu, rowoff, r.n);
-        if constexpr (HAS_F) lseg(sb.f, rowoff, r.f);
+        if constexpr (HAS_NU) lseg(sb.nu, rowoff, r.n, NT_C);
+        if constexpr (HAS_F) lseg(sb.f, rowoff, r.f, NT_C);
 #endif
         if constexpr (BC_PACKED) {
             packed_issue(yp, r);
@@ -260,7 +275,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
             for (int k = 0; k < 2; ++k) {
                 if (DN_CF_PF || has_mask[k]) {        // not pipelined: an absent condition costs no load (wave-uniform branch)
                     uint8_t t[NW + 1];
-                    lseg(mask8[k], rowoff, t);
+                    lseg(mask8[k], rowoff, t, NT_NO);
                     uint32_t w = 0u;
 #pragma unroll
                     for (int n = 0; n < NW; ++n) w |= (uint32_t)t[n] << (8 * n);

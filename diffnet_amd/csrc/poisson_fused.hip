@@ -193,12 +193,12 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = ceil_div(nely, g.R);
-    // Launches that fill the chip anyway (>= 4 waves per SIMD at the full strip height): chain W neighbouring strips per workgroup (closed-form
-    // Q1 kernel, poisson2d_q1_cf.hip) -- the same waves, but a workgroup reads W R + 2 node rows instead of W (R + 2) and recomputes one
-    // seam layer instead of W.  Smaller launches keep one strip per workgroup (more, independent workgroups).
-    const int cw = poisson2d_q1_cf_chain();
+    // One strip per workgroup.  The closed-form Q1 kernel can also CHAIN W neighbouring strips per workgroup (poisson2d_q1_cf.hip, "PLAN2D"
+    // "T,E,R,W"): a workgroup then reads W R + 2 node rows instead of W (R + 2) and recomputes one seam layer instead of W -- measured
+    // traffic goes from 1.09x to 1.02x of the algorithmic bytes, but the launch does not get faster: its length is the 17 dependent row
+    // trips of a strip either way (the chained strips wait for their lower neighbour's last layer instead of recomputing it), and the
+    // hand-overs cost 1-2 us (profiles/r3_rotate_chain.txt: 56.0 / 57.1 / 58.0 / 61.9 us for W = 1 / 2 / 4 / 8 on batches in rotation).
     g.W = 1;
-    if (P == 1 && cw > 1 && g.E == 4 && g.T == 128 && g.R >= 8 && g.R + 3 <= 64 && g.strips >= cw && waves_per_strip * g.strips >= 4096) g.W = cw;
     return g;
 }
 

@@ -58,9 +58,164 @@ __global__ void __launch_bounds__(256) stream_blocks_kernel(const v4f* __restric
     }
 }
 
+// The marching access pattern of the fused 2-D kernel without its arithmetic: a workgroup of 128 threads owns a strip of R node rows of
+// one 512-wide sample and walks it row by row -- per row one 16-byte load per thread and input array (+ optionally the dword of the node
+// shared with the right neighbour), a dependent (load -> use -> store) step, one 16-byte store -- with D rows requested ahead of the
+// row being consumed.  What rate does this structure reach for a given (R, D), i.e. waves per SIMD and rows in flight per wave?
+// SHARED: 0 no shared node, 1 a dword load per lane, 2 the neighbouring lane's first value (ds_bpermute) + a dword load by lane 63 only
+template <int D, int SHARED, bool NT_ST, bool NT_LD>
+__global__ void __launch_bounds__(128) march_probe_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                          float* __restrict__ out, int ny, int R, int halo) {
+    const int tid = threadIdx.x, strip = blockIdx.y, smp = blockIdx.z;
+    const long long base = (long long)smp * ny * 512;
+    const float *pa = a + base, *pb = b + base, *pc = c + base;
+    float* po = out + base;
+    const int y0 = strip * R, y1 = min(y0 + R, ny);
+    const int r0 = max(y0 - halo, 0), r1 = min(y1 + halo, ny);          // rows read: the strip's own + `halo` rows on either side
+    const unsigned x0 = 4u * tid, xs = min(4u * tid + 4u, 511u);
+    v4f ra[D], rb[D], rc[D];
+    float sa[D], sb[D], sc[D];
+    auto issue = [&](int slot, int y) {
+        const unsigned off = (unsigned)min(y, r1 - 1) * 512u;      // rows past the strip's last one re-read that row (cache hits), as the real kernel does
+        if constexpr (NT_LD) {
+            ra[slot] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pa + off + x0));
+            rb[slot] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pb + off + x0));
+            rc[slot] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pc + off + x0));
+        } else {
+            ra[slot] = *reinterpret_cast<const v4f*>(pa + off + x0);
+            rb[slot] = *reinterpret_cast<const v4f*>(pb + off + x0);
+            rc[slot] = *reinterpret_cast<const v4f*>(pc + off + x0);
+        }
+        if constexpr (SHARED == 1) { sa[slot] = pa[off + xs]; sb[slot] = pb[off + xs]; sc[slot] = pc[off + xs]; }
+        if constexpr (SHARED == 2) {
+            sa[slot] = sb[slot] = sc[slot] = 0.f;
+            if ((tid & 63) == 63) { sa[slot] = pa[off + xs]; sb[slot] = pb[off + xs]; sc[slot] = pc[off + xs]; }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, r0 + d);
+    v4f carry = {0.f, 0.f, 0.f, 0.f};
+    for (int y = r0; y < r1; y += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (y + d < r1) {
+                v4f r = ra[d] * rb[d] + rc[d] + carry;
+                if constexpr (SHARED == 1) r.w += sa[d] * sb[d] + sc[d];
+                if constexpr (SHARED == 2) {
+                    const bool last = (tid & 63) == 63;
+                    const float na = __shfl_down(ra[d].x, 1, 64), nb = __shfl_down(rb[d].x, 1, 64), nc = __shfl_down(rc[d].x, 1, 64);
+                    r.w += (last ? sa[d] : na) * (last ? sb[d] : nb) + (last ? sc[d] : nc);
+                }
+                carry = r * 0.5f;
+                issue(d, y + d + D);
+                if (y + d >= y0 && y + d < y1) {
+                    if constexpr (NT_ST) __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(po + (unsigned)(y + d) * 512u + x0));
+                    else *reinterpret_cast<v4f*>(po + (unsigned)(y + d) * 512u + x0) = r;
+                }
+            }
+        }
+    }
+}
+
+// Paired form: rows (2k, 2k + 1) -- one 4 KB block of a 512-wide fp32 array -- are requested TOGETHER and consumed together (two rows per
+// trip), optionally with the next pair already in flight (AHEAD = 2 pairs).
+template <int AHEAD, bool NT_ST, bool NT_LD>
+__global__ void __launch_bounds__(128) march_pairs_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                          float* __restrict__ out, int ny, int R) {
+    const int tid = threadIdx.x, strip = blockIdx.y, smp = blockIdx.z;
+    const long long base = (long long)smp * ny * 512;
+    const float *pa = a + base, *pb = b + base, *pc = c + base;
+    float* po = out + base;
+    const int y0 = strip * R, y1 = min(y0 + R, ny);
+    const unsigned x0 = 4u * tid;
+    v4f ra[AHEAD][2], rb[AHEAD][2], rc[AHEAD][2];
+    auto ld = [&](const float* p, unsigned off) {
+        if constexpr (NT_LD) return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p + off + x0));
+        else return *reinterpret_cast<const v4f*>(p + off + x0);
+    };
+    auto issue = [&](int slot, int y) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned off = (unsigned)min(y + k, y1 - 1) * 512u;
+            ra[slot][k] = ld(pa, off); rb[slot][k] = ld(pb, off); rc[slot][k] = ld(pc, off);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) issue(s, y0 + 2 * s);
+    v4f carry = {0.f, 0.f, 0.f, 0.f};
+    for (int y = y0; y < y1; y += 2 * AHEAD) {
+#pragma unroll
+        for (int s = 0; s < AHEAD; ++s) {
+            const int yy = y + 2 * s;
+            if (yy < y1) {
+                v4f r0 = ra[s][0] * rb[s][0] + rc[s][0] + carry;
+                v4f r1 = ra[s][1] * rb[s][1] + rc[s][1] + r0 * 0.5f;
+                carry = r1 * 0.5f;
+                issue(s, yy + 2 * AHEAD);
+                if constexpr (NT_ST) {
+                    __builtin_nontemporal_store(r0, reinterpret_cast<v4f*>(po + (unsigned)yy * 512u + x0));
+                    if (yy + 1 < y1) __builtin_nontemporal_store(r1, reinterpret_cast<v4f*>(po + (unsigned)(yy + 1) * 512u + x0));
+                } else {
+                    *reinterpret_cast<v4f*>(po + (unsigned)yy * 512u + x0) = r0;
+                    if (yy + 1 < y1) *reinterpret_cast<v4f*>(po + (unsigned)(yy + 1) * 512u + x0) = r1;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace dn
 
 using namespace dn;
+
+// rows_ahead: 1..4 rows requested ahead per wave; flags: bit 0 read one halo row on either side of a strip, bit 1 also the dword of the
+// shared node, bit 2 non-temporal stores, bit 3 non-temporal vector loads, bit 4 shared node from the neighbouring lane (+ a load by lane 63).
+// Arrays (B, ny, 512) fp32.
+extern "C" int dn_probe_march(const float* a, const float* b, const float* c, float* out, int32_t B, int32_t ny, int32_t R, int32_t rows_ahead,
+                              int32_t flags, void* stream) {
+    if (!a || !b || !c || !out || B < 1 || ny < 2 || R < 1 || rows_ahead < 1 || rows_ahead > 4) return DN_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(1, (ny + R - 1) / R, B), block(128);
+    const int halo = flags & 1;
+    if (flags & 32) {            // paired rows (no halo, no shared node): rows_ahead = pairs in flight (1 or 2)
+        if (R & 1) return DN_E_BADARG;
+#define DN_PAIRS(A)                                                                                                              \
+    do {                                                                                                                         \
+        if ((flags & 4) && (flags & 8)) hipLaunchKernelGGL((march_pairs_kernel<A, true, true>), grid, block, 0, s, a, b, c, out, ny, R);   \
+        else if (flags & 4) hipLaunchKernelGGL((march_pairs_kernel<A, true, false>), grid, block, 0, s, a, b, c, out, ny, R);              \
+        else if (flags & 8) hipLaunchKernelGGL((march_pairs_kernel<A, false, true>), grid, block, 0, s, a, b, c, out, ny, R);              \
+        else hipLaunchKernelGGL((march_pairs_kernel<A, false, false>), grid, block, 0, s, a, b, c, out, ny, R);                            \
+    } while (0)
+        if (rows_ahead >= 2) DN_PAIRS(2);
+        else DN_PAIRS(1);
+#undef DN_PAIRS
+        DN_LAUNCH_CHECK();
+        return 0;
+    }
+#define DN_MARCH2(D, SH)                                                                                                             \
+    do {                                                                                                                             \
+        if ((flags & 4) && (flags & 8)) hipLaunchKernelGGL((march_probe_kernel<D, SH, true, true>), grid, block, 0, s, a, b, c, out, ny, R, halo);   \
+        else if (flags & 4) hipLaunchKernelGGL((march_probe_kernel<D, SH, true, false>), grid, block, 0, s, a, b, c, out, ny, R, halo);              \
+        else if (flags & 8) hipLaunchKernelGGL((march_probe_kernel<D, SH, false, true>), grid, block, 0, s, a, b, c, out, ny, R, halo);              \
+        else hipLaunchKernelGGL((march_probe_kernel<D, SH, false, false>), grid, block, 0, s, a, b, c, out, ny, R, halo);                            \
+    } while (0)
+#define DN_MARCH(D)                                                          \
+    do {                                                                     \
+        if (flags & 16) DN_MARCH2(D, 2);                                     \
+        else if (flags & 2) DN_MARCH2(D, 1);                                 \
+        else DN_MARCH2(D, 0);                                                \
+    } while (0)
+    switch (rows_ahead) {
+        case 1: DN_MARCH(1); break;
+        case 2: DN_MARCH(2); break;
+        case 3: DN_MARCH(3); break;
+        default: DN_MARCH(4); break;
+    }
+#undef DN_MARCH2
+#undef DN_MARCH
+    DN_LAUNCH_CHECK();
+    return 0;
+}
 
 // mode: bit 0 = non-temporal stores, bit 1 = non-temporal loads, bits 2.. = form (0: one vector per thread; 1: blocks of 4 vectors per
 // thread, one block per workgroup; 2: the same, 2048 persistent workgroups striding over the blocks)

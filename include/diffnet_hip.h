@@ -141,6 +141,13 @@ const char *dn_build_info(void);
  * roofline.stream_ceiling.  mode: bit 0 non-temporal stores, bit 1 non-temporal loads, bits 2.. the form (0 one 16-byte vector per
  * thread, 1 blocks of four vectors per thread, 2 the same with 2048 persistent workgroups). */
 int dn_probe_stream(const float *a, const float *b, const float *c, float *out, int64_t n, int32_t mode, void *stream);
+/* Second probe: the MARCHING access pattern of the fused 2-D kernel without its arithmetic (arrays (B, ny, 512) fp32): a 128-thread
+ * workgroup walks a strip of R node rows row by row with `rows_ahead` (1..4) rows requested ahead of the one it consumes.  flags: bit 0
+ * read one halo row on either side of the strip, bit 1 also load the dword of the node shared with the right neighbour, bit 2
+ * non-temporal stores, bit 3 non-temporal vector loads, bit 4 shared node taken from the neighbouring lane (one lane per wave loads it).
+ * tools/march_probe.py: which (R, rows_ahead) the memory system rewards. */
+int dn_probe_march(const float *a, const float *b, const float *c, float *out, int32_t B, int32_t ny, int32_t R, int32_t rows_ahead,
+                   int32_t flags, void *stream);
 
 int64_t dn_poisson_workspace_bytes(const dn_mesh *mesh);
 int dn_poisson_apply(const dn_mesh *mesh, const dn_poisson_args *args, void *stream);
