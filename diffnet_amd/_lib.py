@@ -49,7 +49,7 @@ class DnFsdtArgs(C.Structure):
                 ("D11", C.c_float), ("D12", C.c_float), ("D22", C.c_float), ("D66", C.c_float), ("A44", C.c_float),
                 ("A55", C.c_float), ("q", C.c_float), ("wscale", C.c_float),
                 ("out", C.c_void_p * 3), ("sumsq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("in_scale", C.c_void_p)]
+                ("in_scale", C.c_void_p), ("norms", C.c_void_p), ("in_num", C.c_void_p), ("in_den", C.c_void_p)]
 
 
 I32x3 = C.c_int32 * 3
@@ -62,6 +62,7 @@ SYMBOLS = {
     "dn_config_get": (C.c_char_p, [C.c_char_p]),
     "dn_probe_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "dn_probe_march": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dn_probe_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dn_poisson_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
     "dn_poisson_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnPoissonArgs), C.c_void_p]),
     "dn_gauss_pt_eval_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,

@@ -18,11 +18,30 @@
 // and marches over element rows; node values and partially assembled outputs of the current layer stay in
 // registers; the contribution to the node column shared with the right neighbour goes through a double-buffered LDS
 // slot; strip / chunk seams are closed by recomputing one layer (no atomics, bitwise repeatable).
+#include <algorithm>
 #include <cstdlib>
 
 #include "poisson_common.h"
 
 namespace dn {
+
+// LDS words of the chained strips' hand-overs as inline asm (a `volatile` LDS access makes the compiler drain every outstanding load: see
+// poisson2d_q1_cf.hip)
+__device__ __forceinline__ unsigned fs_lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void fs_lds_st(unsigned a, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void fs_lds_st(unsigned a, unsigned v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ float fs_lds_ld(unsigned a) {
+    float d;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(a) : "memory");
+    return d;
+}
+__device__ __forceinline__ unsigned fs_lds_ld_u(unsigned a) {
+    unsigned d;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(a) : "memory");
+    return d;
+}
+constexpr unsigned FS_SPIN_MAX = 1u << 20;     // bound of every LDS flag poll: a protocol error must end in wrong numbers, not in a hung GPU
+constexpr int FS_CH_MAXW = 12;                 // sub-strips (waves) per chained workgroup: 12 waves = 3 per SIMD at <= 168 VGPRs
 
 struct FsdtParams {
     float b[4][4], dx[4][4], dy[4][4];     // 1-D tables at the Gauss points (derivatives scaled by 2/h)
@@ -30,6 +49,9 @@ struct FsdtParams {
     float D11, D12, D22, D66, A44, A55, q;
     const float* fld[3];                   // w, phi_x, phi_y
     const float* in_scale;                 // optional 3 device floats: field k is scaled as it is loaded
+    const float* in_num;                   // optional 3 + 3 device floats: field k is scaled by in_num[k] / in_den[k] (0 where in_den[k] <= 0)
+    const float* in_den;
+    float* norms;                          // optional 3 device floats: sqrt of the three sums of squares, written by the last workgroup
     const void* mask;
     int mask_is_u8, mask_batched;
     const float* bcf[3];
@@ -40,6 +62,7 @@ struct FsdtParams {
     unsigned* counter;
     double* sumsq;                         // 3 doubles
     int nx, ny, nelx, nely, rows_per_strip, want_sums;
+    int nstrips;                           // strips per sample (chained launches: the last workgroup of a column may hold fewer sub-strips)
 };
 
 // Deterministic in-kernel final reduction of three scalars (same protocol as finish_sums in poisson_common.h).
@@ -93,7 +116,10 @@ __device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const double e = block_sum(e3[k], red, tid, nthreads);
-            if (tid == 0) p.sumsq[k] = e;
+            if (tid == 0) {
+                if (p.sumsq) p.sumsq[k] = e;
+                if (p.norms) p.norms[k] = (float)sqrt(e);
+            }
         }
         if (tid == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -171,21 +197,32 @@ __device__ __forceinline__ void fsdt_elem(const FsdtParams& p, const float (&F)[
 // The P new node rows of layer k + 1 are requested before the arithmetic of layer k (software pipeline: `W`), and the
 // finished rows of layer k are stored after that request (a store issued first would be younger than the loads the next
 // consumer waits for; sitting in a divergent branch it would turn that wait into vmcnt(0)).
-template <int P, int NGP, int MK, bool BCF>
-__global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
+// CH (chained strips): the workgroup holds W = blockDim.x / 64 sub-strips of ONE wave each (64 element columns), neighbouring strips of
+// one column of chunks.  A sub-strip does not recompute the layer under its first node row: it publishes that row (values after the
+// Dirichlet substitution) in LDS for the last layer of the sub-strip below, which answers with that layer's contributions to the row.
+// At one sample the element rows have to be cut into strips of 2 to fill the chip -- un-chained that is one recomputed layer per two
+// (+50 % arithmetic in a kernel bound by its 918 instructions per element); chained it is one per workgroup.  Inside a one-wave
+// sub-strip the hand-over to the right neighbour is a lane shuffle: no LDS slot, no barrier.
+template <int P, int NGP, int MK, bool BCF, bool CH>
+__global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(const FsdtParams p) {
     constexpr int NB = P + 1;
     constexpr int NW = P;                  // nodes owned per thread per node row
-    const int T = blockDim.x;
-    const int tid = threadIdx.x;
-    const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+    const int T = CH ? 64 : (int)blockDim.x;
+    const int sub = CH ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
+    const int nsub = CH ? (int)blockDim.x >> 6 : 1;
+    const int tid = CH ? (int)threadIdx.x & 63 : (int)threadIdx.x;
+    const int chunk = blockIdx.x, strip = (int)blockIdx.y * nsub + sub, b = blockIdx.z;
+    const bool active = !CH || strip < p.nstrips;
+    const bool chain_dn = CH && sub > 0, chain_up = CH && sub + 1 < nsub && strip + 1 < p.nstrips;
     const int q = chunk * (T - 1) + tid;   // chunks overlap by one thread column
     const int ex0 = q, x0 = ex0 * P;
     const bool col_owner = !(chunk > 0 && tid == 0);
     const int64_t nps = (int64_t)p.nx * p.ny;
     const int R = p.rows_per_strip;
     const int ey_own = strip * R;
-    const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;
+    const int ey_begin = (ey_own > 0 && !chain_dn) ? ey_own - 1 : ey_own;     // chain_dn: no seam layer
     const int ey_end = min(ey_own + R, p.nely);
+    const int ymax = chain_up ? ey_end * P - 1 : p.ny - 1;     // chain_up: the top node row comes from the sub-strip above, not from HBM
     const float okf = (ex0 < p.nelx) ? 1.f : 0.f;      // threads right of the mesh compute on clamped data, scaled by 0
 
     const float* fb[3];
@@ -205,10 +242,35 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
 
     float fscale[3] = {1.f, 1.f, 1.f};
     if (p.in_scale) { fscale[0] = p.in_scale[0]; fscale[1] = p.in_scale[1]; fscale[2] = p.in_scale[2]; }
+    if (p.in_num) {               // cotangent of the norms over the norms (the VJP of ||R_k||), torch's convention at ||R_k|| == 0: zero
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float den = p.in_den[k];
+            fscale[k] = den > 0.f ? p.in_num[k] / den : 0.f;
+        }
+    }
 
-    __shared__ float xch[2][3][P][256];
-    __shared__ double red[8];
+    __shared__ float xch[CH ? 1 : 2][3][P][CH ? 1 : 256];
+    __shared__ double red[16];
     __shared__ int last_flag;
+    // CH: per seam (sub-strip s | s + 1) SEAM_WORDS x 64 floats + 2 flags, in dynamic LDS: [0 .. 3 NB) the upper strip's first node row,
+    // [3 NB] its Dirichlet bits, [3 NB + 1 .. 6 NB + 1) the lower strip's contributions to that row, [6 NB + 1 .. 9 NB + 1) the upper
+    // strip's own (parked) contributions
+    constexpr int SEAM_WORDS = 9 * NB + 1;
+    extern __shared__ float fs_dyn[];
+    float* seam_base = fs_dyn;                                             // [nsub - 1][SEAM_WORDS][64]
+    unsigned* flag_base = reinterpret_cast<unsigned*>(fs_dyn + (size_t)(nsub > 1 ? nsub - 1 : 0) * SEAM_WORDS * 64);       // [nsub - 1][2]
+    if constexpr (CH) {
+        if ((int)threadIdx.x < 2 * (nsub - 1)) flag_base[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    auto spin_until = [&](const unsigned* flag) {
+        const unsigned fa = fs_lds_addr(flag);
+        for (unsigned n = 0; n < FS_SPIN_MAX; ++n) {
+            if (__builtin_amdgcn_readfirstlane((int)fs_lds_ld_u(fa)) != 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
 
     float cu[3][NB][NW + 1], acc[3][NB][NW + 1];
     unsigned fixed[NB];
@@ -226,7 +288,7 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
         uint8_t mb[NW + 1];
     };
     auto row_issue = [&](int yr, RawRow& w) {
-        const unsigned rowoff = (unsigned)min(yr, p.ny - 1) * (unsigned)p.nx;
+        const unsigned rowoff = (unsigned)min(yr, ymax) * (unsigned)p.nx;
 #pragma unroll
         for (int k = 0; k < 3; ++k) load_seg<NW, false>(fb[k], rowoff, x0, p.nx, w.v[k]);
         if constexpr (MK == 1) load_seg<NW, false>(m8, rowoff, x0, p.nx, w.mb);
@@ -286,13 +348,25 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
     // Emit node row yr from acc[.][r] (+ the left neighbour's hand-over for n == 0); Dirichlet rows of the residual carry
     // the boundary values (e1_plate_bending_fsdt.py:222-228), which cu holds at those nodes.
     auto emit_row = [&](int r, int slot, int yr, bool owned_row) {
+        float lefts[3];
+        if constexpr (CH) {               // one wave per sub-strip: the neighbour is the lane to the left
 #pragma unroll
-        for (int k = 0; k < 3; ++k) xch[par][k][r % P][tid] = acc[k][r][NW];
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier (loads stay in flight)
+            for (int k = 0; k < 3; ++k) {
+                float t = __shfl_up(acc[k][r][NW], 1, 64);
+                asm volatile("" : "+v"(t));          // keep the exchange out of the select below (every lane must take part)
+                lefts[k] = tid > 0 ? t : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xch[par][k][r % P][tid] = acc[k][r][NW];
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier (loads stay in flight)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lefts[k] = (tid > 0) ? xch[par][k][r % P][tid - 1] : 0.f;
+        }
         const bool st = owned_row && col_owner;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float left = (tid > 0) ? xch[par][k][r % P][tid - 1] : 0.f;
+            const float left = lefts[k];
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
                 float v = acc[k][r][n] + (n == 0 ? left : 0.f);
@@ -305,11 +379,25 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
         pend_st[slot] = st;
     };
 
+    if (active) {                     // (a chained workgroup's unused sub-strips only join the final reduction)
+    float* seam_dn = seam_base + (size_t)(sub > 0 ? sub - 1 : 0) * SEAM_WORDS * 64;       // seam with the sub-strip below / above
+    float* seam_up = seam_base + (size_t)sub * SEAM_WORDS * 64;
     RawRow W[P];
     {
         RawRow w0;
         row_issue(ey_begin * P, w0);
         row_consume(w0, 0);
+    }
+    if constexpr (CH) {
+        if (chain_dn) {               // publish the strip's first node row for the last layer of the strip below
+            const unsigned s0 = fs_lds_addr(seam_dn + tid);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) fs_lds_st(s0 + (k * NB + n) * 256u, cu[k][0][n]);
+            fs_lds_st(s0 + (3 * NB) * 256u, fixed[0]);
+            if (tid == 0) fs_lds_st(fs_lds_addr(flag_base + 2 * (sub - 1)), 1u);       // LDS executes a wave's accesses in order
+        }
     }
 #pragma unroll
     for (int r = 1; r <= P; ++r) row_issue(ey_begin * P + r, W[r - 1]);
@@ -319,6 +407,17 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
 #pragma unroll
         for (int r = 1; r <= P; ++r) row_issue((ey + 1) * P + r, W[r - 1]);      // rows beyond the mesh re-read the last one (unused)
         flush_rows();
+        if constexpr (CH) {
+            if (chain_up && ey == ey_end - 1) {       // the strip's last layer: its top node row is the first row of the strip above
+                spin_until(flag_base + 2 * sub);
+                const unsigned s0 = fs_lds_addr(seam_up + tid);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int n = 0; n <= NW; ++n) cu[k][P][n] = fs_lds_ld(s0 + (k * NB + n) * 256u);
+                fixed[P] = fs_lds_ld_u(s0 + (3 * NB) * 256u);
+            }
+        }
         const bool own_layer = ey >= ey_own;
         {
             static_assert(NW + 1 == NB, "one element per thread: the row state is the element's node block");
@@ -337,8 +436,22 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
 #pragma unroll
                     for (int ib = 0; ib < NB; ++ib) acc[k][jb][ib] = fmaf(okf, g[k][jb][ib], acc[k][jb][ib]);
         }
+        if (CH && chain_dn && ey == ey_own) {
+            // the strip's first node row still lacks the contributions of the layer below it (the strip below computes them at its very
+            // end): park this half, the node values and the Dirichlet bits in LDS and finish the row after the march
+            const unsigned s0 = fs_lds_addr(seam_dn + tid);
 #pragma unroll
-        for (int r = 0; r < P; ++r) emit_row(r, r, ey * P + r, own_layer);
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) {
+                    fs_lds_st(s0 + (6 * NB + 1 + k * NB + n) * 256u, acc[k][0][n]);      // (node values and bits: as published at the start)
+                }
+#pragma unroll
+            for (int r = 1; r < P; ++r) emit_row(r, r, ey * P + r, own_layer);
+        } else {
+#pragma unroll
+            for (int r = 0; r < P; ++r) emit_row(r, r, ey * P + r, own_layer);
+        }
         par ^= 1;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -352,26 +465,63 @@ __global__ void __launch_bounds__(256) fsdt2d_kernel(const FsdtParams p) {
         fixed[0] = fixed[P];
     }
     flush_rows();
+    if constexpr (CH) {
+        if (chain_up) {               // this strip's contributions to the first row of the strip above
+            const unsigned s0 = fs_lds_addr(seam_up + tid);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) fs_lds_st(s0 + (3 * NB + 1 + k * NB + n) * 256u, acc[k][0][n]);
+            if (tid == 0) fs_lds_st(fs_lds_addr(flag_base + 2 * sub + 1), 1u);
+        }
+    }
     if (ey_end == p.nely) {
         emit_row(0, 0, p.ny - 1, true);
         flush_rows();
     }
+    if constexpr (CH) {
+        if (chain_dn) {               // finish the strip's first node row: parked half + the carry of the strip below
+            spin_until(flag_base + 2 * (sub - 1) + 1);
+            const unsigned s0 = fs_lds_addr(seam_dn + tid);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) {
+                    acc[k][0][n] = fs_lds_ld(s0 + (6 * NB + 1 + k * NB + n) * 256u) + fs_lds_ld(s0 + (3 * NB + 1 + k * NB + n) * 256u);
+                    cu[k][0][n] = fs_lds_ld(s0 + (k * NB + n) * 256u);
+                }
+            fixed[0] = fs_lds_ld_u(s0 + (3 * NB) * 256u);
+            emit_row(0, 0, ey_own * P, true);
+            flush_rows();
+        }
+    }
+    }                                 // active
 
-    if (p.want_sums) finish_sums3(p, sq, tid, T, red, &last_flag);
+    if (p.want_sums) finish_sums3(p, sq, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
 }
 
 static inline int fs_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static constexpr int64_t FSDT_WS_HEADER = 64 * (1 + 64);
 
-struct FsdtGeom { int T, chunks, R, strips; };
+struct FsdtGeom { int T, chunks, R, strips, W; };     // W > 1: chained launch, W one-wave sub-strips per workgroup (T == 64)
 
-static FsdtGeom fsdt_plan(const dn_mesh* m) {
+// Cost model of a launch plan, in wave-layers on the busiest SIMD (the kernel is bound by its arithmetic: ~918 VALU instructions per
+// element layer at Q2 / 3 x 3; a SIMD issues them at ~2.4 cycles each once two waves share it, ~4.7 with a single wave): workgroups
+// are dealt over 256 CUs, a CU holds 12 waves (<= 168 VGPRs), its busiest SIMD a quarter of the CU's wave-layers.
+static double fsdt_cost(long long nwg, int wg_waves, double wg_wave_layers) {
+    const long long per_cu = (nwg + 255) / 256;
+    const long long resident = std::min<long long>(std::max(1, 12 / wg_waves), per_cu);
+    const double waves_per_simd = (double)(resident * wg_waves) / 4.0;
+    return (double)per_cu * wg_wave_layers / 4.0 * (waves_per_simd < 2.0 ? 2.0 / std::max(1.0, waves_per_simd) : 1.0);
+}
+
+static FsdtGeom fsdt_plan(const dn_mesh* m, bool allow_chain = true) {
     FsdtGeom g;
     const int P = m->degree;
     const int Q = (m->nx - 1) / P + 1;          // logical thread columns (one per element + the closing column)
     const int nely = (m->ny - 1) / P;
     double best = -1.0;
-    g.T = 64; g.chunks = 1;
+    g.T = 64; g.chunks = 1; g.W = 1;
     for (int T = 64; T <= 256; T += 64) {
         const int chunks = Q <= T ? 1 : fs_ceil_div(Q - 1, T - 1);
         const double util = (double)Q / ((double)chunks * T);
@@ -392,9 +542,27 @@ static FsdtGeom fsdt_plan(const dn_mesh* m) {
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = fs_ceil_div(nely, g.R);
-    const char* e = config(CFG_PLAN_FSDT);      // "T,R" (tuning experiments only)
-    int T, RR;
-    if (e && sscanf(e, "%d,%d", &T, &RR) == 2 && T >= 64 && T <= 256 && RR >= 1) {
+    // Chained alternative (fsdt2d_kernel<.., CH>): W one-wave sub-strips of R rows per workgroup recompute ONE seam layer per workgroup
+    // instead of one per strip.  Taken when the model says the busiest SIMD gets at least 5 % less to do.
+    if (allow_chain && nely >= 4) {
+        const int chunks64 = Q <= 64 ? 1 : fs_ceil_div(Q - 1, 63);
+        const double cost1 = fsdt_cost((long long)g.chunks * g.strips * m->batch, g.T / 64, (double)(g.T / 64) * (g.R + 1));
+        double bestc = cost1 * 0.95;
+        for (int RR = 1; RR <= 8; ++RR) {
+            for (int W = 2; W <= FS_CH_MAXW; ++W) {
+                if (RR * W > nely && !(RR == 1 && W == 2)) continue;
+                const int strips = fs_ceil_div(nely, RR);
+                const long long nwg = (long long)chunks64 * fs_ceil_div(strips, W) * m->batch;
+                const double c = fsdt_cost(nwg, W, (double)W * RR + 1.0) * (1.0 + 0.002 * W);       // ties: shorter chains
+                if (c < bestc) { bestc = c; g.T = 64; g.chunks = chunks64; g.R = RR; g.strips = strips; g.W = W; }
+            }
+        }
+    }
+    const char* e = config(CFG_PLAN_FSDT);      // "T,R[,W]" (tuning experiments only; W >= 2: chained, T is then 64)
+    int T, RR, W = 1;
+    if (e && sscanf(e, "%d,%d,%d", &T, &RR, &W) >= 2 && T >= 64 && T <= 256 && RR >= 1) {
+        g.W = (W >= 2 && W <= FS_CH_MAXW && allow_chain) ? W : 1;
+        if (g.W > 1) T = 64;
         g.T = T; g.R = RR > nely ? nely : RR;
         g.chunks = Q <= T ? 1 : fs_ceil_div(Q - 1, T - 1);
         g.strips = fs_ceil_div(nely, g.R);
@@ -413,15 +581,25 @@ static int fsdt_validate(const dn_mesh* m) {
 
 template <int P, int NGP>
 static int fsdt_launch_mk(const FsdtParams& pp, const FsdtGeom& g, int batch, hipStream_t s) {
-    dim3 grid(g.chunks, g.strips, batch), block(g.T);
     const int mk = !pp.mask ? 0 : (pp.mask_is_u8 ? 1 : 2);
     const bool bcf = mk != 0 && (pp.bcf[0] || pp.bcf[1] || pp.bcf[2]);
+    if (g.W > 1) {                    // chained sub-strips: one wave each, seams through dynamic LDS
+        if (bcf || g.T != 64 || g.W > FS_CH_MAXW) return DN_E_BADARG;
+        dim3 grid(g.chunks, (g.strips + g.W - 1) / g.W, batch), block(64 * g.W);
+        const size_t lds = (size_t)(g.W - 1) * ((9 * (P + 1) + 1) * 64 * sizeof(float) + 2 * sizeof(unsigned));
+        switch (mk) {
+            case 0: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 0, false, true>), grid, block, lds, s, pp); return 0;
+            case 1: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, false, true>), grid, block, lds, s, pp); return 0;
+            default: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, false, true>), grid, block, lds, s, pp); return 0;
+        }
+    }
+    dim3 grid(g.chunks, g.strips, batch), block(g.T);
     switch (mk * 2 + (bcf ? 1 : 0)) {
-        case 0: case 1: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 0, false>), grid, block, 0, s, pp); return 0;
-        case 2: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, false>), grid, block, 0, s, pp); return 0;
-        case 3: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, true>), grid, block, 0, s, pp); return 0;
-        case 4: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, false>), grid, block, 0, s, pp); return 0;
-        default: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, true>), grid, block, 0, s, pp); return 0;
+        case 0: case 1: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 0, false, false>), grid, block, 0, s, pp); return 0;
+        case 2: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, false, false>), grid, block, 0, s, pp); return 0;
+        case 3: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, true, false>), grid, block, 0, s, pp); return 0;
+        case 4: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, false, false>), grid, block, 0, s, pp); return 0;
+        default: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, true, false>), grid, block, 0, s, pp); return 0;
     }
 }
 
@@ -441,18 +619,22 @@ using namespace dn;
 
 extern "C" int64_t dn_fsdt_workspace_bytes(const dn_mesh* m) {
     if (fsdt_validate(m) != 0) return DN_E_BADARG;
-    const FsdtGeom g = fsdt_plan(m);
-    return FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * g.chunks * g.strips * m->batch;
+    const FsdtGeom g = fsdt_plan(m, false), gc = fsdt_plan(m, true);         // either plan fits (un-chained has the most workgroups per strip)
+    const int64_t n1 = (int64_t)g.chunks * g.strips * m->batch, n2 = (int64_t)gc.chunks * gc.strips * m->batch;
+    return FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * std::max(n1, n2);
 }
 
 extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stream) {
     int rc = fsdt_validate(m);
     if (rc) return rc;
     if (!a || !a->w || !a->phi_x || !a->phi_y) return DN_E_BADARG;
-    if (!a->out[0] && !a->out[1] && !a->out[2] && !a->sumsq) return DN_E_BADARG;
-    const FsdtGeom g = fsdt_plan(m);
-    const int64_t nwg = (int64_t)g.chunks * g.strips * m->batch;
-    if (a->sumsq && (!a->workspace || a->workspace_bytes < FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
+    if (!a->out[0] && !a->out[1] && !a->out[2] && !a->sumsq && !a->norms) return DN_E_BADARG;
+    if ((a->in_num != nullptr) != (a->in_den != nullptr) || (a->in_num && a->in_scale)) return DN_E_BADARG;
+    const bool want_red = a->sumsq || a->norms;
+    const bool any_bcf = a->bc_mask && (a->bc_field[0] || a->bc_field[1] || a->bc_field[2]);
+    const FsdtGeom g = fsdt_plan(m, !any_bcf);
+    const int64_t nwg = (int64_t)g.chunks * ((g.strips + g.W - 1) / g.W) * m->batch;
+    if (want_red && (!a->workspace || a->workspace_bytes < FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
 
     FsdtParams pp;
     for (int i = 0; i < 4; ++i)
@@ -465,6 +647,7 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     pp.D11 = a->D11; pp.D12 = a->D12; pp.D22 = a->D22; pp.D66 = a->D66; pp.A44 = a->A44; pp.A55 = a->A55; pp.q = a->q;
     pp.fld[0] = a->w; pp.fld[1] = a->phi_x; pp.fld[2] = a->phi_y;
     pp.in_scale = a->in_scale;
+    pp.in_num = a->in_num; pp.in_den = a->in_den; pp.norms = a->norms;
     pp.mask = a->bc_mask; pp.mask_is_u8 = a->mask_is_u8; pp.mask_batched = a->mask_batched;
     for (int k = 0; k < 3; ++k) {
         pp.bcf[k] = a->bc_field[k]; pp.bcf_batched[k] = a->bc_field_batched[k]; pp.bcv[k] = a->bc_value[k];
@@ -476,7 +659,8 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     pp.nx = m->nx; pp.ny = m->ny;
     pp.nelx = (m->nx - 1) / m->degree; pp.nely = (m->ny - 1) / m->degree;
     pp.rows_per_strip = g.R;
-    pp.want_sums = a->sumsq ? 1 : 0;
+    pp.nstrips = g.strips;
+    pp.want_sums = want_red ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (m->degree) {
         case 1: rc = fsdt_launch<1>(pp, g, m->ngp, m->batch, s); break;

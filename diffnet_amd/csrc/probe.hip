@@ -164,9 +164,93 @@ __global__ void __launch_bounds__(128) march_pairs_kernel(const float* __restric
     }
 }
 
+// Tile form: a workgroup of NT threads owns TR node rows of one 512-wide sample, requests ALL the rows it needs -- its own and one halo
+// row on either side, three arrays -- at once (every load in flight before the first use), parks them in LDS, then walks the rows out of
+// LDS (a dependent chain on LDS latency, not on HBM latency) and stores its TR rows.  Many short-lived workgroups, like a flat stream.
+template <int NT, int TR, bool NT_LD, bool XCD>
+__global__ void __launch_bounds__(NT) tile_probe_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                        float* __restrict__ out, int ny, int tiles) {
+    constexpr int ROWS = TR + 2;
+    constexpr int V = ROWS * 128 / NT + ((ROWS * 128) % NT ? 1 : 0);       // 16-byte vectors per thread and array
+    extern __shared__ v4f lds[];                                           // [3][ROWS][128]
+    unsigned lid = blockIdx.x;
+    if constexpr (XCD) {        // consecutive tiles (which share halo rows) on the same XCD
+        const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
+        lid = xcd * base + min(xcd, rem) + idx;
+    }
+    const int tile = (int)(lid % (unsigned)tiles), smp = (int)(lid / (unsigned)tiles);
+    const long long sbase = (long long)smp * ny * 512;
+    const float *pa = a + sbase, *pb = b + sbase, *pc = c + sbase;
+    float* po = out + sbase;
+    const int y0 = tile * TR;
+    const int tid = threadIdx.x;
+    v4f ra[V], rb[V], rc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i = tid + k * NT, row = min(i >> 7, ROWS - 1), col = i & 127;
+        const unsigned off = (unsigned)min(max(y0 - 1 + row, 0), ny - 1) * 512u + 4u * col;
+        if constexpr (NT_LD) {
+            ra[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pa + off));
+            rb[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pb + off));
+            rc[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pc + off));
+        } else {
+            ra[k] = *reinterpret_cast<const v4f*>(pa + off);
+            rb[k] = *reinterpret_cast<const v4f*>(pb + off);
+            rc[k] = *reinterpret_cast<const v4f*>(pc + off);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i = tid + k * NT;
+        if (i < ROWS * 128) { lds[i] = ra[k]; lds[ROWS * 128 + i] = rb[k]; lds[2 * ROWS * 128 + i] = rc[k]; }
+    }
+    __syncthreads();
+    // walk: NT / 128 row groups, each thread a 4-node column segment; TR rows are split among the row groups
+    const int col = tid & 127, grp = tid >> 7;
+    constexpr int G = NT / 128;
+    v4f carry = {0.f, 0.f, 0.f, 0.f};
+    for (int r = grp; r < TR; r += G) {
+        v4f acc = carry;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {       // the row and its two neighbours (what an element layer needs)
+            const int i = (r + d) * 128 + col;
+            acc += lds[i] * lds[ROWS * 128 + i] + lds[2 * ROWS * 128 + i];
+        }
+        carry = acc * 0.25f;
+        if (y0 + r < ny) __builtin_nontemporal_store(acc, reinterpret_cast<v4f*>(po + (unsigned)(y0 + r) * 512u + 4u * col));
+    }
+}
+
 }  // namespace dn
 
 using namespace dn;
+
+// tile probe: threads 256 | 512, rows_per_tile 4 | 8 | 16, flags: bit 3 non-temporal loads, bit 6 XCD-aware tile order
+extern "C" int dn_probe_tile(const float* a, const float* b, const float* c, float* out, int32_t B, int32_t ny, int32_t rows_per_tile,
+                             int32_t threads, int32_t flags, void* stream) {
+    if (!a || !b || !c || !out || B < 1 || ny < 2) return DN_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int tiles = (ny + rows_per_tile - 1) / rows_per_tile;
+    const dim3 grid((unsigned)(tiles * B));
+    const size_t lds = (size_t)3 * (rows_per_tile + 2) * 128 * 16;
+    const bool nt = flags & 8, xcd = flags & 64;
+#define DN_TILE(NT, TR)                                                                                                                  \
+    do {                                                                                                                                 \
+        if (nt && xcd) hipLaunchKernelGGL((tile_probe_kernel<NT, TR, true, true>), grid, dim3(NT), lds, s, a, b, c, out, ny, tiles);      \
+        else if (nt) hipLaunchKernelGGL((tile_probe_kernel<NT, TR, true, false>), grid, dim3(NT), lds, s, a, b, c, out, ny, tiles);       \
+        else if (xcd) hipLaunchKernelGGL((tile_probe_kernel<NT, TR, false, true>), grid, dim3(NT), lds, s, a, b, c, out, ny, tiles);      \
+        else hipLaunchKernelGGL((tile_probe_kernel<NT, TR, false, false>), grid, dim3(NT), lds, s, a, b, c, out, ny, tiles);              \
+    } while (0)
+    if (threads == 256 && rows_per_tile == 4) DN_TILE(256, 4);
+    else if (threads == 256 && rows_per_tile == 8) DN_TILE(256, 8);
+    else if (threads == 512 && rows_per_tile == 8) DN_TILE(512, 8);
+    else if (threads == 512 && rows_per_tile == 16) DN_TILE(512, 16);
+    else if (threads == 256 && rows_per_tile == 16) DN_TILE(256, 16);
+    else return DN_E_UNSUPPORTED;
+#undef DN_TILE
+    DN_LAUNCH_CHECK();
+    return 0;
+}
 
 // rows_ahead: 1..4 rows requested ahead per wave; flags: bit 0 read one halo row on either side of a strip, bit 1 also the dword of the
 // shared node, bit 2 non-temporal stores, bit 3 non-temporal vector loads, bit 4 shared node from the neighbouring lane (+ a load by lane 63).

@@ -93,8 +93,8 @@ class _FsdtLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, phi_x, phi_y, fem, bc, bc_values, consts, q, wscale):
-        outs, sums = ops.fsdt_apply(fem.geom, w, phi_x, phi_y, bc, bc_values, q=q, wscale=wscale, want_sums=True, **consts)
-        norms = sums.sqrt().float()
+        # the launch writes the three norms itself (sqrt of its in-kernel fixed-order fp64 sums): no torch op behind the kernel
+        outs, _, norms = ops.fsdt_apply(fem.geom, w, phi_x, phi_y, bc, bc_values, q=q, wscale=wscale, want_sums=False, want_norms=True, **consts)
         ctx.save_for_backward(*outs, norms)
         ctx.fem, ctx.bc, ctx.consts, ctx.wscale = fem, bc, consts, wscale
         return norms
@@ -105,9 +105,9 @@ class _FsdtLoss(torch.autograd.Function):
         *Rs, norms = ctx.saved_tensors
         # d||R_k||/dR_k = R_k / ||R_k||, with torch's norm_backward convention at ||R_k|| == 0 (zero subgradient): the
         # reference script starts from all-zero fields, where R2 = R3 = 0 exactly (e1_plate_bending_fsdt.py:341-349)
-        scale = torch.where(norms > 0, gnorms / norms, torch.zeros_like(norms)).contiguous()
-        outs, _ = ops.fsdt_apply(ctx.fem.geom, *Rs, ctx.bc, (0.0, 0.0, 0.0), q=0.0, wscale=ctx.wscale, want_sums=False, in_scale=scale,
-                                 **ctx.consts)
+        # (the kernel forms gnorms[k] / norms[k] itself, 0 where the norm is 0)
+        outs, _ = ops.fsdt_apply(ctx.fem.geom, *Rs, ctx.bc, (0.0, 0.0, 0.0), q=0.0, wscale=ctx.wscale, want_sums=False,
+                                 in_num=gnorms.contiguous(), in_den=norms, **ctx.consts)
         return outs[0], outs[1], outs[2], None, None, None, None, None, None
 
 

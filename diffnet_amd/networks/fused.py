@@ -13,6 +13,25 @@ from .. import _lib
 from ..ops import _p, _stream
 
 
+# Test switch: with HIP_LAYERS False every module below takes torch's own kernels (MIOpen on the GPU) -- the stock-module composition
+# the reference networks are made of.  `with stock_layers(): ...` is how the GPU tests run the SAME network object both ways.
+HIP_LAYERS = True
+
+
+def _hip(x):
+    return HIP_LAYERS and x.is_cuda and x.dtype == torch.float32
+
+
+class stock_layers:
+    def __enter__(self):
+        global HIP_LAYERS
+        self.prev, HIP_LAYERS = HIP_LAYERS, False
+
+    def __exit__(self, *exc):
+        global HIP_LAYERS
+        HIP_LAYERS = self.prev
+
+
 def _workspace(x, n_inst, S):
     """fp64 partial-sum scratch for the sliced path (few, large instances); None when the C side needs none."""
     nbytes = _lib.lib().dn_instnorm_workspace_bytes(n_inst, S)
@@ -68,7 +87,7 @@ class InstanceNormAct(nn.Module):
     def forward(self, x):
         if x[0, 0].numel() <= 1:
             raise ValueError(f"Expected more than 1 spatial element when training, got input size {x.size()}")   # torch's message
-        if x.is_cuda and x.dtype == torch.float32:
+        if _hip(x):
             return _InstNormAct.apply(x, self.eps, self.slope)
         y = F.instance_norm(x, eps=self.eps)
         return y if self.slope == 1.0 else F.leaky_relu(y, self.slope)
@@ -118,7 +137,7 @@ class _UpConvOut(torch.autograd.Function):
 def upsample_pad_conv4(x, weight, bias=None, sigmoid=True):
     """The U-Net's output block on the HIP kernels: x (B,C,h,w), weight (Cout,C,4,4), bias (Cout) -> (B,Cout,2h,2w).
     One launch pair per output channel (the reference networks use Cout = 1)."""
-    if not (x.is_cuda and x.dtype == torch.float32 and weight.shape[-2:] == (4, 4) and x.dim() == 4):
+    if not (_hip(x) and weight.shape[-2:] == (4, 4) and x.dim() == 4):
         raise _lib.DiffNetHipError("upsample_pad_conv4: float32 CUDA tensors (B,C,h,w) and 4x4 weights only")
     outs = [_UpConvOut.apply(x, weight[co:co + 1], None if bias is None else bias[co:co + 1], sigmoid) for co in range(weight.shape[0])]
     return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
@@ -165,7 +184,7 @@ class _UpConv3dOut(torch.autograd.Function):
 def upsample_conv3(x, weight, bias=None, sigmoid=True):
     """The 3-D generator's output block on the HIP kernels: x (B,C,d,h,w), weight (Cout,C,3,3,3), bias (Cout) ->
     (B,Cout,2d,2h,2w); one launch set per output channel."""
-    if not (x.is_cuda and x.dtype == torch.float32 and tuple(weight.shape[-3:]) == (3, 3, 3) and x.dim() == 5):
+    if not (_hip(x) and tuple(weight.shape[-3:]) == (3, 3, 3) and x.dim() == 5):
         raise _lib.DiffNetHipError("upsample_conv3: float32 CUDA tensors (B,C,d,h,w) and 3x3x3 weights only")
     outs = [_UpConv3dOut.apply(x, weight[co:co + 1], None if bias is None else bias[co:co + 1], sigmoid) for co in range(weight.shape[0])]
     return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
@@ -256,7 +275,7 @@ class _ConvT3dK4S2(torch.autograd.Function):
 
 
 def _k4s2(m, x, coarse_channels):
-    return (x.is_cuda and x.dtype == torch.float32 and m.bias is None and tuple(m.kernel_size) == (4, 4, 4) and tuple(m.stride) == (2, 2, 2)
+    return (_hip(x) and m.bias is None and tuple(m.kernel_size) == (4, 4, 4) and tuple(m.stride) == (2, 2, 2)
             and tuple(m.padding) == (1, 1, 1) and tuple(m.dilation) == (1, 1, 1) and m.groups == 1
             and tuple(getattr(m, "output_padding", (0, 0, 0))) == (0, 0, 0))
 
@@ -356,7 +375,7 @@ class _ConvT2dK4S2(torch.autograd.Function):
 
 
 def _k4s2_2d(m, x):
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(m.kernel_size) == (4, 4) and tuple(m.stride) == (2, 2)
+    return (_hip(x) and x.dim() == 4 and tuple(m.kernel_size) == (4, 4) and tuple(m.stride) == (2, 2)
             and tuple(m.padding) == (1, 1) and tuple(m.dilation) == (1, 1) and m.groups == 1 and m.padding_mode == "zeros"
             and tuple(getattr(m, "output_padding", (0, 0))) == (0, 0))
 
@@ -422,7 +441,7 @@ class Conv2dValid(nn.Conv2d):
 
     def forward(self, x):
         k = self.kernel_size
-        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and k[0] == k[1] and k[0] <= 7 and tuple(self.stride) == (1, 1)
+        if (_hip(x) and x.dim() == 4 and k[0] == k[1] and k[0] <= 7 and tuple(self.stride) == (1, 1)
                 and tuple(self.padding) == (0, 0) and tuple(self.dilation) == (1, 1) and self.groups == 1):
             return _Conv2dValid.apply(x, self.weight, self.bias)
         return super().forward(x)

@@ -5,6 +5,7 @@ Sigmoid.  Input sizes must be multiples of 32 (>= 64: InstanceNorm needs more th
 import torch
 from torch import nn
 
+from . import fused
 from .fused import Conv2dS2, ConvTranspose2dS2, InstanceNormAct, upsample_pad_conv4
 
 
@@ -62,7 +63,7 @@ class UNet(nn.Module):
         u = d[5]
         for i in range(1, 5):
             u = getattr(self, f"up{i}")(u, d[5 - i])
-        if u.is_cuda and u.dtype == torch.float32:
+        if fused._hip(u):
             # Upsample -> ZeroPad -> Conv(64 -> out, 4x4) -> Sigmoid as one HIP kernel each way (dn_upconv_out_*); the
             # modules in self.final stay the parameter holders (state_dict keys final.2.weight / final.2.bias)
             conv = self.final[2]

@@ -5,6 +5,7 @@ Upsample x2 -> Conv3d 3^3 pad 1 -> Sigmoid.  Default torch initialisation (the r
 import torch
 from torch import nn
 
+from . import fused
 from .fused import Conv3dS2, ConvTranspose3dS2, InstanceNormAct, upsample_conv3
 
 
@@ -59,7 +60,7 @@ class GoodGenerator(nn.Module):
         u = skips.pop()                                # bottleneck
         for name, *_ in self._UP:
             u = getattr(self, name)(u, skips.pop())
-        if u.is_cuda and u.dtype == torch.float32:
+        if fused._hip(u):
             # Upsample -> Conv3d(32 -> out, 3^3) -> Sigmoid as one HIP kernel each way (dn_upconv3d_out_*); self.final keeps
             # the parameters (state_dict keys final.1.weight / final.1.bias)
             conv = self.final[1]

@@ -374,7 +374,9 @@ def call_cache_clear():
     """Forget the cached prepared calls (after dn_config_set of a launch-plan switch: the workspace size depends on the plan)."""
     with _WS_LOCK:
         _CALL_CACHE.clear()
+        _FSDT_CACHE.clear()
     _POISSON_WS_BYTES.clear()
+    _FSDT_WS_BYTES.clear()
 
 
 class PoissonPlan:
@@ -653,16 +655,92 @@ def residual_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0):
 
 
 _FSDT_WS_BYTES = {}
+_FSDT_CACHE = __import__("collections").OrderedDict()
+
+
+def _fsdt_key(geom, flds, bc, bc_values, consts, in_scale, in_num, in_den, flags):
+    """Key of a cached prepared dn_fsdt_apply call (see _call_key); None when an argument needs a conversion copy."""
+    parts = [geom.key, flds[0].device.index, torch.cuda.current_stream(flds[0].device).cuda_stream, consts, flags]
+    for t in flds:
+        k = _tkey(t)
+        if k is None or k == 0 or k[1] != torch.float32:
+            return None
+        parts.append(k)
+    kb = _tkey(bc)
+    if kb is None or (kb != 0 and kb[1] not in (torch.float32, torch.uint8)):
+        return None
+    parts.append(kb)
+    for v in bc_values:
+        if isinstance(v, torch.Tensor) and v.numel() > 1:
+            kv = _tkey(v)
+            if kv is None or kv[1] != torch.float32:
+                return None
+            parts.append(kv)
+        else:
+            parts.append(float(v))
+    for t in (in_scale, in_num, in_den):
+        k = _tkey(t)
+        if k is None or (k != 0 and (k[1] != torch.float32 or k[2] != (3,))):
+            return None
+        parts.append(k)
+    return tuple(parts)
 
 
 def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.0, D12=0.0, D22=1.0, D66=1.0, A44=1.0, A55=1.0,
-               q=0.0, wscale=1.0, want_out=True, want_sums=True, in_scale=None):
+               q=0.0, wscale=1.0, want_out=True, want_sums=True, in_scale=None, want_norms=False, in_num=None, in_den=None):
     """One launch of dn_fsdt_apply (include/diffnet_hip.h): the three assembled FSDT plate residuals of the fields
     (B,1,ny,nx) and / or the float64 device tensor of their three sums of squares.  `bc`: Dirichlet node mask (fp32,
     `>= 0.5`, or bool/uint8), per sample or shared; `bc_values[k]`: float or tensor the k-th field / residual takes there;
-    `in_scale`: optional float32 device tensor of 3 factors applied to the fields as they are loaded."""
+    `in_scale`: optional float32 device tensor of 3 factors applied to the fields as they are loaded; `in_num` / `in_den`: the same
+    with the factors in_num[k] / in_den[k] (0 where in_den[k] <= 0) formed by the kernel; `want_norms`: a third result, the float32
+    tensor of the three Frobenius norms written by the same launch.  Returns (outs | None, sums | None[, norms]).
+    Calls on the same buffers reuse their prepared argument structs (small LRU, fresh outputs per call: see poisson_apply)."""
     if geom.nsd != 2:
         raise DiffNetHipError("fsdt_apply: 2-D meshes only")
+    consts = tuple(float(x) for x in (D11, D12, D22, D66, A44, A55, q, wscale))
+    flds = (w, phi_x, phi_y)
+    key = None
+    if all(isinstance(t, torch.Tensor) and t.is_cuda for t in flds) and tuple(w.shape[1:]) == (1, *geom.node_shape) and w.shape == phi_x.shape == phi_y.shape:
+        key = _fsdt_key(geom, flds, bc, bc_values, consts, in_scale, in_num, in_den, (want_out, want_sums, want_norms))
+    ent = None
+    if key is not None:
+        with _WS_LOCK:
+            ent = _FSDT_CACHE.get(key)
+            if ent is not None:
+                _FSDT_CACHE.move_to_end(key)
+    if ent is None:
+        _CALL_STATS["miss" if key is not None else "uncached"] += 1
+        mesh, args, keep, shape = _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num, in_den, want_sums or want_norms)
+        ent = (mesh, args, C.byref(mesh), C.byref(args), shape, [t for t in keep if any(t is x for x in _WS.values())])
+        if key is not None:
+            with _WS_LOCK:
+                _FSDT_CACHE[key] = ent
+                while len(_FSDT_CACHE) > _CALL_CACHE_MAX:
+                    _FSDT_CACHE.popitem(last=False)
+    else:
+        _CALL_STATS["hit"] += 1
+    mesh, args, mref, aref, shape, _ = ent
+    dev = w.device
+    outs = sums = norms = None
+    if want_out:
+        o3 = torch.empty((3, *shape), dtype=torch.float32, device=dev)      # one allocation, three views
+        outs = list(o3.unbind(0))
+        p0, step = o3.data_ptr(), 4 * o3[0].numel()
+        args.out[0], args.out[1], args.out[2] = p0, p0 + step, p0 + 2 * step
+    if want_sums:
+        sums = torch.empty(3, dtype=torch.float64, device=dev)
+        args.sumsq = sums.data_ptr()
+    if want_norms:
+        norms = torch.empty(3, dtype=torch.float32, device=dev)
+        args.norms = norms.data_ptr()
+    rc = _lib.lib().dn_fsdt_apply(mref, aref, _stream(w))
+    if rc:
+        _lib.check(rc, "dn_fsdt_apply")
+    return (outs, sums, norms) if want_norms else (outs, sums)
+
+
+def _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num, in_den, want_red):
+    """Validation + argument struct of a dn_fsdt_apply call, outputs left unset: (mesh, args, tensors to keep alive, field shape)."""
     flds = [_require(t, n, 4) for t, n in ((w, "w"), (phi_x, "phi_x"), (phi_y, "phi_y"))]
     B = flds[0].shape[0]
     shape = (B, 1, *geom.node_shape)
@@ -698,24 +776,18 @@ def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.
                 keep.append(v)
             else:
                 args.bc_value[k] = float(v)
-    args.D11, args.D12, args.D22, args.D66, args.A44, args.A55 = (float(x) for x in (D11, D12, D22, D66, A44, A55))
-    args.q, args.wscale = float(q), float(wscale)
+    args.D11, args.D12, args.D22, args.D66, args.A44, args.A55, args.q, args.wscale = consts
     mesh = geom.mesh_struct(B)
-    if in_scale is not None:
-        in_scale = _require(in_scale, "in_scale", 1)
-        if in_scale.numel() != 3:
-            raise ValueError("in_scale must hold 3 floats")
-        args.in_scale = in_scale.data_ptr()
-        keep.append(in_scale)
-    outs = None
-    if want_out:
-        o3 = torch.empty((3, *shape), dtype=torch.float32, device=flds[0].device)      # one allocation, three views
-        outs = [o3[0], o3[1], o3[2]]
-        for k in range(3):
-            args.out[k] = outs[k].data_ptr()
-    sums = None
-    if want_sums:
-        sums = torch.empty(3, dtype=torch.float64, device=flds[0].device)
+    for name, t in (("in_scale", in_scale), ("in_num", in_num), ("in_den", in_den)):
+        if t is not None:
+            t = _require(t, name, 1)
+            if t.numel() != 3:
+                raise ValueError(f"{name} must hold 3 floats")
+            setattr(args, name, t.data_ptr())
+            keep.append(t)
+    if (in_num is None) != (in_den is None) or (in_num is not None and in_scale is not None):
+        raise ValueError("fsdt_apply: in_num and in_den go together, and not with in_scale")
+    if want_red:
         key = (mesh.nx, mesh.ny, mesh.degree, mesh.ngp, B)
         nbytes = _FSDT_WS_BYTES.get(key)
         if nbytes is None:
@@ -725,11 +797,8 @@ def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.
             _FSDT_WS_BYTES[key] = nbytes
         ws = _workspace(flds[0].device, nbytes)
         keep.append(ws)
-        args.sumsq = sums.data_ptr()
         args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
-    rc = _lib.lib().dn_fsdt_apply(C.byref(mesh), C.byref(args), _stream(flds[0]))
-    _lib.check(rc, "dn_fsdt_apply")
-    return outs, sums
+    return mesh, args, keep, shape
 
 
 def compute_winding_nodes(points, normals, area, q):

@@ -148,6 +148,11 @@ int dn_probe_stream(const float *a, const float *b, const float *c, float *out, 
  * tools/march_probe.py: which (R, rows_ahead) the memory system rewards. */
 int dn_probe_march(const float *a, const float *b, const float *c, float *out, int32_t B, int32_t ny, int32_t R, int32_t rows_ahead,
                    int32_t flags, void *stream);
+/* Third probe: the TILE access pattern -- a workgroup requests all rows of a tile of rows_per_tile (4 | 8 | 16) node rows plus one halo row
+ * on either side at once, parks them in LDS and walks them from there (threads 256 | 512; flags bit 3 non-temporal loads, bit 6
+ * consecutive tiles on one XCD). */
+int dn_probe_tile(const float *a, const float *b, const float *c, float *out, int32_t B, int32_t ny, int32_t rows_per_tile, int32_t threads,
+                  int32_t flags, void *stream);
 
 int64_t dn_poisson_workspace_bytes(const dn_mesh *mesh);
 int dn_poisson_apply(const dn_mesh *mesh, const dn_poisson_args *args, void *stream);
@@ -214,6 +219,11 @@ typedef struct dn_fsdt_args {
     int64_t workspace_bytes;
     const float *in_scale; /* optional: 3 device floats, field k is multiplied by in_scale[k] as it is loaded (before the
                               Dirichlet substitution) -- lets the VJP of the three norms run without a scaling pass */
+    float *norms;          /* optional: 3 device floats, norms[k] = sqrt(sum of squares of residual k) written by the same launch -- the
+                              three Frobenius norms of e1_plate_bending_fsdt.py:230-232 without a torch op behind the kernel */
+    const float *in_num;   /* optional, both or neither (not with in_scale): field k is multiplied by in_num[k] / in_den[k] as it is */
+    const float *in_den;   /* loaded, by 0 where in_den[k] <= 0: the VJP of the norms is this call on the saved residuals with
+                              in_num = cotangents of the norms, in_den = the norms (torch's zero subgradient at a zero norm) */
 } dn_fsdt_args;
 int64_t dn_fsdt_workspace_bytes(const dn_mesh *mesh);
 int dn_fsdt_apply(const dn_mesh *mesh, const dn_fsdt_args *args, void *stream);

@@ -1,0 +1,183 @@
+"""GPU tests added in round 3: cached prepared calls behind the public API, strict prepared launches, the slab path with compact
+Dirichlet forms (in-process emulation of the ranks), the registered operator's mask validation, the measurement probes."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import boundary_mask, close, cu, dev, module, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kw,B", [(dict(domain_size=64, ngp_1d=2), 2), (dict(domain_size=33, nsd=3), 1), (dict(domain_size=65, ngp_1d=3, fem_basis_deg=2), 2)])
+def test_cached_calls_are_bitwise_equal_and_follow_their_buffers(kw, B):
+    """energy_loss_and_grad / residual_loss keep the prepared launch of a call in a small LRU keyed on pointers, shapes, condition
+    forms and coefficients (ops.poisson_apply): a repeat must give bitwise the results of the uncached preparation, write into FRESH
+    output tensors (an earlier result is never overwritten), see in-place updates of its inputs, miss on new buffers, and leave inputs
+    that need a conversion copy (non-contiguous, bool masks) to the uncached path."""
+    from diffnet_amd import ops
+    m = module(kw)
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = cu(seeded(shape, 1)), cu(seeded(shape, 2) + 0.5), cu(seeded(shape, 3))
+    bc = boundary_mask((1,) + shape[1:]).to(torch.uint8).to(dev())
+    ops.call_cache_clear()
+    ops._CALL_STATS.update(hit=0, miss=0, uncached=0)
+    scale = 1.0 / (B * m.geom.nelem_total)
+    kwargs = dict(alpha=2.0, beta=1.0, c=1.0, wscale=1.0, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
+    ref = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], **kwargs).launch()
+    ref = [t.clone() for t in ref]
+    l1, g1 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+    l2, g2 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+    assert ops._CALL_STATS["miss"] == 1 and ops._CALL_STATS["hit"] == 1
+    assert g1.data_ptr() != g2.data_ptr() and l1.data_ptr() != l2.data_ptr()          # fresh outputs per call
+    for g, l in ((g1, l1), (g2, l2)):
+        assert torch.equal(g, ref[0]) and torch.equal(l, ref[2])
+    # in-place update of an input: same key, new values
+    u.mul_(0.5)
+    l3, g3 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+    ref3 = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], **kwargs).launch()
+    assert ops._CALL_STATS["hit"] == 2 and torch.equal(g3, ref3[0]) and torch.equal(l3, ref3[2])
+    assert torch.equal(g1, ref[0])                                                     # the earlier result is untouched
+    # new buffers: a miss, then a hit of the new entry
+    u2 = u.clone()
+    l4, g4 = m.energy_loss_and_grad(u2, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+    assert ops._CALL_STATS["miss"] == 2 and torch.equal(g4, g3)
+    # another coefficient: another entry
+    l5, _ = m.energy_loss_and_grad(u2, nu, f, dirichlet=[(bc, 0.0)], c=0.5)
+    assert ops._CALL_STATS["miss"] == 3 and float(l5) != float(l4)
+    # inputs that need a conversion are never cached: a non-contiguous field, a bool mask
+    wide = torch.zeros(shape[:-1] + (2 * shape[-1],), device=dev())
+    un = wide[..., ::2]
+    un.copy_(u2)
+    assert not un.is_contiguous()
+    l6, g6 = m.energy_loss_and_grad(un, nu, f, dirichlet=[(bc.bool(), 0.0)], c=1.0)
+    assert ops._CALL_STATS["uncached"] == 1 and torch.equal(g6, g4) and torch.equal(l6, l4)
+    # the residual form shares the cache
+    if m.geom.deg == 1:
+        r1 = m.residual_loss(u2, nu, f, dirichlet=[(bc, 0.0)])
+        r2 = m.residual_loss(u2, nu, f, dirichlet=[(bc, 0.0)])
+        assert torch.equal(r1, r2)
+    with pytest.raises(Exception, match="not contiguous"):
+        ops.PoissonPlan(m.geom, un, nu, f, None, [(bc, 0.0)], **kwargs)
+    with pytest.raises(Exception, match="bool or non-contiguous"):
+        ops.PoissonPlan(m.geom, u2, nu, f, None, [(bc.bool(), 0.0)], **kwargs)
+
+
+@pytest.mark.parametrize("nsd,sizes,world", [(2, (40, 37), 2), (2, (64, 64), 3), (3, (17, 19, 23), 2), (3, (16, 16, 23), 4)])
+def test_slab_path_takes_packed_masks_and_box_faces(nsd, sizes, world):
+    """SlabPoisson with the compact Dirichlet forms: a PackedMask is unpacked for the slab launches, BoxFaces name faces of
+    the GLOBAL box -- the faces across the decomposed axis exist on the outermost ranks only.  The ranks are emulated in-process (the
+    prepared launches of every rank run on this GPU; no collective): the shares of the loss add up to the global loss, interior
+    layers of the slab gradients equal the global gradient, interface layers are the sum of the two neighbours' parts.  Uneven slabs
+    (22 element layers over 4 ranks: 6 / 6 / 5 / 5) included."""
+    from diffnet_amd import BoxFaces, PackedMask
+    from diffnet_amd.slab import SlabPoisson
+    lengths = (1.0, 0.8, 1.3)[:nsd]
+    kw = dict(nsd=nsd, domain_sizes=sizes + (1,) * (3 - nsd), domain_lengths=lengths + (1.0,) * (3 - nsd), domain_size=sizes[0])
+    m = module(kw)
+    B = 2
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = cu(seeded(shape, 41)), cu(seeded(shape, 42) + 0.5), cu(seeded(shape, 43))
+    src = (seeded(shape, 44) < 0.04).to(torch.uint8).to(dev())
+    box = BoxFaces("all")
+    lref, gref = m.energy_loss_and_grad(u, nu, f, dirichlet=[(src, 1.0), (box, 0.0)], c=0.7)
+    total, gsum = 0.0, torch.zeros_like(u)
+    for r in range(world):
+        sp = SlabPoisson(nsd, sizes, lengths, r, world, ngp_1d=2, device=dev())
+        dec = sp.dec
+        ul, nul, fl = dec.take(u), dec.take(nu), dec.take(f)
+        cond = [(PackedMask.pack(dec.take(src)), 1.0), (box, 0.0)]
+        scale = 1.0 / (B * dec.nel_global)
+        main, lo, hi, local = sp._plans(ul, nul, fl, cond, 0.7, 1.0, scale)
+        assert all(isinstance(d.mask, torch.Tensor) for d in local)
+        grad, _, loss = main.launch()
+        total += float(loss)
+        gsum[:, :, dec.n0:dec.n1 + 1] += grad
+        # the thin launches (one element layer under each interior face) give this rank's part of the interface layers
+        if lo is not None:
+            close(lo.launch()[0][:, :, 0], grad[:, :, 0].cpu().numpy(), rtol=1e-6, arel=1e-6)
+        if hi is not None:
+            close(hi.launch()[0][:, :, 1], grad[:, :, -1].cpu().numpy(), rtol=1e-6, arel=1e-6)
+        assert (lo is None) == (r == 0) and (hi is None) == (r == world - 1)
+        with pytest.raises(Exception, match="contiguous"):
+            sp._plans(ul[..., ::2], nul, fl, cond, 0.7, 1.0, scale)
+    np.testing.assert_allclose(total, float(lref), rtol=2e-6)
+    close(gsum, gref.cpu().numpy(), rtol=1e-5, arel=2e-6)
+
+
+def test_registered_operator_validates_int32_masks():
+    """int32 mask tensors are reserved for bit-packed masks (ops.PackedMask.bits): an int32 IMAGE is rejected instead of being
+    reinterpreted as bit rows, and a bit tensor of the wrong shape is rejected by the operator."""
+    from diffnet_amd import ops, torch_ops
+    m = module(dict(domain_size=32, nsd=3))
+    shape = (1, 1, 32, 32, 32)
+    u = cu(seeded(shape, 1))
+    img = boundary_mask(shape).to(torch.int32).to(dev())
+    with pytest.raises(TypeError, match="int32"):
+        m.energy_loss(u, dirichlet=[(img, 0.0)])
+    bad_bits = torch.zeros((1, 32 * 32, 2), dtype=torch.int32, device=dev())        # row_words 2 for nx = 32: not a packed mask of this mesh
+    with pytest.raises(Exception, match="bit-packed"):
+        torch_ops.poisson_apply(u, None, None, None, bad_bits, None, 0.0, None, None, 0.0, *torch_ops.geometry_args(m.geom), 2.0, 1.0, 1.0, 1.0, 1.0, 1.0)
+    # a packed mask in 3-D travels as its cached uint8 image (nothing is unpacked per call)
+    pm = ops.PackedMask.pack(boundary_mask(shape).to(torch.uint8).to(dev()))
+    l1 = m.energy_loss(u, dirichlet=[(pm, 0.0)])
+    img8 = pm._u8
+    l2 = m.energy_loss(u, dirichlet=[(pm, 0.0)])
+    assert pm._u8 is img8 and torch.equal(l1, l2)
+    l3 = m.energy_loss(u, dirichlet=[(boundary_mask(shape).to(dev()), 0.0)])
+    assert torch.equal(l1, l3)
+
+
+def test_measurement_probes_compute_what_they_say():
+    """dn_probe_stream / dn_probe_march are measurement kernels, but their results are defined (out = a * b + c; the marching probe writes
+    every owned row): a probe that skipped work would report a rate that means nothing."""
+    from diffnet_amd import _lib
+    L = _lib.lib()
+    B, n = 2, 512
+    a, b, c = (cu(seeded((B, n, n), s)) for s in (1, 2, 3))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for mode in range(12):
+        out = torch.full_like(a, float("nan"))
+        assert L.dn_probe_stream(a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), a.numel(), mode, stream) == 0
+        assert torch.equal(out, a * b + c), mode
+    for flags in (4, 5, 7, 12, 21, 29, 36, 44):
+        for R, D in ((16, 1), (16, 2), (8, 3), (32, 4)):
+            out = torch.full_like(a, float("nan"))
+            assert L.dn_probe_march(a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), B, n, R, D, flags, stream) == 0
+            assert bool(torch.isfinite(out).all()), (flags, R, D)
+    assert L.dn_probe_stream(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.data_ptr(), 6, 0, stream) == -1
+    assert L.dn_probe_march(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.data_ptr(), B, n, 16, 9, 0, stream) == -1
+
+
+@pytest.mark.parametrize("deg,ngp,sizes,B", [(2, 3, (65, 65), 1), (2, 3, (129, 41), 2), (1, 2, (70, 37), 3), (3, 3, (64, 46), 1), (2, 4, (257, 33), 1)])
+def test_fsdt_chained_strips_equal_single_strips(deg, ngp, sizes, B):
+    """dn_fsdt_apply with chained sub-strips (PLAN_FSDT "64,R,W": W one-wave sub-strips per workgroup, rows shared through LDS, one
+    recomputed seam layer per workgroup instead of one per strip) against the un-chained launch ("T,R") for every chain length class:
+    W = 2 .. 12, strips of 1 .. 5 element rows, a last workgroup with fewer sub-strips than the chain, more than one chunk of 63
+    element columns, Q1 / Q2 / Q3, no mask / uint8 / fp32 masks, the sums and the norms written by the launch; and the launch plan the
+    library picks by itself against both."""
+    from diffnet_amd import _lib, ops
+    kw = dict(nsd=2, domain_sizes=sizes, domain_lengths=(1.0, 0.9), domain_size=sizes[0], fem_basis_deg=deg, ngp_1d=ngp)
+    m = module(kw)
+    shape = (B, 1, sizes[1], sizes[0])
+    flds = [cu(seeded(shape, 90 + i)) for i in range(3)]
+    bcf = boundary_mask(shape).to(dev())
+    bcf[0, 0, sizes[1] // 2, 3:9] = 1.0
+    consts = dict(D11=1.3, D12=0.4, D22=1.1, D66=0.6, A44=0.8, A55=0.9, q=1.2, wscale=0.3)
+    try:
+        for mask in (None, bcf, bcf.to(torch.uint8)):
+            _lib.config_set("PLAN_FSDT", "192,3")
+            ref, rsums, rnorms = ops.fsdt_apply(m.geom, *flds, mask, (0.1, -0.2, 0.3), want_norms=True, **consts)
+            cases = ["64,1,2", "64,2,3", "64,1,12", "64,3,5", "64,5,4", "64,2,9", "64,4,7", ""]
+            for plan in cases:
+                _lib.config_set("PLAN_FSDT", plan)
+                got, sums, norms = ops.fsdt_apply(m.geom, *flds, mask, (0.1, -0.2, 0.3), want_norms=True, **consts)
+                for k in range(3):
+                    scale = float(ref[k].abs().max())
+                    assert float((got[k] - ref[k]).abs().max()) <= 3e-6 * scale, f"plan {plan!r} field {k} mask {None if mask is None else mask.dtype}"
+                np.testing.assert_allclose(sums.cpu().numpy(), rsums.cpu().numpy(), rtol=1e-6)
+                np.testing.assert_allclose(norms.cpu().numpy(), np.sqrt(rsums.cpu().numpy()), rtol=1e-6)
+    finally:
+        _lib.config_set("PLAN_FSDT", "")

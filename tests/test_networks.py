@@ -55,6 +55,110 @@ def test_network_matches_reference_cpu(name):
     check(net, z, torch.device("cpu"))
 
 
+GRAD_SPECS = ["unet_2_1_n64", "ae_1_1_d2_n32", "goodgen3d_1_1_n32"]
+
+
+def _param_stats(grads):
+    """Same statistics as tools/gen_golden.py:param_stats."""
+    out = []
+    for i, g in enumerate(grads):
+        gd = g.detach().double().reshape(-1).cpu().numpy()
+        sign = np.random.default_rng(1000 + i).integers(0, 2, gd.size) * 2.0 - 1.0
+        out.append([gd.sum(), np.sqrt((gd * gd).sum()), (gd * sign).sum()])
+    return np.array(out)
+
+
+def _check_stats(got, ref, names, rel):
+    """Every parameter's gradient: norm to `rel`, sum and random projection to `rel` x norm x a factor for the number of terms."""
+    for k, name in enumerate(names):
+        norm = ref[k, 1]
+        assert abs(got[k, 1] - norm) <= rel * norm + 1e-12, f"{name}: |grad| {got[k, 1]} vs {norm}"
+        for c in (0, 2):
+            assert abs(got[k, c] - ref[k, c]) <= 4.0 * rel * norm + 1e-12, f"{name}: statistic {c}: {got[k, c]} vs {ref[k, c]} (|grad| {norm})"
+
+
+def check_all_param_grads(name, dev):
+    """Gradient wrt EVERY parameter against the reference's (eval mode), through per-parameter statistics (netgrads_*.npz)."""
+    z = np.load(os.path.join(GOLDEN, f"net_{name}.npz"))
+    zg = np.load(os.path.join(GOLDEN, f"netgrads_{name}.npz"))
+    net = build(name).to(dev)
+    assert [k for k, _ in net.named_parameters()] == list(zg["names"])
+    x = torch.from_numpy(z["x"]).to(dev)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = net(x)
+    grads = torch.autograd.grad(y, list(net.parameters()), torch.from_numpy(z["cot"]).to(dev))
+    _check_stats(_param_stats(grads), zg["stats"], list(zg["names"]), 2e-3 if dev.type == "cuda" else 2e-4)
+
+
+@pytest.mark.parametrize("name", GRAD_SPECS)
+def test_every_parameter_gradient_matches_reference_cpu(name):
+    check_all_param_grads(name, torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name", GRAD_SPECS)
+def test_train_mode_matches_reference_cpu(name):
+    """Dropout live (the reference trains with Dropout 0.5 in four U-Net blocks, unets.py:13-45): with the CPU generator seeded as in the
+    fixture the rebuilt network must draw the same masks -- same Dropout modules, same places, same order -- and reproduce the
+    reference's train-mode output and gradients."""
+    z = np.load(os.path.join(GOLDEN, f"net_{name}.npz"))
+    zg = np.load(os.path.join(GOLDEN, f"netgrads_{name}.npz"))
+    net = build(name).train()
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    torch.manual_seed(777)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = net(x)
+    np.testing.assert_allclose(y.detach().numpy(), zg["y_train"], rtol=1e-5, atol=1e-6)
+    g = torch.autograd.grad(y, [x] + list(net.parameters()), torch.from_numpy(z["cot"]))
+    np.testing.assert_allclose(g[0].numpy(), zg["grad_x_train"], rtol=1e-3, atol=1e-4 * float(np.abs(zg["grad_x_train"]).max()))
+    _check_stats(_param_stats(g[1:]), zg["stats_train"], list(zg["names"]), 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GRAD_SPECS)
+def test_every_parameter_gradient_matches_reference_gpu(name):
+    check_all_param_grads(name, torch.device("cuda:0"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GRAD_SPECS)
+def test_train_mode_hip_blocks_equal_stock_modules_gpu(name):
+    """Train mode on the GPU (Dropout live): the network on the hand-written HIP layers against the SAME network object on torch's own
+    layers (fused.stock_layers(): the stock-module composition the reference is made of), same seed before each forward -> same
+    Dropout masks (nn.Dropout is the stock module in both): output, input gradient and every parameter gradient."""
+    from diffnet_amd.networks import fused
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLDEN, f"net_{name}.npz"))
+    net = build(name).to(dev).train()
+    x = torch.from_numpy(z["x"]).to(dev).requires_grad_(True)
+    cot = torch.from_numpy(z["cot"]).to(dev)
+
+    def run():
+        torch.manual_seed(4242)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = net(x)
+        return y, torch.autograd.grad(y, [x] + list(net.parameters()), cot)
+
+    y_hip, g_hip = run()
+    with fused.stock_layers():
+        y_ref, g_ref = run()
+    assert float((y_hip - y_ref).abs().max()) > 0.0 or name.startswith("ae")      # two different code paths really ran
+    np.testing.assert_allclose(y_hip.detach().cpu().numpy(), y_ref.detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
+    names = ["x"] + [k for k, _ in net.named_parameters()]
+    for n, a, b in zip(names, g_hip, g_ref):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-3 * scale, f"{name} {n}: {float((a - b).abs().max())} vs scale {scale}"
+    # and the dropout really was live: a second seed gives another output
+    torch.manual_seed(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y2 = net(x)
+    if name != "ae_1_1_d2_n32":        # the AE has no Dropout (autoencoders.py:7-95)
+        assert float((y2 - y_hip).abs().max()) > 1e-4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(SPECS))
 def test_network_matches_reference_gpu(name):

@@ -75,6 +75,7 @@ def _worker(rank, world, port, nsd, sizes, lengths, B, out_dir):
     (2, 3, (9, 8, 12), (1.0, 0.8, 1.5)),
     (3, 3, (7, 6, 11), (1.0, 1.0, 1.0)),
     (2, 2, (17, 22, 1), (1.0, 1.3, 1.0)),
+    (4, 3, (6, 5, 15), (1.0, 0.7, 1.2)),          # 14 element layers over 4 ranks: 4 / 4 / 3 / 3 (the 255 = 7 x 32 + 31 remainder pattern of 256^3 over 8)
 ])
 def test_slab_decomposition_matches_global(tmp_path, world, nsd, sizes, lengths):
     from oracle.fem_oracle import Oracle

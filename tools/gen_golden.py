@@ -444,6 +444,47 @@ def gen_networks(outdir):
         print("net", name, nparam, checksum)
 
 
+def param_stats(grads):
+    """Per parameter tensor: [sum, l2 norm, dot with a seeded +-1 vector] of its gradient (float64): a small fixture that still pins
+    every entry of every parameter gradient (the random projection sees all of them)."""
+    out = []
+    for i, g in enumerate(grads):
+        gd = g.detach().double().reshape(-1).numpy()
+        sign = np.random.default_rng(1000 + i).integers(0, 2, gd.size) * 2.0 - 1.0
+        out.append([gd.sum(), np.sqrt((gd * gd).sum()), (gd * sign).sum()])
+    return np.array(out)
+
+
+def gen_network_grads(outdir):
+    """Gradients wrt EVERY parameter (eval mode, same seeds as gen_networks) as per-parameter statistics, and a TRAIN-mode forward +
+    backward (Dropout live; torch.manual_seed(777) right before the call fixes the masks of the CPU generator)."""
+    from DiffNet.networks.unets import UNet
+    from DiffNet.networks.autoencoders import AE
+    from DiffNet.networks.wgan3d import GoodGenerator
+    specs = [
+        ("unet_2_1_n64", lambda: UNet(in_channels=2, out_channels=1), (2, 2, 64, 64)),
+        ("ae_1_1_d2_n32", lambda: AE(in_channels=1, out_channels=1, n_downsample=2), (2, 1, 32, 32)),
+        ("goodgen3d_1_1_n32", lambda: GoodGenerator(in_channels=1, out_channels=1), (1, 1, 32, 32, 32)),
+    ]
+    for name, ctor, shape in specs:
+        torch.manual_seed(2024)
+        net = ctor().eval()
+        g = rng(31)
+        x = torch.rand(shape, generator=g).requires_grad_(True)
+        y = net(x)
+        cot = torch.rand(y.shape, generator=g)
+        params = list(net.parameters())
+        grads = torch.autograd.grad(y, params, cot)
+        net.train()
+        torch.manual_seed(777)
+        yt = net(x)
+        gt = torch.autograd.grad(yt, [x] + params, cot)
+        np.savez_compressed(os.path.join(outdir, f"netgrads_{name}.npz"), names=np.array([k for k, _ in net.named_parameters()]),
+                            stats=param_stats(grads), y_train=T(yt), grad_x_train=T(gt[0]), stats_train=param_stats(gt[1:]),
+                            torch_version=torch.__version__)
+        print("netgrads", name, len(params), float(yt.mean()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -676,7 +717,7 @@ def gen_networks_large(outdir):
 if __name__ == "__main__":
     # default: tables, operators, loss bodies and networks; the other fixture families are selected by flag
     outdir = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
-    extra = {"--fdm": gen_fdm, "--winding": gen_winding, "--datasets": gen_datasets, "--l2": gen_l2, "--net512": gen_networks_large}
+    extra = {"--fdm": gen_fdm, "--winding": gen_winding, "--datasets": gen_datasets, "--l2": gen_l2, "--net512": gen_networks_large, "--netgrads": gen_network_grads}
     chosen = [fn for flag, fn in extra.items() if flag in sys.argv]
     if chosen:
         install_shims()

@@ -40,9 +40,9 @@ for mode in (0, 2, 3):
     us = timeit(fn)
     print(f"stream form {mode >> 2} nt_loads {(mode >> 1) & 1} nt_stores {mode & 1}: {us:7.2f} us  {alg / us / 1e6:6.2f} TB/s algorithmic", flush=True)
 
-for flags in (4, 12, 36, 44):
-    for R in (8, 16, 32):
-        for D in (1, 2):
+for flags in (7,):
+    for R in (16,):
+        for D in (1,):
             def fn(k, R=R, D=D, flags=flags):
                 a, b, c, o = sets[k]
                 rc = L.dn_probe_march(a.data_ptr(), b.data_ptr(), c.data_ptr(), o.data_ptr(), B, n, R, D, flags, stream())
@@ -50,3 +50,12 @@ for flags in (4, 12, 36, 44):
             us = timeit(fn)
             print(f"march {'PAIRED rows ' if flags & 32 else ''}halo {flags & 1} shared-node {'lane' if flags & 16 else (flags >> 1) & 1} nt_stores {(flags >> 2) & 1} nt_loads {(flags >> 3) & 1}  R {R:3d} ({64 * (n // R) * 2 / 1024:4.1f} waves/SIMD) rows ahead {D}: "
                   f"{us:7.2f} us  {alg / us / 1e6:6.2f} TB/s algorithmic", flush=True)
+
+for flags in (0, 8, 64, 72):
+    for threads, TR in ((256, 4), (256, 8), (512, 8), (256, 16), (512, 16)):
+        def fn(k, threads=threads, TR=TR, flags=flags):
+            a, b, c, o = sets[k]
+            rc = L.dn_probe_tile(a.data_ptr(), b.data_ptr(), c.data_ptr(), o.data_ptr(), B, n, TR, threads, flags, stream())
+            assert rc == 0, rc
+        us = timeit(fn)
+        print(f"tile  rows {TR:2d} (+2 halo) threads {threads} nt_loads {(flags >> 3) & 1} xcd-order {(flags >> 6) & 1}: {us:7.2f} us  {alg / us / 1e6:6.2f} TB/s algorithmic", flush=True)
