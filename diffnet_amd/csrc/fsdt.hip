@@ -62,7 +62,6 @@ struct FsdtParams {
     unsigned* counter;
     double* sumsq;                         // 3 doubles
     int nx, ny, nelx, nely, rows_per_strip, want_sums;
-    int nstrips;                           // strips per sample (chained launches: the last workgroup of a column may hold fewer sub-strips)
 };
 
 // Deterministic in-kernel final reduction of three scalars (same protocol as finish_sums in poisson_common.h).
@@ -130,35 +129,54 @@ __device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&
 // Sum-factorised one x-Gauss point at a time: x-stage of the three fields for that point (value / x-derivative per node
 // row), the NGP y-points with the constitutive law and the y-transpose, then the x-transpose of that point straight into
 // g -- the live set is one point's stage values and cotangents (36 registers at Q2) instead of all points' (108).
-template <int P, int NGP>
+// MID (Q2 with the symmetric 3-point rule, checked on the host): the middle Gauss point sits on the middle node, where the basis is
+// (0, 1, 0) and its derivative (-d, 0, +d).  A third of all 1-D contractions then are a copy or one difference instead of three
+// fused multiply-adds: 171 of the element's 954 instructions (fmaf(0, x, a) cannot be folded by the compiler -- x may be a NaN --, so
+// the zeros are spelled out here; same numbers as the generic form to rounding: d (F2 - F0) has one rounding less than d F2 + (-d) F0).
+template <int P, int NGP, bool MID>
 __device__ __forceinline__ void fsdt_elem(const FsdtParams& p, const float (&F)[3][P + 1][P + 1], float (&g)[3][P + 1][P + 1]) {
     constexpr int NB = P + 1;
+    static_assert(!MID || (P == 2 && NGP == 3), "MID: Q2 elements, 3-point rule");
+    const float dxm = p.dx[1][NB - 1], dym = p.dy[1][NB - 1];       // derivative of the last basis function at the middle point
 #pragma unroll
     for (int ig = 0; ig < NGP; ++ig) {
+        const bool xm = MID && ig == 1;
         float tv[3][NB], td[3][NB], rv[3][NB], rd[3][NB];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int jb = 0; jb < NB; ++jb) {
                 float a = 0.f, d = 0.f;
+                if (xm) {
+                    a = F[k][jb][1];
+                    d = dxm * (F[k][jb][2] - F[k][jb][0]);
+                } else {
 #pragma unroll
-                for (int ib = 0; ib < NB; ++ib) {
-                    a = fmaf(p.b[ig][ib], F[k][jb][ib], a);
-                    d = fmaf(p.dx[ig][ib], F[k][jb][ib], d);
+                    for (int ib = 0; ib < NB; ++ib) {
+                        a = fmaf(p.b[ig][ib], F[k][jb][ib], a);
+                        d = fmaf(p.dx[ig][ib], F[k][jb][ib], d);
+                    }
                 }
                 tv[k][jb] = a; td[k][jb] = d; rv[k][jb] = 0.f; rd[k][jb] = 0.f;
             }
 #pragma unroll
         for (int jg = 0; jg < NGP; ++jg) {
+            const bool ym = MID && jg == 1;
             float val[3], fx[3], fy[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float v = 0.f, x = 0.f, y = 0.f;
+                if (ym) {
+                    v = tv[k][1];
+                    x = td[k][1];
+                    y = dym * (tv[k][2] - tv[k][0]);
+                } else {
 #pragma unroll
-                for (int jb = 0; jb < NB; ++jb) {
-                    v = fmaf(p.b[jg][jb], tv[k][jb], v);
-                    x = fmaf(p.b[jg][jb], td[k][jb], x);
-                    y = fmaf(p.dy[jg][jb], tv[k][jb], y);
+                    for (int jb = 0; jb < NB; ++jb) {
+                        v = fmaf(p.b[jg][jb], tv[k][jb], v);
+                        x = fmaf(p.b[jg][jb], td[k][jb], x);
+                        y = fmaf(p.dy[jg][jb], tv[k][jb], y);
+                    }
                 }
                 val[k] = v; fx[k] = x; fy[k] = y;
             }
@@ -169,23 +187,40 @@ __device__ __forceinline__ void fsdt_elem(const FsdtParams& p, const float (&F)[
             const float Mxy = W * (p.D66 * (fy[1] + fx[2]));
             const float cv[3] = {-p.q * W, Qx, Qy}, cx[3] = {Qx, Mxx, Mxy}, cy[3] = {Qy, Mxy, Myy};
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < 3; ++k) {
+                if (ym) {
+                    const float t = dym * cy[k];
+                    rv[k][0] -= t;
+                    rv[k][1] += cv[k];
+                    rv[k][2] += t;
+                    rd[k][1] += cx[k];
+                } else {
 #pragma unroll
-                for (int jb = 0; jb < NB; ++jb) {
-                    rv[k][jb] = fmaf(p.b[jg][jb], cv[k], rv[k][jb]);
-                    rv[k][jb] = fmaf(p.dy[jg][jb], cy[k], rv[k][jb]);
-                    rd[k][jb] = fmaf(p.b[jg][jb], cx[k], rd[k][jb]);
+                    for (int jb = 0; jb < NB; ++jb) {
+                        rv[k][jb] = fmaf(p.b[jg][jb], cv[k], rv[k][jb]);
+                        rv[k][jb] = fmaf(p.dy[jg][jb], cy[k], rv[k][jb]);
+                        rd[k][jb] = fmaf(p.b[jg][jb], cx[k], rd[k][jb]);
+                    }
                 }
+            }
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int jb = 0; jb < NB; ++jb)
+            for (int jb = 0; jb < NB; ++jb) {
+                if (xm) {
+                    const float t = dxm * rd[k][jb];
+                    g[k][jb][0] -= t;
+                    g[k][jb][1] += rv[k][jb];
+                    g[k][jb][2] += t;
+                } else {
 #pragma unroll
-                for (int ib = 0; ib < NB; ++ib) {
-                    g[k][jb][ib] = fmaf(p.b[ig][ib], rv[k][jb], g[k][jb][ib]);
-                    g[k][jb][ib] = fmaf(p.dx[ig][ib], rd[k][jb], g[k][jb][ib]);
+                    for (int ib = 0; ib < NB; ++ib) {
+                        g[k][jb][ib] = fmaf(p.b[ig][ib], rv[k][jb], g[k][jb][ib]);
+                        g[k][jb][ib] = fmaf(p.dx[ig][ib], rd[k][jb], g[k][jb][ib]);
+                    }
                 }
+            }
     }
 }
 
@@ -203,7 +238,7 @@ __device__ __forceinline__ void fsdt_elem(const FsdtParams& p, const float (&F)[
 // At one sample the element rows have to be cut into strips of 2 to fill the chip -- un-chained that is one recomputed layer per two
 // (+50 % arithmetic in a kernel bound by its 918 instructions per element); chained it is one per workgroup.  Inside a one-wave
 // sub-strip the hand-over to the right neighbour is a lane shuffle: no LDS slot, no barrier.
-template <int P, int NGP, int MK, bool BCF, bool CH>
+template <int P, int NGP, int MK, bool BCF, bool CH, bool MID>
 __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(const FsdtParams p) {
     constexpr int NB = P + 1;
     constexpr int NW = P;                  // nodes owned per thread per node row
@@ -211,18 +246,24 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
     const int sub = CH ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
     const int nsub = CH ? (int)blockDim.x >> 6 : 1;
     const int tid = CH ? (int)threadIdx.x & 63 : (int)threadIdx.x;
-    const int chunk = blockIdx.x, strip = (int)blockIdx.y * nsub + sub, b = blockIdx.z;
-    const bool active = !CH || strip < p.nstrips;
-    const bool chain_dn = CH && sub > 0, chain_up = CH && sub + 1 < nsub && strip + 1 < p.nstrips;
+    const int chunk = blockIdx.x, b = blockIdx.z;
+    const int R = p.rows_per_strip;
+    // Rows of this (sub-)strip.  Un-chained: strips of R element rows, each recomputes the layer under its first row.  Chained: the
+    // workgroup covers nsub * R - 1 rows; sub-strip 0 -- the one that recomputes the seam layer under the workgroup -- owns R - 1 of
+    // them, the others R, so that EVERY wave of the workgroup marches R layers (a workgroup is as slow as its slowest wave, and a wave
+    // left alone on its SIMD issues at half the rate: with equal strips the chained launch was slower than the un-chained one)
+    const int rows_wg = nsub * R - 1;
+    const int ey_own = CH ? (int)blockIdx.y * rows_wg + (sub == 0 ? 0 : R - 1 + (sub - 1) * R) : (int)blockIdx.y * R;
+    const int own_rows = (CH && sub == 0) ? R - 1 : R;
+    const bool active = !CH || sub == 0 || ey_own < p.nely;
+    const bool chain_dn = CH && sub > 0, chain_up = CH && sub + 1 < nsub && ey_own + own_rows < p.nely;
     const int q = chunk * (T - 1) + tid;   // chunks overlap by one thread column
     const int ex0 = q, x0 = ex0 * P;
     const bool col_owner = !(chunk > 0 && tid == 0);
     const int64_t nps = (int64_t)p.nx * p.ny;
-    const int R = p.rows_per_strip;
-    const int ey_own = strip * R;
     const int ey_begin = (ey_own > 0 && !chain_dn) ? ey_own - 1 : ey_own;     // chain_dn: no seam layer
-    const int ey_end = min(ey_own + R, p.nely);
-    const int ymax = chain_up ? ey_end * P - 1 : p.ny - 1;     // chain_up: the top node row comes from the sub-strip above, not from HBM
+    const int ey_end = min(ey_own + own_rows, p.nely);
+    const int ymax = chain_up ? max(ey_end * P - 1, 0) : p.ny - 1;     // chain_up: the top node row comes from the sub-strip above, not from HBM
     const float okf = (ex0 < p.nelx) ? 1.f : 0.f;      // threads right of the mesh compute on clamped data, scaled by 0
 
     const float* fb[3];
@@ -386,6 +427,8 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
     {
         RawRow w0;
         row_issue(ey_begin * P, w0);
+#pragma unroll
+        for (int r = 1; r <= P; ++r) row_issue(ey_begin * P + r, W[r - 1]);       // all P + 1 rows of the first layer in flight together
         row_consume(w0, 0);
     }
     if constexpr (CH) {
@@ -399,8 +442,6 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
             if (tid == 0) fs_lds_st(fs_lds_addr(flag_base + 2 * (sub - 1)), 1u);       // LDS executes a wave's accesses in order
         }
     }
-#pragma unroll
-    for (int r = 1; r <= P; ++r) row_issue(ey_begin * P + r, W[r - 1]);
     for (int ey = ey_begin; ey < ey_end; ++ey) {
 #pragma unroll
         for (int r = 1; r <= P; ++r) row_consume(W[r - 1], r);
@@ -428,7 +469,7 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
                 for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
                     for (int ib = 0; ib < NB; ++ib) g[k][jb][ib] = 0.f;
-            fsdt_elem<P, NGP>(p, cu, g);
+            fsdt_elem<P, NGP, MID>(p, cu, g);
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -503,7 +544,7 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
 static inline int fs_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static constexpr int64_t FSDT_WS_HEADER = 64 * (1 + 64);
 
-struct FsdtGeom { int T, chunks, R, strips, W; };     // W > 1: chained launch, W one-wave sub-strips per workgroup (T == 64)
+struct FsdtGeom { int T, chunks, R, strips, W; };     // W > 1: chained launch, W one-wave sub-strips per workgroup (T == 64); strips = workgroups per column of chunks
 
 // Cost model of a launch plan, in wave-layers on the busiest SIMD (the kernel is bound by its arithmetic: ~918 VALU instructions per
 // element layer at Q2 / 3 x 3; a SIMD issues them at ~2.4 cycles each once two waves share it, ~4.7 with a single wave): workgroups
@@ -542,22 +583,14 @@ static FsdtGeom fsdt_plan(const dn_mesh* m, bool allow_chain = true) {
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = fs_ceil_div(nely, g.R);
-    // Chained alternative (fsdt2d_kernel<.., CH>): W one-wave sub-strips of R rows per workgroup recompute ONE seam layer per workgroup
-    // instead of one per strip.  Taken when the model says the busiest SIMD gets at least 5 % less to do.
-    if (allow_chain && nely >= 4) {
-        const int chunks64 = Q <= 64 ? 1 : fs_ceil_div(Q - 1, 63);
-        const double cost1 = fsdt_cost((long long)g.chunks * g.strips * m->batch, g.T / 64, (double)(g.T / 64) * (g.R + 1));
-        double bestc = cost1 * 0.95;
-        for (int RR = 1; RR <= 8; ++RR) {
-            for (int W = 2; W <= FS_CH_MAXW; ++W) {
-                if (RR * W > nely && !(RR == 1 && W == 2)) continue;
-                const int strips = fs_ceil_div(nely, RR);
-                const long long nwg = (long long)chunks64 * fs_ceil_div(strips, W) * m->batch;
-                const double c = fsdt_cost(nwg, W, (double)W * RR + 1.0) * (1.0 + 0.002 * W);       // ties: shorter chains
-                if (c < bestc) { bestc = c; g.T = 64; g.chunks = chunks64; g.R = RR; g.strips = strips; g.W = W; }
-            }
-        }
-    }
+    // Chained alternative (fsdt2d_kernel<.., CH>, "PLAN_FSDT" "64,R,W"): W one-wave sub-strips per workgroup recompute ONE seam layer per
+    // workgroup instead of one per strip -- a quarter less arithmetic at one sample.  Measured (profiles/r3_fsdt_plans.txt), it is not
+    // faster: at B = 1 the launch is bound by the latency chain of a wave's 2-3 layers, not by the arithmetic (28.9 us either way), at
+    // B = 8 it won 5 % before the middle-point form of the element and loses 20 % with it (the chained instantiation is capped at 168
+    // VGPRs by its 12-wave workgroups and spills).  Only chain lengths that fill the SIMDs evenly (4, 10, 12) are usable at all: a
+    // workgroup's waves go to the SIMDs in turn, and a second workgroup is not placed when one SIMD would exceed its register file.
+    // Kept as a plan option, not chosen by the library.
+    (void)fsdt_cost;
     const char* e = config(CFG_PLAN_FSDT);      // "T,R[,W]" (tuning experiments only; W >= 2: chained, T is then 64)
     int T, RR, W = 1;
     if (e && sscanf(e, "%d,%d,%d", &T, &RR, &W) >= 2 && T >= 64 && T <= 256 && RR >= 1) {
@@ -565,7 +598,7 @@ static FsdtGeom fsdt_plan(const dn_mesh* m, bool allow_chain = true) {
         if (g.W > 1) T = 64;
         g.T = T; g.R = RR > nely ? nely : RR;
         g.chunks = Q <= T ? 1 : fs_ceil_div(Q - 1, T - 1);
-        g.strips = fs_ceil_div(nely, g.R);
+        g.strips = g.W > 1 ? fs_ceil_div(nely, g.W * g.R - 1) : fs_ceil_div(nely, g.R);
     }
     return g;
 }
@@ -579,36 +612,40 @@ static int fsdt_validate(const dn_mesh* m) {
     return 0;
 }
 
-template <int P, int NGP>
+template <int P, int NGP, bool MID>
 static int fsdt_launch_mk(const FsdtParams& pp, const FsdtGeom& g, int batch, hipStream_t s) {
     const int mk = !pp.mask ? 0 : (pp.mask_is_u8 ? 1 : 2);
     const bool bcf = mk != 0 && (pp.bcf[0] || pp.bcf[1] || pp.bcf[2]);
     if (g.W > 1) {                    // chained sub-strips: one wave each, seams through dynamic LDS
         if (bcf || g.T != 64 || g.W > FS_CH_MAXW) return DN_E_BADARG;
-        dim3 grid(g.chunks, (g.strips + g.W - 1) / g.W, batch), block(64 * g.W);
+        dim3 grid(g.chunks, g.strips, batch), block(64 * g.W);
         const size_t lds = (size_t)(g.W - 1) * ((9 * (P + 1) + 1) * 64 * sizeof(float) + 2 * sizeof(unsigned));
         switch (mk) {
-            case 0: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 0, false, true>), grid, block, lds, s, pp); return 0;
-            case 1: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, false, true>), grid, block, lds, s, pp); return 0;
-            default: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, false, true>), grid, block, lds, s, pp); return 0;
+            case 0: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 0, false, true, MID>), grid, block, lds, s, pp); return 0;
+            case 1: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, false, true, MID>), grid, block, lds, s, pp); return 0;
+            default: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, false, true, MID>), grid, block, lds, s, pp); return 0;
         }
     }
     dim3 grid(g.chunks, g.strips, batch), block(g.T);
     switch (mk * 2 + (bcf ? 1 : 0)) {
-        case 0: case 1: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 0, false, false>), grid, block, 0, s, pp); return 0;
-        case 2: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, false, false>), grid, block, 0, s, pp); return 0;
-        case 3: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, true, false>), grid, block, 0, s, pp); return 0;
-        case 4: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, false, false>), grid, block, 0, s, pp); return 0;
-        default: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, true, false>), grid, block, 0, s, pp); return 0;
+        case 0: case 1: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 0, false, false, MID>), grid, block, 0, s, pp); return 0;
+        case 2: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, false, false, MID>), grid, block, 0, s, pp); return 0;
+        case 3: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 1, true, false, MID>), grid, block, 0, s, pp); return 0;
+        case 4: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, false, false, MID>), grid, block, 0, s, pp); return 0;
+        default: hipLaunchKernelGGL((fsdt2d_kernel<P, NGP, 2, true, false, MID>), grid, block, 0, s, pp); return 0;
     }
 }
 
 template <int P>
-static int fsdt_launch(const FsdtParams& pp, const FsdtGeom& g, int ngp, int batch, hipStream_t s) {
+static int fsdt_launch(const FsdtParams& pp, const FsdtGeom& g, int ngp, int batch, bool mid, hipStream_t s) {
     switch (ngp) {
-        case 2: return fsdt_launch_mk<P, 2>(pp, g, batch, s);
-        case 3: return fsdt_launch_mk<P, 3>(pp, g, batch, s);
-        case 4: return fsdt_launch_mk<P, 4>(pp, g, batch, s);
+        case 2: return fsdt_launch_mk<P, 2, false>(pp, g, batch, s);
+        case 3:
+            if constexpr (P == 2) {
+                if (mid) return fsdt_launch_mk<P, 3, true>(pp, g, batch, s);
+            }
+            return fsdt_launch_mk<P, 3, false>(pp, g, batch, s);
+        case 4: return fsdt_launch_mk<P, 4, false>(pp, g, batch, s);
         default: return DN_E_UNSUPPORTED;
     }
 }
@@ -633,7 +670,7 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     const bool want_red = a->sumsq || a->norms;
     const bool any_bcf = a->bc_mask && (a->bc_field[0] || a->bc_field[1] || a->bc_field[2]);
     const FsdtGeom g = fsdt_plan(m, !any_bcf);
-    const int64_t nwg = (int64_t)g.chunks * ((g.strips + g.W - 1) / g.W) * m->batch;
+    const int64_t nwg = (int64_t)g.chunks * g.strips * m->batch;
     if (want_red && (!a->workspace || a->workspace_bytes < FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
 
     FsdtParams pp;
@@ -659,13 +696,18 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     pp.nx = m->nx; pp.ny = m->ny;
     pp.nelx = (m->nx - 1) / m->degree; pp.nely = (m->ny - 1) / m->degree;
     pp.rows_per_strip = g.R;
-    pp.nstrips = g.strips;
     pp.want_sums = want_red ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (m->degree) {
-        case 1: rc = fsdt_launch<1>(pp, g, m->ngp, m->batch, s); break;
-        case 2: rc = fsdt_launch<2>(pp, g, m->ngp, m->batch, s); break;
-        default: rc = fsdt_launch<3>(pp, g, m->ngp, m->batch, s); break;
+        case 1: rc = fsdt_launch<1>(pp, g, m->ngp, m->batch, false, s); break;
+        case 2: {
+            // the symmetric 3-point rule puts its middle point on the middle node of a Q2 element: basis (0, 1, 0), derivative (-d, 0, d)
+            const bool mid = m->ngp == 3 && m->basis[1][0] == 0.f && m->basis[1][2] == 0.f && m->basis[1][1] == 1.f && m->dbasis[1][1] == 0.f &&
+                             m->dbasis[1][0] == -m->dbasis[1][2] && config(CFG_FSDT_GENERIC) == nullptr;
+            rc = fsdt_launch<2>(pp, g, m->ngp, m->batch, mid, s);
+            break;
+        }
+        default: rc = fsdt_launch<3>(pp, g, m->ngp, m->batch, false, s); break;
     }
     if (rc) return rc;
     DN_LAUNCH_CHECK();

@@ -587,13 +587,18 @@ def test_fsdt_fused_full_size_q2_strips_and_chunks():
     for k in range(3):
         np.testing.assert_allclose(float(sums[k]), float((Kb[k].double() ** 2).sum()), rtol=1e-6)
     from diffnet_amd import _lib
-    _lib.config_set("PLAN_FSDT", "64,7")
     try:
+        _lib.config_set("PLAN_FSDT", "64,7")
         Ka2, _ = ops.fsdt_apply(m.geom, *a3, bc, **kw)
+        _lib.config_set("PLAN_FSDT", "192,4")
+        Ka3, _ = ops.fsdt_apply(m.geom, *a3, bc, **kw)
     finally:
         _lib.config_set("PLAN_FSDT", "")
-    for x, y in zip(Ka, Ka2):
-        assert torch.equal(x, y)
+    for x, y, z in zip(Ka, Ka2, Ka3):
+        assert torch.equal(y, z)                 # two partitions of the un-chained kernel: seam recomputation is exact
+        # the launch plan the library picks may be the chained kernel, another instantiation whose fused multiply-adds the compiler
+        # contracts differently: equal to an ulp or two
+        assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max())
 
 
 def test_graph_captured_training_iteration_matches_eager():

@@ -176,13 +176,16 @@ def test_fsdt_full_size_1025_q2():
     for k in range(3):
         np.testing.assert_allclose(float(sums[k]), float((Kb[k].double() ** 2).sum()), rtol=1e-6)
         assert float((Ka[k] * bc).abs().max()) == 0.0
-    _lib.config_set("PLAN_FSDT", "64,7")
     try:
+        _lib.config_set("PLAN_FSDT", "64,7")
         Ka2, _ = ops.fsdt_apply(m.geom, *a3, bc, **kw)
+        _lib.config_set("PLAN_FSDT", "192,2")
+        Ka3, _ = ops.fsdt_apply(m.geom, *a3, bc, **kw)
     finally:
         _lib.config_set("PLAN_FSDT", "")
-    for x, y in zip(Ka, Ka2):
-        assert torch.equal(x, y)
+    for x, y, z in zip(Ka, Ka2, Ka3):
+        assert torch.equal(y, z)                 # two partitions of the un-chained kernel: bitwise (seam recomputation is exact)
+        assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max())      # the library's own plan may be the chained kernel (other fma contraction)
     # oracle on a strip: a 1025 x 9 mesh (512 x 4 Q2 elements) with the same hx, hy
     ny = 9
     skw = dict(domain_sizes=(n, ny, 1), domain_lengths=(1.0, (ny - 1) / (n - 1), 1.0), domain_size=n, domain_length=1.0, fem_basis_deg=2)

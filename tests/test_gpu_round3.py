@@ -65,8 +65,8 @@ def test_cached_calls_are_bitwise_equal_and_follow_their_buffers(kw, B):
         ops.PoissonPlan(m.geom, u2, nu, f, None, [(bc.bool(), 0.0)], **kwargs)
 
 
-@pytest.mark.parametrize("nsd,sizes,world", [(2, (40, 37), 2), (2, (64, 64), 3), (3, (17, 19, 23), 2), (3, (16, 16, 23), 4)])
-def test_slab_path_takes_packed_masks_and_box_faces(nsd, sizes, world):
+@pytest.mark.parametrize("nsd,sizes,world,B", [(2, (40, 37), 2, 2), (2, (64, 64), 3, 1), (3, (17, 19, 23), 2, 2), (3, (16, 16, 23), 4, 1)])
+def test_slab_path_takes_packed_masks_and_box_faces(nsd, sizes, world, B):
     """SlabPoisson with the compact Dirichlet forms: a PackedMask is unpacked for the slab launches, BoxFaces name faces of
     the GLOBAL box -- the faces across the decomposed axis exist on the outermost ranks only.  The ranks are emulated in-process (the
     prepared launches of every rank run on this GPU; no collective): the shares of the loss add up to the global loss, interior
@@ -77,7 +77,6 @@ def test_slab_path_takes_packed_masks_and_box_faces(nsd, sizes, world):
     lengths = (1.0, 0.8, 1.3)[:nsd]
     kw = dict(nsd=nsd, domain_sizes=sizes + (1,) * (3 - nsd), domain_lengths=lengths + (1.0,) * (3 - nsd), domain_size=sizes[0])
     m = module(kw)
-    B = 2
     shape = (B, 1, *m.geom.node_shape)
     u, nu, f = cu(seeded(shape, 41)), cu(seeded(shape, 42) + 0.5), cu(seeded(shape, 43))
     src = (seeded(shape, 44) < 0.04).to(torch.uint8).to(dev())
@@ -100,7 +99,11 @@ def test_slab_path_takes_packed_masks_and_box_faces(nsd, sizes, world):
             close(lo.launch()[0][:, :, 0], grad[:, :, 0].cpu().numpy(), rtol=1e-6, arel=1e-6)
         if hi is not None:
             close(hi.launch()[0][:, :, 1], grad[:, :, -1].cpu().numpy(), rtol=1e-6, arel=1e-6)
-        assert (lo is None) == (r == 0) and (hi is None) == (r == world - 1)
+        # (prepared thin launches exist at batch 1, where the two node layers under a face are a contiguous view of the slab tensors)
+        assert (lo is None) == (r == 0 or B > 1) and (hi is None) == (r == world - 1 or B > 1)
+        if B > 1 and r > 0:
+            part = sp._thin_part(slice(0, 2), 0, ul, nul, fl, local, 0.7, 1.0, scale)
+            close(part, grad[:, :, 0].cpu().numpy(), rtol=1e-6, arel=1e-6)
         with pytest.raises(Exception, match="contiguous"):
             sp._plans(ul[..., ::2], nul, fl, cond, 0.7, 1.0, scale)
     np.testing.assert_allclose(total, float(lref), rtol=2e-6)
@@ -141,7 +144,7 @@ def test_measurement_probes_compute_what_they_say():
     for mode in range(12):
         out = torch.full_like(a, float("nan"))
         assert L.dn_probe_stream(a.data_ptr(), b.data_ptr(), c.data_ptr(), out.data_ptr(), a.numel(), mode, stream) == 0
-        assert torch.equal(out, a * b + c), mode
+        assert torch.allclose(out, a * b + c, rtol=1e-6, atol=1e-7), mode          # (the kernel contracts a * b + c into one fma)
     for flags in (4, 5, 7, 12, 21, 29, 36, 44):
         for R, D in ((16, 1), (16, 2), (8, 3), (32, 4)):
             out = torch.full_like(a, float("nan"))
@@ -181,3 +184,28 @@ def test_fsdt_chained_strips_equal_single_strips(deg, ngp, sizes, B):
                 np.testing.assert_allclose(norms.cpu().numpy(), np.sqrt(rsums.cpu().numpy()), rtol=1e-6)
     finally:
         _lib.config_set("PLAN_FSDT", "")
+
+
+def test_fsdt_q2_middle_point_form_equals_the_generic_form():
+    """Q2 with the symmetric 3-point rule runs an element routine in which the contractions at the middle Gauss point (basis (0, 1, 0),
+    derivative (-d, 0, d)) are spelled as copies and differences; dn_config_set("FSDT_GENERIC") runs the table-driven routine.  Same
+    numbers to rounding (d (F2 - F0) against d F2 + (-d) F0 + 0 F1: one rounding less)."""
+    from diffnet_amd import _lib, ops
+    m = module(dict(domain_size=129, fem_basis_deg=2, ngp_1d=3))
+    shape = (2, 1, 129, 129)
+    flds = [cu(seeded(shape, 60 + i)) for i in range(3)]
+    bc = boundary_mask(shape).to(dev())
+    consts = dict(D11=1.3, D12=0.4, D22=1.1, D66=0.6, A44=0.8, A55=0.9, q=1.2, wscale=0.3)
+    try:
+        for plan in ("192,4", "64,3,4"):
+            _lib.config_set("PLAN_FSDT", plan)
+            a, sa = ops.fsdt_apply(m.geom, *flds, bc, (0.0, 0.1, 0.0), **consts)
+            _lib.config_set("FSDT_GENERIC", "1")
+            b, sb = ops.fsdt_apply(m.geom, *flds, bc, (0.0, 0.1, 0.0), **consts)
+            _lib.config_set("FSDT_GENERIC", "")
+            for x, y in zip(a, b):
+                assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()), plan
+            np.testing.assert_allclose(sa.cpu().numpy(), sb.cpu().numpy(), rtol=1e-6)
+    finally:
+        _lib.config_set("PLAN_FSDT", "")
+        _lib.config_set("FSDT_GENERIC", "")

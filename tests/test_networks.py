@@ -70,9 +70,12 @@ def _param_stats(grads):
 
 def _check_stats(got, ref, names, rel):
     """Every parameter's gradient: norm to `rel`, sum and random projection to `rel` x norm x a factor for the number of terms."""
+    # gradients that are zero in exact arithmetic (a bias in front of an InstanceNorm: the AE's convolutions) are rounding noise of the
+    # order 1e-7 of the network's largest gradient in both implementations: compared against that floor, not against each other
+    floor = 1e-5 * float(ref[:, 1].max())
     for k, name in enumerate(names):
-        norm = ref[k, 1]
-        assert abs(got[k, 1] - norm) <= rel * norm + 1e-12, f"{name}: |grad| {got[k, 1]} vs {norm}"
+        norm = max(ref[k, 1], floor)
+        assert abs(got[k, 1] - ref[k, 1]) <= rel * norm + 1e-12, f"{name}: |grad| {got[k, 1]} vs {ref[k, 1]}"
         for c in (0, 2):
             assert abs(got[k, c] - ref[k, c]) <= 4.0 * rel * norm + 1e-12, f"{name}: statistic {c}: {got[k, c]} vs {ref[k, c]} (|grad| {norm})"
 
@@ -147,8 +150,9 @@ def test_train_mode_hip_blocks_equal_stock_modules_gpu(name):
     assert float((y_hip - y_ref).abs().max()) > 0.0 or name.startswith("ae")      # two different code paths really ran
     np.testing.assert_allclose(y_hip.detach().cpu().numpy(), y_ref.detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
     names = ["x"] + [k for k, _ in net.named_parameters()]
+    floor = 1e-5 * max(float(b.abs().max()) for b in g_ref[1:])       # exactly-zero gradients (bias in front of InstanceNorm) are noise in both
     for n, a, b in zip(names, g_hip, g_ref):
-        scale = float(b.abs().max()) + 1e-30
+        scale = max(float(b.abs().max()), floor)
         assert float((a - b).abs().max()) <= 2e-3 * scale, f"{name} {n}: {float((a - b).abs().max())} vs scale {scale}"
     # and the dropout really was live: a second seed gives another output
     torch.manual_seed(1)
