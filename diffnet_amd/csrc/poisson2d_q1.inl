@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256, DN_Q1_2D_WAVES) poisson2d_q1_raw_kernel(c
     constexpr bool BC_ANY = (FL & (FL_BC | FL_BC_U8C)) != 0, BC_U8C = (FL & FL_BC_U8C) != 0;
     const int T = blockDim.x;
     const int tid = threadIdx.x;
-    const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+    const int chunk = blockIdx.x, strip = selected_strip(p, (int)blockIdx.y), b = blockIdx.z;
     const int q = chunk * (T - 1) + tid;
     const int ex0 = q * E;
     const int x0 = ex0;

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     }
     const int chunk = (int)(lid % gridDim.x), strip = (int)((lid / gridDim.x) % gridDim.y), b = (int)(lid / (gridDim.x * gridDim.y));
 #else
-    const int chunk = blockIdx.x, strip = (int)blockIdx.y * W + sub, b = blockIdx.z;
+    const int chunk = blockIdx.x, strip = W > 1 ? (int)blockIdx.y * W + sub : selected_strip(p, (int)blockIdx.y), b = blockIdx.z;      // (chained launches cover every strip)
 #endif
     const bool active = W == 1 || strip < p.nstrips;                         // the last workgroup of a sample may hold fewer than W strips
     const bool chain_dn = W > 1 && sub > 0;                                  // the strip below is in this workgroup

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256, NGP == 4 ? 2 : (T16 ? (NGP == 2 ? ((FL & 
     lid /= (unsigned)chunks_x;
     const int tile = (int)(lid % (unsigned)tiles_y);
     lid /= (unsigned)tiles_y;
-    const int strip = (int)(lid % (unsigned)strips_z), b = (int)(lid / (unsigned)strips_z);
+    const int strip = selected_strip(p, (int)(lid % (unsigned)strips_z)), b = (int)(lid / (unsigned)strips_z);
     const int q = chunk * (TX - 1) + tx;
     const int ex0 = q * E, x0 = ex0;
     const int ey = tile * (TY - 1) + ty;
@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
     lid /= (unsigned)chunks_x;
     const int tile = (int)(lid % (unsigned)tiles_y);
     lid /= (unsigned)tiles_y;
-    const int strip = (int)(lid % (unsigned)strips_z), b = (int)(lid / (unsigned)strips_z);
+    const int strip = selected_strip(p, (int)(lid % (unsigned)strips_z)), b = (int)(lid / (unsigned)strips_z);
     const int nx0 = chunk * 15, ny0 = tile * 15;               // first node of the tile
     const int x0 = nx0 + tx, ey = ny0 + ty;                    // the thread's node == lower-left node of its element
     const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);

@@ -36,9 +36,16 @@ struct PoissonParams {
     int nx, ny, nz;        // nodes
     int nelx, nely, nelz;  // elements
     int rows_per_strip;    // element layers per strip along the marched axis
-    int nstrips;           // 2-D: strips per sample (chained launches: the last workgroup of a sample may hold fewer than W)
+    int nstrips;           // strips per sample along the marched axis (the whole mesh, whatever the launch selects)
+    int strip_sel;         // 0: the launch covers every strip; 1: only the first and the last one; 2: all but those (dn_poisson_args.strip_select)
+    int acc_sums;          // the final scalars are ADDED to what energy / sumsq hold (the second launch of a split evaluation)
     int want_sums;
 };
+
+// strip index of the idx-th launched strip (split evaluations launch a subset of the strips: PoissonParams::strip_sel)
+__device__ __forceinline__ int selected_strip(const PoissonParams& p, int idx) {
+    return p.strip_sel == 1 ? (idx == 0 ? 0 : p.nstrips - 1) : (p.strip_sel == 2 ? idx + 1 : idx);
+}
 
 // Per-sample base pointers (wave-uniform): all in-kernel indexing is a 32-bit offset from these.
 struct SampleBases {
@@ -182,6 +189,10 @@ __device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, fl
         }
         block_sum2(e, s, red, tid, nthreads);
         if (tid == 0) {
+            if (p.acc_sums) {         // second launch of a split evaluation (host checks that both double slots exist): fixed order, first + second
+                e += *p.energy;
+                s += *p.sumsq;
+            }
             if (p.energy) *p.energy = e;
             if (p.sumsq) *p.sumsq = s;
             if (p.energy_f32) *p.energy_f32 = (float)(e * p.energy_scale);

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) poisson2d_kernel(const PoissonParams p) {
     constexpr int NW = E * P;             // nodes owned per thread per node row
     const int T = blockDim.x;
     const int tid = threadIdx.x;
-    const int chunk = blockIdx.x, strip = blockIdx.y, b = blockIdx.z;
+    const int chunk = blockIdx.x, strip = selected_strip(p, (int)blockIdx.y), b = blockIdx.z;
     const int q = chunk * (T - 1) + tid;  // logical thread column (chunks overlap by one thread)
     const int ex0 = q * E;                // first element of this thread
     const int x0 = ex0 * P;               // first node
@@ -481,17 +481,28 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.want_sums = want_red ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
+    // split evaluation (dn_poisson_args.strip_select): a launch over the first and the last strip of the marched axis, or over the rest
+    if (a->strip_select < 0 || a->strip_select > 2) return DN_E_BADARG;
+    if (a->accumulate_sums && want_red && !(a->energy && a->sumsq)) return DN_E_BADARG;      // the running sums live in the two double slots
+    pp.strip_sel = a->strip_select;
+    pp.acc_sums = (a->accumulate_sums && want_red) ? 1 : 0;
+    auto launched = [&](int total) { return a->strip_select == 1 ? std::min(total, 2) : (a->strip_select == 2 ? std::max(total - 2, 0) : total); };
     if (m->nsd == 2) {
-        const Geom2D g = plan2d_env(m, P, allow_e4);
+        Geom2D g = plan2d_env(m, P, allow_e4);
         pp.rows_per_strip = g.R;
         pp.nstrips = g.strips;
+        if (a->strip_select) g.W = 1;
+        g.strips = launched(g.strips);
+        if (g.strips == 0) return 0;                         // fewer than three strips: the other launch did everything
         const int NW = g.E * P;
         const bool vec = vec_ok(NW);
         rc = launch2d(pp, g, P, m->ngp, m->batch, vec, s);
     } else {
-        const Geom3D g = plan3d_env(m);
+        Geom3D g = plan3d_env(m);
         pp.rows_per_strip = g.R;
         pp.nstrips = g.strips;
+        g.strips = launched(g.strips);
+        if (g.strips == 0) return 0;
         const int NW = g.E;
         const bool vec = vec_ok(NW);
         switch (m->ngp) {

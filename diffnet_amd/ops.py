@@ -386,11 +386,19 @@ class PoissonPlan:
     host-side preparation -- and for anything captured into a HIP graph.  Outputs are overwritten by every launch."""
 
     def __init__(self, geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
-                 out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None, strict=True):
+                 out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None, strict=True, strip_select=0, continues=None):
+        """strip_select 1 / 2: the launch covers only the first + last strip of the marched axis / all the others (include/diffnet_hip.h:
+        split evaluation); `continues`: the PoissonPlan of the first launch of such a pair -- this one writes into its outputs and adds
+        its sums to that launch's."""
         # strict: every tensor argument must be usable as it is (contiguous float32 fields, float32 / uint8 mask images) -- a conversion
         # would be a one-time copy that later launches keep reading after the caller has updated the original in place
+        if continues is not None:
+            out = continues.result[0]
         self.mesh, self.args, self.keep, self.result = _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale,
-                                                                        want_out, want_sums, loss_scale, out, strict=strict)
+                                                                        want_out, want_sums, loss_scale, out, strict=strict,
+                                                                        reuse=None if continues is None else continues.result)
+        self.args.strip_select = int(strip_select)
+        self.args.accumulate_sums = int(continues is not None)
         self.device = u.device
         self.stream = torch.cuda.current_stream(u.device).cuda_stream      # the reduction workspace belongs to this stream
         self._fn = _lib.lib().dn_poisson_apply
@@ -406,7 +414,7 @@ class PoissonPlan:
         return self.result
 
 
-def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out, strict=False):
+def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out, strict=False, reuse=None):
     """Validation + argument structs of one dn_poisson_apply call: (mesh, args, tensors to keep alive, result tuple)."""
     nsd = geom.nsd
     u = _require(u, "u", nsd + 2, strict)
@@ -504,7 +512,7 @@ def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, ou
     if out is not None:
         args.out = out.data_ptr()
     if want_sums:
-        sums = torch.empty(2, dtype=torch.float64, device=u.device)
+        sums = reuse[1] if reuse is not None else torch.empty(2, dtype=torch.float64, device=u.device)
         key = (mesh.nsd, mesh.degree, mesh.ngp, mesh.nx, mesh.ny, mesh.nz, B)
         nbytes = _POISSON_WS_BYTES.get(key)
         if nbytes is None:
@@ -521,7 +529,7 @@ def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, ou
     if loss_scale is not None:
         if not want_sums:
             raise ValueError("loss_scale needs want_sums=True")
-        loss32 = torch.empty((), dtype=torch.float32, device=u.device)
+        loss32 = reuse[2] if reuse is not None else torch.empty((), dtype=torch.float32, device=u.device)
         args.energy_f32, args.energy_scale = loss32.data_ptr(), float(loss_scale)
     keep += [t for t in (out, sums, loss32) if t is not None]
     return mesh, args, keep, ((out, sums, loss32) if loss_scale is not None else (out, sums))

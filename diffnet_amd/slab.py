@@ -13,9 +13,9 @@ Exchange steps per loss evaluation -- nothing else crosses GPUs:
     asynchronous; the loss is sum / (B * nel_GLOBAL), not a mean of per-rank means (slabs may differ by one layer);
   * backward: the gradient on an interface layer is the sum of both neighbours' contributions: one
     point-to-point exchange of a single node layer per interior face (256 KiB at 256^3), added in a fixed
-    order (lower rank's part first) so both replicas are bitwise identical.  Each rank's own part comes from a thin
-    launch over the one element layer under the face, so the transfers are in flight (side stream, pre-allocated
-    buffers) while the slab kernel runs.
+    order (lower rank's part first) so both replicas are bitwise identical.  The slab is evaluated in two launches -- the
+    strips next to the faces first, then the interior (SlabPoisson) -- so the transfers are in flight (side stream,
+    pre-allocated buffers) while the interior is computed, and nothing is computed twice.
 """
 import torch
 import torch.distributed as dist
@@ -179,55 +179,22 @@ def slab_energy_loss_and_grad(dec, local_sum_and_grad, batch, group=None, interf
 
 
 class SlabPoisson:
-    """Slab-parallel fused Poisson energy on the GPU: the per-rank FEM module + the two exchange steps.  Per evaluation:
-    two thin launches (the element layer under each interior face -> this rank's part of the interface-layer gradient), the
-    layer exchange started on a side stream, the slab kernel on the main stream, the 4-byte loss all-reduce (asynchronous),
-    then one small add per face."""
+    """Slab-parallel fused Poisson energy on the GPU: the per-rank FEM module + the two exchange steps.  Per evaluation TWO launches of
+    the fused kernel on the slab, nothing computed twice: first the strips next to the two faces across the decomposed axis (C ABI:
+    dn_poisson_args.strip_select = 1) -- after it this rank's parts of its interface layers are final, and their exchange with the
+    neighbouring ranks starts on a side stream --, then all the other strips (strip_select = 2, sums added to the first launch's),
+    which the exchange overlaps; the 4-byte loss all-reduce (asynchronous); one small add per face."""
 
     def __init__(self, nsd, sizes_xyz, lengths_xyz, rank, world, ngp_1d=2, group=None, device=None, overlap=True):
         from . import DiffNet2DFEM, DiffNet3DFEM
         self.dec = SlabDecomposition(nsd, sizes_xyz, lengths_xyz, rank, world)
         cls = DiffNet3DFEM if nsd == 3 else DiffNet2DFEM
         self.fem = cls(None, **self.dec.local_kwargs(ngp_1d=ngp_1d))
-        # one element layer: the module that evaluates the face-adjacent layer alone (same h => same tables)
-        slow = nsd - 1
-        h = self.dec.local_lengths[slow] / (self.dec.e1 - self.dec.e0)
-        thin = SlabDecomposition(nsd, sizes_xyz, lengths_xyz, rank, world)
-        thin.local_sizes = self.dec.local_sizes[:slow] + (2,)
-        thin.local_lengths = self.dec.local_lengths[:slow] + (h,)
-        self.fem_thin = cls(None, **thin.local_kwargs(ngp_1d=ngp_1d))
         if device is not None:
-            self.fem, self.fem_thin = self.fem.to(device), self.fem_thin.to(device)
+            self.fem = self.fem.to(device)
         self.group = group
         self.overlap = overlap and world > 1
         self.exchange = InterfaceExchange(self.dec, group)
-
-    @staticmethod
-    def _cut(t, sl):
-        return None if t is None else (t[:, :, sl].contiguous() if t.shape[2] > 2 else t)
-
-    def _thin_part(self, sl, keep, u, nu, f, dirichlet, c, jac, scale):
-        from . import ops
-        d = [ops.Dirichlet(self._cut(x.mask, sl), self._cut(x.value, sl) if isinstance(x.value, torch.Tensor) and x.value.dim() == u.dim()
-                           else x.value) for x in ops._norm_dirichlet(dirichlet)]
-        g, _ = ops.poisson_apply(self.fem_thin.geom, self._cut(u, sl), self._cut(nu, sl), self._cut(f, sl), None, d, alpha=2.0 * c, beta=1.0,
-                                 c=c, wscale=jac, out_scale=scale, want_out=True, want_sums=False)
-        return g[:, :, keep]
-
-    def _thin_plan(self, sl, u, nu, f, dirichlet, c, jac, scale):
-        """Prepared launch over the one element layer next to a face, or None when the two node layers are not a contiguous view of
-        the slab tensors (batch > 1: the cut would be a copy made per evaluation)."""
-        from . import ops
-        cut = lambda t: None if t is None else t[:, :, sl]
-        mcut = lambda mk: mk if mk.shape[2] <= 2 else cut(mk)          # (BoxFaces images are (1,1,*N): one sample, contiguous cuts)
-        views = [cut(u), cut(nu), cut(f)] + [mcut(x.mask) for x in ops._norm_dirichlet(dirichlet)]
-        if any(v is not None and not v.is_contiguous() for v in views):
-            return None
-        if any(isinstance(x.value, torch.Tensor) for x in ops._norm_dirichlet(dirichlet)):
-            return None
-        d = [ops.Dirichlet(mcut(x.mask), x.value) for x in ops._norm_dirichlet(dirichlet)]
-        return ops.PoissonPlan(self.fem_thin.geom, cut(u), cut(nu), cut(f), None, d, alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale,
-                               want_out=True, want_sums=False)
 
     def _local_conditions(self, dirichlet, like):
         """Dirichlet conditions in the form the slab launches take: tensor images of the LOCAL slab.  A PackedMask (given for the local
@@ -253,8 +220,9 @@ class SlabPoisson:
 
     def _plans(self, u_local, nu, f, dirichlet, c, jac, scale):
         """The step's launches prepared once per set of buffers (ops.PoissonPlan): at 256^3 over 8 ranks a rank's kernels take ~30 us,
-        the host-side preparation of three dn_poisson_apply calls ~75 us.  Re-prepared when a buffer, shape or coefficient changes.
-        Returns (main, lo, hi, local conditions)."""
+        the host-side preparation of the dn_poisson_apply calls more.  Re-prepared when a buffer, shape or coefficient changes.
+        Returns (first launch, second launch | None, local conditions): with the overlapped exchange the first launch covers the strips
+        next to the faces, the second the rest; otherwise one launch covers the slab."""
         from . import ops
         dl = ops._norm_dirichlet(dirichlet)
         for name, t in (("u_local", u_local), ("nu", nu), ("f", f)) + tuple(("Dirichlet mask", x.mask) for x in dl) + tuple(("Dirichlet value", x.value) for x in dl):
@@ -267,11 +235,10 @@ class SlabPoisson:
         if getattr(self, "_plan_key", None) != key:
             dec = self.dec
             local = self._local_conditions(dl, u_local)
-            main = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, local, alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale,
-                                   want_out=True, want_sums=True, loss_scale=scale)
-            lo = self._thin_plan(slice(0, 2), u_local, nu, f, local, c, jac, scale) if (self.overlap and dec.rank > 0) else None
-            hi = self._thin_plan(slice(-2, None), u_local, nu, f, local, c, jac, scale) if (self.overlap and dec.rank + 1 < dec.world) else None
-            self._plan_key, self._plan = key, (main, lo, hi, local)
+            kw = dict(alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
+            first = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, local, strip_select=1 if self.overlap else 0, **kw)
+            rest = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, local, strip_select=2, continues=first, **kw) if self.overlap else None
+            self._plan_key, self._plan = key, (first, rest, local)
         return self._plan
 
     def energy_loss_and_grad(self, u_local, nu=None, f=None, dirichlet=(), c=1.0, jac=1.0):
@@ -280,27 +247,18 @@ class SlabPoisson:
         B = u_local.shape[0]
         dec = self.dec
         scale = 1.0 / (B * dec.nel_global)
-        main, plan_lo, plan_hi, dirichlet = self._plans(u_local, nu, f, dirichlet, c, jac, scale)      # conditions as local tensor images
-
-        def parts():
-            lo = hi = None
-            if dec.rank > 0:
-                lo = plan_lo.launch()[0][:, :, 0] if plan_lo is not None else self._thin_part(slice(0, 2), 0, u_local, nu, f, dirichlet, c, jac, scale)
-            if dec.rank + 1 < dec.world:
-                hi = plan_hi.launch()[0][:, :, 1] if plan_hi is not None else self._thin_part(slice(-2, None), 1, u_local, nu, f, dirichlet, c, jac, scale)
-            return lo, hi
-
-        # same sequence as slab_energy_loss_and_grad, with the loss taken from the launch itself: the kernel writes
-        # energy_local / (B * nel_global) as float32, the all-reduce sums those shares (no clone / divide / cast kernels per step)
+        first, rest, _ = self._plans(u_local, nu, f, dirichlet, c, jac, scale)
+        # the loss is taken from the launches themselves: the kernel writes energy_local / (B * nel_global) as float32, the all-reduce sums
+        # those shares (no clone / divide / cast kernels per step)
         ex = self.exchange
-        started = False
-        if dec.world > 1 and self.overlap:
-            ex.start(*parts())
-            started = True
-        grad, _, loss = main.launch()
+        grad, _, loss = first.launch()
+        if rest is not None:
+            # this rank's parts of its two interface layers are final: start their exchange (side stream), then compute the interior
+            ex.start(grad[:, :, 0] if dec.rank > 0 else None, grad[:, :, -1] if dec.rank + 1 < dec.world else None)
+            rest.launch()
         if dec.world > 1:
             work = dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            if not started:
+            if rest is None:
                 ex.start(grad[:, :, 0] if dec.rank > 0 else None, grad[:, :, -1] if dec.rank + 1 < dec.world else None)
             ex.finish(grad)
             work.wait()

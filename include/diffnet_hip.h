@@ -131,6 +131,13 @@ typedef struct dn_poisson_args {
     float *energy_f32;     /* optional device scalar: (float)(energy * energy_scale), e.g. the mean loss, written by the
                               same launch (saves the caller two elementwise kernels per evaluation); needs workspace  */
     double energy_scale;
+    /* Split evaluation (no reference counterpart; the slab-parallel path, diffnet_amd/slab.py): the marched axis (y in 2-D, z in 3-D) is
+     * cut into strips by the launch plan.  strip_select 1 launches only the first and the last strip -- the node layers next to the two
+     * faces across the marched axis are complete after it, so their exchange with the neighbouring ranks can start --, 2 launches all the
+     * other strips; 0 (default) all of them.  The two launches write disjoint parts of `out`.  accumulate_sums != 0: the final scalars
+     * are added to what `energy` / `sumsq` (both required then) already hold and energy_f32 is formed from the running energy: launch 1
+     * with accumulate_sums = 0, then launch 2 with 1, on one stream, gives the sums of the whole mesh in a fixed order. */
+    int32_t strip_select, accumulate_sums;
 } dn_poisson_args;
 
 int dn_abi_version(void);

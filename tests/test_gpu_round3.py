@@ -69,8 +69,9 @@ def test_cached_calls_are_bitwise_equal_and_follow_their_buffers(kw, B):
 def test_slab_path_takes_packed_masks_and_box_faces(nsd, sizes, world, B):
     """SlabPoisson with the compact Dirichlet forms: a PackedMask is unpacked for the slab launches, BoxFaces name faces of
     the GLOBAL box -- the faces across the decomposed axis exist on the outermost ranks only.  The ranks are emulated in-process (the
-    prepared launches of every rank run on this GPU; no collective): the shares of the loss add up to the global loss, interior
-    layers of the slab gradients equal the global gradient, interface layers are the sum of the two neighbours' parts.  Uneven slabs
+    prepared launches of every rank run on this GPU; no collective): the two launches of a rank's evaluation (face strips, then the
+    interior) leave the interface layers final after the first; the shares of the loss add up to the global loss, interior layers of
+    the slab gradients equal the global gradient, interface layers are the sum of the two neighbours' parts.  Uneven slabs
     (22 element layers over 4 ranks: 6 / 6 / 5 / 5) included."""
     from diffnet_amd import BoxFaces, PackedMask
     from diffnet_amd.slab import SlabPoisson
@@ -89,21 +90,16 @@ def test_slab_path_takes_packed_masks_and_box_faces(nsd, sizes, world, B):
         ul, nul, fl = dec.take(u), dec.take(nu), dec.take(f)
         cond = [(PackedMask.pack(dec.take(src)), 1.0), (box, 0.0)]
         scale = 1.0 / (B * dec.nel_global)
-        main, lo, hi, local = sp._plans(ul, nul, fl, cond, 0.7, 1.0, scale)
-        assert all(isinstance(d.mask, torch.Tensor) for d in local)
-        grad, _, loss = main.launch()
+        first, rest, local = sp._plans(ul, nul, fl, cond, 0.7, 1.0, scale)
+        assert all(isinstance(d.mask, torch.Tensor) for d in local) and rest is not None
+        grad, _, loss = first.launch()
+        # after the first launch (the strips next to the faces) this rank's parts of its interface layers are final ...
+        face_lo, face_hi = grad[:, :, 0].clone(), grad[:, :, -1].clone()
+        g2, _, loss2 = rest.launch()
+        assert g2.data_ptr() == grad.data_ptr() and loss2.data_ptr() == loss.data_ptr()      # ... the second launch fills in the rest
+        assert torch.equal(grad[:, :, 0], face_lo) and torch.equal(grad[:, :, -1], face_hi)
         total += float(loss)
         gsum[:, :, dec.n0:dec.n1 + 1] += grad
-        # the thin launches (one element layer under each interior face) give this rank's part of the interface layers
-        if lo is not None:
-            close(lo.launch()[0][:, :, 0], grad[:, :, 0].cpu().numpy(), rtol=1e-6, arel=1e-6)
-        if hi is not None:
-            close(hi.launch()[0][:, :, 1], grad[:, :, -1].cpu().numpy(), rtol=1e-6, arel=1e-6)
-        # (prepared thin launches exist at batch 1, where the two node layers under a face are a contiguous view of the slab tensors)
-        assert (lo is None) == (r == 0 or B > 1) and (hi is None) == (r == world - 1 or B > 1)
-        if B > 1 and r > 0:
-            part = sp._thin_part(slice(0, 2), 0, ul, nul, fl, local, 0.7, 1.0, scale)
-            close(part, grad[:, :, 0].cpu().numpy(), rtol=1e-6, arel=1e-6)
         with pytest.raises(Exception, match="contiguous"):
             sp._plans(ul[..., ::2], nul, fl, cond, 0.7, 1.0, scale)
     np.testing.assert_allclose(total, float(lref), rtol=2e-6)
@@ -209,3 +205,42 @@ def test_fsdt_q2_middle_point_form_equals_the_generic_form():
     finally:
         _lib.config_set("PLAN_FSDT", "")
         _lib.config_set("FSDT_GENERIC", "")
+
+
+@pytest.mark.parametrize("kw,B,cfg", [(dict(domain_size=512, ngp_1d=3), 3, None), (dict(domain_size=96, ngp_1d=2), 2, ("Q1_RULE_KERNEL", "1")),
+                                      (dict(domain_size=129, ngp_1d=3, fem_basis_deg=2), 1, None), (dict(domain_size=65, nsd=3), 2, None),
+                                      (dict(domain_size=65, nsd=3), 1, ("Q1_3D_T16", "1")), (dict(domain_size=33, nsd=3, ngp_1d=3), 1, None),
+                                      (dict(domain_size=9, nsd=3), 1, None)])
+def test_split_evaluation_equals_one_launch(kw, B, cfg):
+    """dn_poisson_args.strip_select: the launch over the first + last strip of the marched axis followed by the launch over the other
+    strips (sums accumulated) is the one-launch evaluation -- the gradient bitwise (the two launches write disjoint strips, every strip
+    is computed exactly as in the full launch), the loss to the rounding of one more addition.  Every kernel family that marches strips:
+    closed-form and per-point 2-D Q1, generic Q2, the two 3-D forms, a 3-point rule, and a mesh with fewer than three strips."""
+    from diffnet_amd import _lib, ops
+    m = module(kw)
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = cu(seeded(shape, 51)), cu(seeded(shape, 52) + 0.5), cu(seeded(shape, 53))
+    bc = boundary_mask((1,) + shape[1:]).to(torch.uint8).to(dev())
+    scale = 1.0 / (B * m.geom.nelem_total)
+    kwargs = dict(alpha=2.0, beta=1.0, c=1.0, wscale=1.0, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
+    if cfg:
+        _lib.config_set(*cfg)
+    try:
+        ref = [t.clone() for t in ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], **kwargs).launch()]
+        first = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], strip_select=1, **kwargs)
+        rest = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], strip_select=2, continues=first, **kwargs)
+        first.result[0].fill_(float("nan"))
+        first.launch()
+        part = first.result[0].clone()
+        out, sums, loss = rest.launch()
+        assert torch.equal(out, ref[0])
+        done = ~torch.isnan(part)                   # what the first launch wrote is final (meshes of one or two strips: everything)
+        assert torch.equal(part[done], ref[0][done]) and bool(done[:, :, 0].all()) and bool(done[:, :, -1].all())
+        np.testing.assert_allclose(sums.cpu().numpy(), ref[1].cpu().numpy(), rtol=1e-12)
+        np.testing.assert_allclose(float(loss), float(ref[2]), rtol=2e-7)
+        with pytest.raises(Exception):
+            bad = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], strip_select=3, **kwargs)
+            bad.launch()
+    finally:
+        if cfg:
+            _lib.config_set(cfg[0], "")
