@@ -530,7 +530,7 @@ def main():
     torch.cuda.synchronize()
     steady_region_ms = rot_region[0].elapsed_time(rot_region[1]) / (2 * K)
     # side fields: the same launch re-evaluating ONE batch (Infinity-Cache assisted: what rounds 1 and 2 reported as the step), and the
-    # rotation with the mask held in the other formats (median of 40)
+    # rotation with the mask held in the other formats (median of 60 after 200 untimed launches)
     for _ in range(50):
         rot[0].launch()
     same_ms = sorted(timed_pairs(rot[0].launch, K)[0])
@@ -544,9 +544,9 @@ def main():
                 pls[t[0]].launch()
                 t[0] = (t[0] + 1) % NROT
 
-            for _ in range(20):
+            for _ in range(200):          # 12 ms under load first: a few warm-up launches would leave the timed ones in the load-onset transient
                 go()
-            bc_forms_us[name] = round(sorted(timed_pairs(go, 40)[0])[20] * 1e3, 2)
+            bc_forms_us[name] = round(sorted(timed_pairs(go, 60)[0])[30] * 1e3, 2)
             del pls
     # stream ceiling: a plain streaming kernel (dn_probe_stream: out = a * b + c, 16-byte vectors) over the SAME arrays and rotation --
     # three arrays read once, one written once; best of its forms / cache policies

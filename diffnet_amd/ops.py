@@ -30,8 +30,14 @@ def _require(t, name, ndim=None, strict=False):
     return t.contiguous()
 
 
+def _raw_stream(device):
+    """The current HIP stream of `device` as an integer handle (torch.cuda.current_stream() builds a Stream object: ~8 us per call,
+    more than the rest of a cached launch)."""
+    return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+
+
 def _stream(t):
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(_raw_stream(t.device))
 
 
 def _p(t):
@@ -262,7 +268,7 @@ def _workspace(dev, nbytes):
     """The reduction workspace of (device, current stream): launches on one stream are ordered, so they may share it; a launch on
     another stream gets its own (the ABI asks for one workspace per concurrently used stream).  A prepared launch (PoissonPlan)
     keeps the workspace of the stream it was prepared on and must be launched on that stream."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _raw_stream(dev))
     with _WS_LOCK:
         ws = _WS.get(key)
         if ws is None or ws.numel() < nbytes:
@@ -293,7 +299,7 @@ def _tkey(t):
 
 
 def _call_key(geom, u, nu, f, f_gp, dl, scal, want_out, want_sums, out):
-    parts = [geom.key, u.device.index, torch.cuda.current_stream(u.device).cuda_stream, scal, want_out, want_sums]
+    parts = [geom.key, u.device.index, _raw_stream(u.device), scal, want_out, want_sums]
     for t in (u, nu, f, f_gp, out):
         k = _tkey(t)
         if k is None or (k != 0 and k[1] != torch.float32):
@@ -400,12 +406,12 @@ class PoissonPlan:
         self.args.strip_select = int(strip_select)
         self.args.accumulate_sums = int(continues is not None)
         self.device = u.device
-        self.stream = torch.cuda.current_stream(u.device).cuda_stream      # the reduction workspace belongs to this stream
+        self.stream = _raw_stream(u.device)      # the reduction workspace belongs to this stream
         self._fn = _lib.lib().dn_poisson_apply
         self._mesh_ref, self._args_ref = C.byref(self.mesh), C.byref(self.args)
 
     def launch(self):
-        cur = torch.cuda.current_stream(self.device).cuda_stream
+        cur = _raw_stream(self.device)
         if self.args.workspace and cur != self.stream:
             raise DiffNetHipError("PoissonPlan.launch: prepared on another stream (its reduction workspace is per stream); prepare one plan per stream")
         rc = self._fn(self._mesh_ref, self._args_ref, C.c_void_p(cur))
@@ -617,14 +623,67 @@ def composed_residual(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), jac=1.0
     return R
 
 
+class _PoissonFn(torch.autograd.Function):
+    """(out, sums, loss) of one dn_poisson_apply launch, differentiable wrt u -- the eager counterpart of the registered operator
+    diffnet_mi::poisson_apply (torch_ops.py), whose dispatch costs ~100 us per call (204 -> ~60 us for an energy_loss + backward at
+    64^2, tools/host_profile.py); same formulas as torch_ops._pa_backward, and differentiable again (its backward calls `_fused`)."""
+
+    @staticmethod
+    def forward(ctx, u, nu, f, f_gp, geom, dl, alpha, beta, c, wscale, out_scale, loss_scale):
+        out, sums, loss = poisson_apply(geom, u, nu, f, f_gp, dl, alpha=alpha, beta=beta, c=c, wscale=wscale, out_scale=out_scale,
+                                        want_out=True, want_sums=True, loss_scale=loss_scale)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(out, nu)
+        ctx.meta = (geom, dl, alpha, beta, c, wscale, out_scale, loss_scale)
+        return out, sums, loss
+
+    @staticmethod
+    def backward(ctx, g_out, g_sums, g_loss):
+        out, nu = ctx.saved_tensors
+        geom, dl, alpha, beta, c, wscale, out_scale, loss_scale = ctx.meta
+        hom = tuple(Dirichlet(d.mask, 0.0) for d in dl)       # J = s alpha M K M is symmetric: J^T v is the same launch, homogeneous conditions, no forcing
+
+        def K(v, scale):
+            return _fused(geom, v, nu, None, None, hom, alpha, 0.0, 0.0, wscale, scale, 0.0)[0]
+
+        gu = None
+        if g_out is not None:
+            gu = K(g_out.contiguous(), out_scale)
+        coef = None
+        if g_loss is not None:
+            coef = g_loss * loss_scale
+        if g_sums is not None:
+            coef = g_sums[0].to(torch.float32) if coef is None else coef + g_sums[0].to(torch.float32)
+            t = K(out * (2.0 / out_scale), 1.0) * g_sums[1].to(torch.float32)
+            gu = t if gu is None else gu + t
+        if coef is not None:
+            if alpha != 2.0 * c or beta != 1.0:
+                if g_loss is not None or c != 0.0:
+                    raise RuntimeError("poisson_apply: the energy output is differentiable only in the energy-loss form (alpha = 2c, beta = 1)")
+            else:
+                t = out * (coef / out_scale)
+                gu = t if gu is None else gu + t
+        return (gu,) + (None,) * 11
+
+
 def _fused(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, loss_scale):
-    """(out, sums, loss) of one dn_poisson_apply launch as the registered operator diffnet_mi::poisson_apply: differentiable
-    wrt u through all three outputs (torch_ops._pa_backward), an ordinary node for torch.compile."""
-    from . import torch_ops
-    compact = (geom.nsd == 2 and geom.deg == 1 and f_gp is None and not _lib.CONFIG_MIRROR.get("Q1_RULE_KERNEL") and
-               all(not isinstance(d.value, torch.Tensor) for d in dirichlet))
-    return torch_ops.poisson_apply(u, nu, f, f_gp, *torch_ops.dirichlet_args(dirichlet, u, compact), *torch_ops.geometry_args(geom),
-                                   float(alpha), float(beta), float(c), float(wscale), float(out_scale), float(loss_scale))
+    """(out, sums, loss) of one dn_poisson_apply launch, differentiable wrt u through all three outputs.  Under torch.compile /
+    torch.export the registered operator diffnet_mi::poisson_apply (an ordinary graph node); in eager mode the same launch behind a
+    plain autograd.Function, or directly when nothing requires a gradient."""
+    if torch.compiler.is_compiling():
+        from . import torch_ops
+        compact = (geom.nsd == 2 and geom.deg == 1 and f_gp is None and not _lib.CONFIG_MIRROR.get("Q1_RULE_KERNEL") and
+                   all(not isinstance(d.value, torch.Tensor) for d in dirichlet))
+        return torch_ops.poisson_apply(u, nu, f, f_gp, *torch_ops.dirichlet_args(dirichlet, u, compact), *torch_ops.geometry_args(geom),
+                                       float(alpha), float(beta), float(c), float(wscale), float(out_scale), float(loss_scale))
+    for d in dirichlet:
+        if isinstance(d.mask, torch.Tensor) and d.mask.dtype == torch.int32:
+            raise TypeError("Dirichlet mask images are float32, uint8 or bool; int32 tensors are reserved for bit-packed masks (wrap them in ops.PackedMask)")
+    if torch.is_grad_enabled() and isinstance(u, torch.Tensor) and u.requires_grad:
+        return _PoissonFn.apply(u, nu, f, f_gp, geom, tuple(dirichlet), float(alpha), float(beta), float(c), float(wscale), float(out_scale),
+                                float(loss_scale))
+    return poisson_apply(geom, u, nu, f, f_gp, dirichlet, alpha=alpha, beta=beta, c=c, wscale=wscale, out_scale=out_scale, want_out=True,
+                         want_sums=True, loss_scale=loss_scale)
 
 
 def energy_loss(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), c=1.0, jac=1.0):
@@ -668,7 +727,7 @@ _FSDT_CACHE = __import__("collections").OrderedDict()
 
 def _fsdt_key(geom, flds, bc, bc_values, consts, in_scale, in_num, in_den, flags):
     """Key of a cached prepared dn_fsdt_apply call (see _call_key); None when an argument needs a conversion copy."""
-    parts = [geom.key, flds[0].device.index, torch.cuda.current_stream(flds[0].device).cuda_stream, consts, flags]
+    parts = [geom.key, flds[0].device.index, _raw_stream(flds[0].device), consts, flags]
     for t in flds:
         k = _tkey(t)
         if k is None or k == 0 or k[1] != torch.float32:
