@@ -394,6 +394,10 @@ def main():
     ap.add_argument("--nsd", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config leg (\"configs\")")
+    ap.add_argument("--async-sums", action="store_true",
+                    help="form the loss on a side stream under the next step's launch (PoissonPlan(async_sums=True)) instead of inside the launch "
+                         "(default: its last workgroup adds up the per-workgroup partial sums, a ~3 us serial tail).  Measured SLOWER: the event "
+                         "record / wait between the launches costs more than the tail (60.5 against 56.0 us per step, profiles/r3_async_sums.txt)")
     ap.add_argument("--bc", default="auto", choices=["auto", "bits", "u8", "f32", "box"],
                     help="how the Dirichlet condition is held (auto: one bit per node for 2-D, uint8 image for 3-D: general mask arrays)")
     ap.add_argument("--slab", action="store_true",
@@ -405,6 +409,7 @@ def main():
     ap.add_argument("--slab-batch", type=int, default=1, help="samples of the slab leg's mesh (BASELINE configs[3] is parametric: the reference trains it with batch 8)")
     ap.add_argument("--slab-timeout", type=float, default=180.0, help="watchdog of the slab leg, seconds")
     args = ap.parse_args()
+    args.sync_sums = not args.async_sums
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                                      # does not return
@@ -451,24 +456,40 @@ def main():
     forms = {"u8": lambda bc: [(bc, 0.0)], "f32": lambda bc: [(bc.float(), 0.0)], "bits": lambda bc: [(PackedMask.pack(bc), 0.0)],
              "box": lambda bc: [(BoxFaces("all"), 0.0)]}
 
-    def make_plans(form):
+    def make_plans(form, async_sums=None):
         # the prepared form of m.energy_loss_and_grad(u, nu, f, dirichlet, c) (diffnet_amd.ops.PoissonPlan: argument structs, outputs and
-        # workspace set up once, one ctypes call per launch)
+        # workspace set up once, one ctypes call per launch).  async_sums (--async-sums, not the default: measured slower): the launch writes
+        # the gradient and its per-workgroup partial sums; the loss is formed from them by a one-workgroup kernel on a side stream, i.e.
+        # under the NEXT step's launch
         return [_ops.PoissonPlan(m.geom, u, nu, f, None, forms[form](bc), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale0,
-                                 want_out=True, want_sums=True, loss_scale=scale0) for (u, nu, f, bc) in sets]
+                                 want_out=True, want_sums=True, loss_scale=scale0, async_sums=(not args.sync_sums) if async_sums is None else async_sums)
+                for (u, nu, f, bc) in sets]
 
     rot = make_plans(bc_form)
     turn = [0]
     pending = []
+    last = [None]
 
     def launch_rot():
         k = turn[0]
         turn[0] = (k + 1) % NROT
+        last[0] = rot[k]
         return rot[k].launch()
 
     def step():
         grad, _, loss = launch_rot()
-        if dist is not None:
+        if dist is not None and last[0].async_sums:
+            # the loss lives on the side stream: its all-reduce is issued there too, so that the launch stream never waits for it
+            with torch.cuda.stream(last[0].sums_stream):
+                if backend == "nccl":
+                    work = dist.all_reduce(loss, op=dist.ReduceOp.AVG, async_op=True)
+                else:
+                    loss.div_(world)
+                    work = dist.all_reduce(loss, async_op=True)
+            pending.append((work, loss))
+            if len(pending) > PIPE:
+                pending.pop(0)[0].wait()
+        elif dist is not None:
             # the path's only exchange step: all-reduce of the 4-byte loss (RCCL).  Issued asynchronously so that the
             # next evaluation's kernel does not queue behind the collective; waited PIPE steps later (a small-message
             # all-reduce over xGMI is latency-bound at tens of microseconds, comparable to one step) and drained
@@ -529,6 +550,20 @@ def main():
     rot_region[1].record()
     torch.cuda.synchronize()
     steady_region_ms = rot_region[0].elapsed_time(rot_region[1]) / (2 * K)
+    # side field: the same rotation with the loss formed inside the launch (in-kernel final reduction)
+    sync_ms = None
+    if not args.sync_sums and rank == 0:
+        pls = make_plans(bc_form, async_sums=False)
+        t = [0]
+
+        def go_sync():
+            pls[t[0]].launch()
+            t[0] = (t[0] + 1) % NROT
+
+        for _ in range(200):
+            go_sync()
+        sync_ms = sorted(timed_pairs(go_sync, K)[0])
+        del pls
     # side fields: the same launch re-evaluating ONE batch (Infinity-Cache assisted: what rounds 1 and 2 reported as the step), and the
     # rotation with the mask held in the other formats (median of 60 after 200 untimed launches)
     for _ in range(50):
@@ -611,6 +646,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "poisson fused kernel (one launch per dn_poisson_apply)", "kernel_avg_ms": kern_avg_ms,
+                         "sums": ("the loss of a step is formed from the launch's per-workgroup partial sums by a one-workgroup kernel on a side stream, "
+                                  "under the next step's launch (dn_poisson_finish_sums); kernel_avg_ms is the fused kernel, value / ms_per_step include "
+                                  "every step's reduction (all of them run inside the timed region)") if not args.sync_sums else
+                                 "the loss is formed inside the launch (its last workgroup adds up the partial sums)",
+                         "kernel_avg_ms_with_in_kernel_sums": None if sync_ms is None else sum(sync_ms) / len(sync_ms),
+                         "frac_with_in_kernel_sums": None if sync_ms is None else alg_bytes / (sum(sync_ms) / len(sync_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_median_ms": kern_med_ms, "kernel_min_ms": kern_ms[0], "kernel_max_ms": kern_ms[-1],
                          "frac_at_median": alg_bytes / (kern_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
                          "batches": "%d different batches in rotation, as in the timed steps" % NROT,

@@ -39,7 +39,7 @@ class DnPoissonArgs(C.Structure):
                 ("out_scale", C.c_float),
                 ("out", C.c_void_p), ("energy", C.c_void_p), ("sumsq", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("energy_f32", C.c_void_p), ("energy_scale", C.c_double), ("strip_select", C.c_int32), ("accumulate_sums", C.c_int32)]
+                ("energy_f32", C.c_void_p), ("energy_scale", C.c_double), ("strip_select", C.c_int32), ("accumulate_sums", C.c_int32), ("defer_sums", C.c_int32)]
 
 
 class DnFsdtArgs(C.Structure):
@@ -65,6 +65,7 @@ SYMBOLS = {
     "dn_probe_tile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dn_poisson_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
     "dn_poisson_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnPoissonArgs), C.c_void_p]),
+    "dn_poisson_finish_sums": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnPoissonArgs), C.c_void_p]),
     "dn_gauss_pt_eval_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_void_p]),
     "dn_gauss_pt_eval_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,
@@ -148,6 +149,36 @@ def lib():
         raise DiffNetHipError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
     _LIB = h
     return h
+
+
+_HIP = None
+
+
+def hip_runtime():
+    """ctypes handle of the HIP runtime torch runs on (the instance mapped into this process), for the few calls torch does not expose
+    with the flags needed: events without the system-scope fence of a default event (1.8 us per record, tools/event_cost.py)."""
+    global _HIP
+    if _HIP is None:
+        path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64.so" in ln), None)
+        if path is None:
+            raise DiffNetHipError("the HIP runtime is not loaded in this process (no GPU build of torch?)")
+        h = C.CDLL(path)
+        h.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        h.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        h.hipEventSynchronize.argtypes = [C.c_void_p]
+        h.hipEventDestroy.argtypes = [C.c_void_p]
+        _HIP = h
+    return _HIP
+
+
+def new_event():
+    """A HIP event for stream ordering only: hipEventDisableTiming | hipEventDisableSystemFence."""
+    e = C.c_void_p()
+    rc = hip_runtime().hipEventCreateWithFlags(C.byref(e), C.c_uint(0x2 | 0x20000000))
+    if rc != 0:
+        raise DiffNetHipError(f"hipEventCreateWithFlags: hipError_t {rc}")
+    return e
 
 
 def check(rc, what):

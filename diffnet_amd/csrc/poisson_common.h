@@ -39,6 +39,7 @@ struct PoissonParams {
     int nstrips;           // strips per sample along the marched axis (the whole mesh, whatever the launch selects)
     int strip_sel;         // 0: the launch covers every strip; 1: only the first and the last one; 2: all but those (dn_poisson_args.strip_select)
     int acc_sums;          // the final scalars are ADDED to what energy / sumsq hold (the second launch of a split evaluation)
+    int defer_sums;        // the launch only writes its per-workgroup partial sums; dn_poisson_finish_sums adds them up (on any stream ordered after it)
     int want_sums;
 };
 
@@ -134,6 +135,10 @@ __device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, fl
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     double es = escale * ((double)p.T.c * (double)e1 - (double)e2), ss = (double)sq;
     block_sum2(es, ss, red, tid, nthreads);
+    if (p.defer_sums) {                          // no arrival protocol, no tail: the kernel boundary publishes the partials
+        if (tid == 0) { p.part_energy[blk] = es; p.part_sumsq[blk] = ss; }
+        return;
+    }
     if (tid == 0) {
         // write-through (sc1) 8-byte stores + drain instead of an agent-scope release fence: a release is a
         // `buffer_wbl2` of the whole XCD L2, i.e. every workgroup would wait for everybody's freshly written

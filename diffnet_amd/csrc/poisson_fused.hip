@@ -365,6 +365,25 @@ static int launch2d(const PoissonParams& pp, const Geom2D& g, int P, int ngp, in
 
 }  // namespace dn
 
+namespace dn {
+// Final reduction of a launch's per-workgroup partial sums as its own (one-workgroup) kernel: fixed order -- thread t adds partials
+// t, t + 256, ... in turn, then the fixed-order block sum -- so the scalars are bitwise repeatable.  Same output semantics as the in-kernel
+// reduction (finish_sums in poisson_common.h).
+__global__ void __launch_bounds__(256) poisson_finish_sums_kernel(const double* __restrict__ part_energy, const double* __restrict__ part_sumsq, int n,
+                                                                  double* energy, double* sumsq, float* energy_f32, double energy_scale, int acc) {
+    __shared__ double red[2 * 4];
+    double e = 0.0, s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { e += part_energy[i]; s += part_sumsq[i]; }
+    block_sum2(e, s, red, (int)threadIdx.x, 256);
+    if (threadIdx.x == 0) {
+        if (acc) { e += *energy; s += *sumsq; }
+        if (energy) *energy = e;
+        if (sumsq) *sumsq = s;
+        if (energy_f32) *energy_f32 = (float)(e * energy_scale);
+    }
+}
+}  // namespace dn
+
 using namespace dn;
 
 extern "C" int64_t dn_poisson_workspace_bytes(const dn_mesh* mesh) {
@@ -485,7 +504,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     if (a->strip_select < 0 || a->strip_select > 2) return DN_E_BADARG;
     if (a->accumulate_sums && want_red && !(a->energy && a->sumsq)) return DN_E_BADARG;      // the running sums live in the two double slots
     pp.strip_sel = a->strip_select;
-    pp.acc_sums = (a->accumulate_sums && want_red) ? 1 : 0;
+    pp.acc_sums = (a->accumulate_sums && want_red && !a->defer_sums) ? 1 : 0;      // (deferred: dn_poisson_finish_sums accumulates)
+    pp.defer_sums = (a->defer_sums && want_red) ? 1 : 0;
     auto launched = [&](int total) { return a->strip_select == 1 ? std::min(total, 2) : (a->strip_select == 2 ? std::max(total - 2, 0) : total); };
     if (m->nsd == 2) {
         Geom2D g = plan2d_env(m, P, allow_e4);
@@ -513,6 +533,46 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         }
     }
     if (rc) return rc;
+    DN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Workgroups the launch of (mesh, args) consists of = number of per-workgroup partial sums it leaves in the workspace.
+static long long launched_workgroups(const dn_mesh* m, const dn_poisson_args* a) {
+    auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
+    bool e4 = (m->nx % 4 == 0) && aligned(a->u, 16) && aligned(a->nu, 16) && aligned(a->f, 16) && aligned(a->out, 16);
+    for (int k = 0; k < 2; ++k)
+        if (a->bc[k].mask_kind == DN_MASK_F32 || a->bc[k].mask_kind == DN_MASK_U8)
+            e4 = e4 && aligned(a->bc[k].mask, a->bc[k].mask_kind == DN_MASK_U8 ? 4 : 16) && aligned(a->bc[k].field, 16);
+    auto sel = [&](int total) { return a->strip_select == 1 ? std::min(total, 2) : (a->strip_select == 2 ? std::max(total - 2, 0) : total); };
+    if (m->nsd == 2) {
+        Geom2D g = plan2d_env(m, m->degree, e4);
+        const int W = a->strip_select ? 1 : g.W;
+        return (long long)g.chunks * ((sel(g.strips) + W - 1) / W) * m->batch;
+    }
+    Geom3D g = plan3d_env(m);
+    return (long long)g.chunks * g.tiles * sel(g.strips) * m->batch;
+}
+
+extern "C" int dn_poisson_finish_sums(const dn_mesh* m, const dn_poisson_args* a, void* stream) {
+    int rc = validate_mesh(m);
+    if (rc) return rc;
+    if (!a || !a->workspace || !(a->energy || a->sumsq || a->energy_f32)) return DN_E_BADARG;
+    if (a->accumulate_sums && !(a->energy && a->sumsq)) return DN_E_BADARG;
+    const long long n = launched_workgroups(m, a);
+    if (n <= 0) return 0;
+    const long long nall = num_workgroups(m, true) > num_workgroups(m, false) ? num_workgroups(m, true) : num_workgroups(m, false);
+    if (a->workspace_bytes < DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * nall) return DN_E_WORKSPACE;
+    const double* pe = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a->workspace) + DN_WS_HEADER);
+    // the partial arrays are laid out for the launch's own workgroup count (dn_poisson_apply: part_sumsq = part_energy + nwg)
+    auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
+    bool e4 = (m->nx % 4 == 0) && aligned(a->u, 16) && aligned(a->nu, 16) && aligned(a->f, 16) && aligned(a->out, 16);
+    for (int k = 0; k < 2; ++k)
+        if (a->bc[k].mask_kind == DN_MASK_F32 || a->bc[k].mask_kind == DN_MASK_U8)
+            e4 = e4 && aligned(a->bc[k].mask, a->bc[k].mask_kind == DN_MASK_U8 ? 4 : 16) && aligned(a->bc[k].field, 16);
+    const long long stride = num_workgroups(m, e4);
+    hipLaunchKernelGGL(poisson_finish_sums_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pe, pe + stride, (int)n, a->energy,
+                       a->sumsq, a->energy_f32, a->energy_scale, (int)(a->accumulate_sums != 0));
     DN_LAUNCH_CHECK();
     return 0;
 }

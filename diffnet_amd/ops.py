@@ -264,6 +264,17 @@ _WS_LOCK = __import__("threading").Lock()
 _POISSON_WS_BYTES = {}
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One side stream per device for the deferred final reductions (PoissonPlan(async_sums=True))."""
+    s = _SIDE_STREAMS.get(dev.index)
+    if s is None:
+        s = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    return s
+
+
 def _workspace(dev, nbytes):
     """The reduction workspace of (device, current stream): launches on one stream are ordered, so they may share it; a launch on
     another stream gets its own (the ABI asks for one workspace per concurrently used stream).  A prepared launch (PoissonPlan)
@@ -392,8 +403,14 @@ class PoissonPlan:
     host-side preparation -- and for anything captured into a HIP graph.  Outputs are overwritten by every launch."""
 
     def __init__(self, geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
-                 out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None, strict=True, strip_select=0, continues=None):
-        """strip_select 1 / 2: the launch covers only the first + last strip of the marched axis / all the others (include/diffnet_hip.h:
+                 out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None, strict=True, strip_select=0, continues=None,
+                 async_sums=False):
+        """async_sums: the launch leaves per-workgroup partial sums; the final scalars are formed by a one-workgroup kernel on a SIDE stream
+        (dn_poisson_finish_sums), i.e. under whatever the launch stream runs next -- the in-kernel final reduction is a ~3 us serial tail
+        of every launch.  The gradient is ready in launch-stream order as always; the sums / the loss are ready on the side stream: call
+        `wait_sums()` (makes the current stream wait for them) before consuming them there, or consume them under `sums_stream`.  Such a
+        plan owns its reduction workspace.
+        strip_select 1 / 2: the launch covers only the first + last strip of the marched axis / all the others (include/diffnet_hip.h:
         split evaluation); `continues`: the PoissonPlan of the first launch of such a pair -- this one writes into its outputs and adds
         its sums to that launch's."""
         # strict: every tensor argument must be usable as it is (contiguous float32 fields, float32 / uint8 mask images) -- a conversion
@@ -405,6 +422,18 @@ class PoissonPlan:
                                                                         reuse=None if continues is None else continues.result)
         self.args.strip_select = int(strip_select)
         self.args.accumulate_sums = int(continues is not None)
+        self.async_sums = bool(async_sums) and self.args.workspace is not None and self.args.workspace != 0
+        if self.async_sums:
+            self.args.defer_sums = 1
+            ws = torch.zeros(int(self.args.workspace_bytes), dtype=torch.uint8, device=u.device)      # its own: the partials wait for the side stream
+            self.keep.append(ws)
+            self.args.workspace = ws.data_ptr()
+            self.sums_stream = _side_stream(u.device)
+            self._side = self.sums_stream.cuda_stream
+            self._ev_main, self._ev_done = _lib.new_event(), _lib.new_event()
+            self._hip = _lib.hip_runtime()
+            self._finish = _lib.lib().dn_poisson_finish_sums
+            self._launched = False
         self.device = u.device
         self.stream = _raw_stream(u.device)      # the reduction workspace belongs to this stream
         self._fn = _lib.lib().dn_poisson_apply
@@ -414,10 +443,30 @@ class PoissonPlan:
         cur = _raw_stream(self.device)
         if self.args.workspace and cur != self.stream:
             raise DiffNetHipError("PoissonPlan.launch: prepared on another stream (its reduction workspace is per stream); prepare one plan per stream")
+        if self.async_sums:
+            hip, side = self._hip, C.c_void_p(self._side)
+            if self._launched:
+                hip.hipStreamWaitEvent(C.c_void_p(cur), self._ev_done, 0)      # the previous evaluation's partials and scalars have been consumed
+            rc = self._fn(self._mesh_ref, self._args_ref, C.c_void_p(cur))
+            if rc:
+                _lib.check(rc, "dn_poisson_apply")
+            hip.hipEventRecord(self._ev_main, C.c_void_p(cur))
+            hip.hipStreamWaitEvent(side, self._ev_main, 0)
+            rc = self._finish(self._mesh_ref, self._args_ref, side)
+            if rc:
+                _lib.check(rc, "dn_poisson_finish_sums")
+            hip.hipEventRecord(self._ev_done, side)
+            self._launched = True
+            return self.result
         rc = self._fn(self._mesh_ref, self._args_ref, C.c_void_p(cur))
         if rc:
             _lib.check(rc, "dn_poisson_apply")
         return self.result
+
+    def wait_sums(self):
+        """async_sums: make the current stream wait for the sums / the loss of the last launch (no-op otherwise)."""
+        if self.async_sums and self._launched:
+            self._hip.hipStreamWaitEvent(C.c_void_p(_raw_stream(self.device)), self._ev_done, 0)
 
 
 def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out, strict=False, reuse=None):

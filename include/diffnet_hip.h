@@ -138,6 +138,12 @@ typedef struct dn_poisson_args {
      * are added to what `energy` / `sumsq` (both required then) already hold and energy_f32 is formed from the running energy: launch 1
      * with accumulate_sums = 0, then launch 2 with 1, on one stream, gives the sums of the whole mesh in a fixed order. */
     int32_t strip_select, accumulate_sums;
+    /* defer_sums != 0: the launch leaves its per-workgroup partial sums in the workspace and writes none of energy / sumsq / energy_f32;
+     * dn_poisson_finish_sums(mesh, args, stream) adds them up (one small kernel, fixed order) on ANY stream ordered after the launch --
+     * e.g. a side stream, under the next launch: the in-kernel final reduction is a ~3 us serial tail at the end of a ~56 us launch
+     * (its last workgroup waits for every other one), the deferred one overlaps the next evaluation.  The workspace must not be handed
+     * to another launch before the finish kernel has run (one workspace per evaluation in flight). */
+    int32_t defer_sums;
 } dn_poisson_args;
 
 int dn_abi_version(void);
@@ -165,6 +171,8 @@ int dn_probe_tile(const float *a, const float *b, const float *c, float *out, in
 
 int64_t dn_poisson_workspace_bytes(const dn_mesh *mesh);
 int dn_poisson_apply(const dn_mesh *mesh, const dn_poisson_args *args, void *stream);
+/* Second half of a dn_poisson_apply launch with args->defer_sums set (same mesh, same args): the final scalars from the partial sums. */
+int dn_poisson_finish_sums(const dn_mesh *mesh, const dn_poisson_args *args, void *stream);
 
 /* gauss_pt_eval (DiffNet/DiffNetFEM.py:7-18) for an arbitrary table list, and its adjoint.
  *   out[b,g,e] = sum_a tables[g][a] * in[b, node(e,a)]          (conv_nd with stride `degree`)

@@ -244,3 +244,36 @@ def test_split_evaluation_equals_one_launch(kw, B, cfg):
     finally:
         if cfg:
             _lib.config_set(cfg[0], "")
+
+
+@pytest.mark.parametrize("kw,B", [(dict(domain_size=512, ngp_1d=3), 4), (dict(domain_size=65, nsd=3), 2), (dict(domain_size=64, ngp_1d=2), 1)])
+def test_deferred_sums_on_a_side_stream_equal_the_in_kernel_reduction(kw, B):
+    """PoissonPlan(async_sums=True): the launch leaves per-workgroup partial sums, dn_poisson_finish_sums forms the scalars on a side
+    stream.  Same gradient bitwise, same sums to the rounding of another (fixed) order of additions, repeatable bitwise; the results
+    follow in-place updates of the inputs; many launches back to back (the next launch may not overwrite partials the side stream has
+    not consumed yet) give the same numbers as one."""
+    from diffnet_amd import ops
+    m = module(kw)
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = cu(seeded(shape, 61)), cu(seeded(shape, 62) + 0.5), cu(seeded(shape, 63))
+    bc = boundary_mask((1,) + shape[1:]).to(torch.uint8).to(dev())
+    scale = 1.0 / (B * m.geom.nelem_total)
+    kwargs = dict(alpha=2.0, beta=1.0, c=1.0, wscale=1.0, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
+    ref = [t.clone() for t in ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], **kwargs).launch()]
+    plan = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], async_sums=True, **kwargs)
+    out, sums, loss = plan.launch()
+    plan.wait_sums()
+    assert torch.equal(out, ref[0])
+    np.testing.assert_allclose(sums.cpu().numpy(), ref[1].cpu().numpy(), rtol=1e-13)
+    np.testing.assert_allclose(float(loss), float(ref[2]), rtol=2e-7)
+    first = (sums.clone(), loss.clone())
+    for _ in range(50):
+        plan.launch()
+    plan.wait_sums()
+    assert torch.equal(sums, first[0]) and torch.equal(loss, first[1]) and torch.equal(out, ref[0])
+    u.mul_(0.5)
+    ref2 = [t.clone() for t in ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], **kwargs).launch()]
+    plan.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref2[0])
+    np.testing.assert_allclose(sums.cpu().numpy(), ref2[1].cpu().numpy(), rtol=1e-13)
