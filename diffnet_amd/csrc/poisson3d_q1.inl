@@ -788,15 +788,19 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
         emit_plane(o, keep, uown, ez, own_layer, W, ez + 2);
     };
 
-    // prologue: planes ez_begin and ez_begin + 1 into LDS, the lower one staged
+    // prologue: planes ez_begin and ez_begin + 1 into LDS (both requested before the first is consumed: one memory latency and one barrier
+    // instead of two -- a workgroup of a 128^3 launch marches only ~10 layers), the lower one staged
     RawNodes W;
-    plane_request(ez_begin, W);
-    plane_publish(W, ez_begin);
-    plane_request(ez_begin + 1, W);
+    {
+        RawNodes W0;
+        plane_request(ez_begin, W0);
+        plane_request(ez_begin + 1, W);
+        plane_publish(W0, ez_begin);
+        plane_publish(W, ez_begin + 1);
+    }
     __syncthreads();
     plane_gather(ez_begin, SA, keep_lo, u_lo);
-    plane_publish(W, ez_begin + 1);
-    __syncthreads();
+    __syncthreads();              // every thread has read plane ez_begin before the first layer publishes plane ez_begin + 2 into its slot
     int ez = ez_begin;
     // Wave priorities against lock-step: workgroups that start together and do identical work fall into phase (all request, then all
     // gather, then all compute: the layer period becomes the SUM of the VALU, TA and LDS times instead of their maximum).  Different

@@ -167,7 +167,7 @@ static int chunks_for(int logical_threads, int T) {
 // Pick elements-per-thread, block width and strip height so that (a) the x extent wastes few lanes,
 // (b) the launch has >= ~4 workgroups per CU when the problem allows it, (c) the marched strips are
 // long enough that the one recomputed layer per strip stays a small fraction.
-static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
+static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true, bool chain_ok = false) {
     Geom2D g;
     const int nx = m->nx, nely = (m->ny - 1) / P;
     const int maxE = (P == 1) ? 4 : (P == 2 ? 2 : 1);
@@ -193,12 +193,22 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true) {
     if (R > nely) R = nely;
     g.R = R < 1 ? 1 : R;
     g.strips = ceil_div(nely, g.R);
-    // One strip per workgroup.  The closed-form Q1 kernel can also CHAIN W neighbouring strips per workgroup (poisson2d_q1_cf.hip, "PLAN2D"
-    // "T,E,R,W"): a workgroup then reads W R + 2 node rows instead of W (R + 2) and recomputes one seam layer instead of W -- measured
-    // traffic goes from 1.09x to 1.02x of the algorithmic bytes, but the launch does not get faster: its length is the 17 dependent row
-    // trips of a strip either way (the chained strips wait for their lower neighbour's last layer instead of recomputing it), and the
-    // hand-overs cost 1-2 us (profiles/r3_rotate_chain.txt: 56.0 / 57.1 / 58.0 / 61.9 us for W = 1 / 2 / 4 / 8 on batches in rotation).
+    // The closed-form Q1 kernel can CHAIN W neighbouring strips per workgroup (poisson2d_q1_cf.hip, "PLAN2D" "T,E,R,W"): a workgroup then
+    // reads W R + 2 node rows instead of W (R + 2) and recomputes one seam layer instead of W.
+    //  * Launches that fill the chip at 16-row strips (the bench workload): measured traffic goes from 1.107x to 1.033x of the algorithmic
+    //    bytes, but the launch does not get faster -- its length is the 17 dependent row trips of a strip either way (the chained strips wait
+    //    for their lower neighbour's last layer instead of recomputing it), and the hand-overs cost 1-2 us (profiles/r3_rotate_chain.txt:
+    //    56.0 / 57.1 / 58.0 / 61.9 us for W = 1 / 2 / 4 / 8 on batches in rotation): one strip per workgroup.
+    //  * SMALL launches (cfg2 at B = 1 .. 24), which must cut the rows into strips of 4-8 to get enough waves and then pay 25-50 % for the seam
+    //    layers and halo rows: chained strips of 2-4 rows win 12-18 % at B <= 4 and 2-5 % up to B = 24 (profiles/r3_plan2d_small.txt).  Strip
+    //    height: the smallest of 2, 4, 8 that keeps the launch within 1.5 rounds of waves.
     g.W = 1;
+    const int cw = poisson2d_q1_cf_chain();
+    if (chain_ok && P == 1 && cw > 1 && g.E == 4 && g.T == 128 && g.R < 16) {
+        int Rc = 2;
+        while (Rc < 16 && waves_per_strip * ceil_div(nely, Rc) > 6144) Rc *= 2;
+        if (Rc < 16 && ceil_div(nely, Rc) >= cw) { g.R = Rc; g.strips = ceil_div(nely, Rc); g.W = cw; }
+    }
     return g;
 }
 
@@ -265,8 +275,8 @@ static Geom3D plan3d(const dn_mesh* m) {
 }
 
 // dn_config_set("PLAN2D", "T,E,R") / ("PLAN3D", "TX,TY,E,R") override the launch geometry (tuning experiments only).
-static Geom2D plan2d_env(const dn_mesh* m, int P, bool allow_e4 = true) {
-    Geom2D g = plan2d(m, P, allow_e4);
+static Geom2D plan2d_env(const dn_mesh* m, int P, bool allow_e4 = true, bool chain_ok = false) {
+    Geom2D g = plan2d(m, P, allow_e4, chain_ok);
     const char* e = config(CFG_PLAN2D);
     int T, E, R, W = 0;
     if (e && sscanf(e, "%d,%d,%d,%d", &T, &E, &R, &W) >= 3 && T >= 64 && T <= 256 && (E == 1 || E == 2 || E == 4) && R >= 1 &&
@@ -508,10 +518,12 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.defer_sums = (a->defer_sums && want_red) ? 1 : 0;
     auto launched = [&](int total) { return a->strip_select == 1 ? std::min(total, 2) : (a->strip_select == 2 ? std::max(total - 2, 0) : total); };
     if (m->nsd == 2) {
-        Geom2D g = plan2d_env(m, P, allow_e4);
+        // chained strips: only the closed-form Q1 kernel has them, and a split evaluation selects whole strips
+        const bool chain_ok = P == 1 && a->f_gp == nullptr && config(CFG_Q1_RULE_KERNEL) == nullptr && a->strip_select == 0;
+        Geom2D g = plan2d_env(m, P, allow_e4, chain_ok);
+        if (!chain_ok) g.W = 1;                          // (a "PLAN2D" override may ask for chained strips where they do not exist)
         pp.rows_per_strip = g.R;
         pp.nstrips = g.strips;
-        if (a->strip_select) g.W = 1;
         g.strips = launched(g.strips);
         if (g.strips == 0) return 0;                         // fewer than three strips: the other launch did everything
         const int NW = g.E * P;
@@ -546,9 +558,10 @@ static long long launched_workgroups(const dn_mesh* m, const dn_poisson_args* a)
             e4 = e4 && aligned(a->bc[k].mask, a->bc[k].mask_kind == DN_MASK_U8 ? 4 : 16) && aligned(a->bc[k].field, 16);
     auto sel = [&](int total) { return a->strip_select == 1 ? std::min(total, 2) : (a->strip_select == 2 ? std::max(total - 2, 0) : total); };
     if (m->nsd == 2) {
-        Geom2D g = plan2d_env(m, m->degree, e4);
-        const int W = a->strip_select ? 1 : g.W;
-        return (long long)g.chunks * ((sel(g.strips) + W - 1) / W) * m->batch;
+        const bool chain_ok = m->degree == 1 && a->f_gp == nullptr && config(CFG_Q1_RULE_KERNEL) == nullptr && a->strip_select == 0;
+        Geom2D g = plan2d_env(m, m->degree, e4, chain_ok);
+        if (!chain_ok) g.W = 1;
+        return (long long)g.chunks * ((sel(g.strips) + g.W - 1) / g.W) * m->batch;
     }
     Geom3D g = plan3d_env(m);
     return (long long)g.chunks * g.tiles * sel(g.strips) * m->batch;

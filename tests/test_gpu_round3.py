@@ -233,11 +233,14 @@ def test_split_evaluation_equals_one_launch(kw, B, cfg):
         first.launch()
         part = first.result[0].clone()
         out, sums, loss = rest.launch()
-        assert torch.equal(out, ref[0])
+        # (the one-launch evaluation of a SMALL 2-D Q1 launch runs chained strips, whose seam rows are summed in another order: rounding)
+        chained = m.geom.nsd == 2 and m.geom.deg == 1 and cfg is None
+        same = (lambda a, b: float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())) if chained else torch.equal
+        assert same(out, ref[0])
         done = ~torch.isnan(part)                   # what the first launch wrote is final (meshes of one or two strips: everything)
-        assert torch.equal(part[done], ref[0][done]) and bool(done[:, :, 0].all()) and bool(done[:, :, -1].all())
-        np.testing.assert_allclose(sums.cpu().numpy(), ref[1].cpu().numpy(), rtol=1e-12)
-        np.testing.assert_allclose(float(loss), float(ref[2]), rtol=2e-7)
+        assert same(part[done], ref[0][done]) and bool(done[:, :, 0].all()) and bool(done[:, :, -1].all())
+        np.testing.assert_allclose(sums.cpu().numpy(), ref[1].cpu().numpy(), rtol=1e-6 if chained else 1e-12)
+        np.testing.assert_allclose(float(loss), float(ref[2]), rtol=2e-6 if chained else 2e-7)
         with pytest.raises(Exception):
             bad = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], strip_select=3, **kwargs)
             bad.launch()
