@@ -1001,6 +1001,9 @@ static void launch3_flags(const PoissonParams& pp, const Geom3D& g, int batch, h
 #define DN_CAT(a, b) DN_CAT2(a, b)
 int DN_CAT(launch_poisson3d_q1_g, DN_NGP)(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s) {
     if (g.E == 1) { launch3_flags<DN_NGP, 1, false>(pp, g, batch, s); return 0; }
+#if DN_NGP == 2 && defined(DN_Q1W_E2)          // experiment (tools/variant_build.sh): two elements per thread in the generic marching form
+    if (g.E == 2) { if (vec) launch3_flags<DN_NGP, 2, true>(pp, g, batch, s); else launch3_flags<DN_NGP, 2, false>(pp, g, batch, s); return 0; }
+#endif
     return DN_E_UNSUPPORTED;
 }
 

@@ -295,7 +295,7 @@ static Geom3D plan3d_env(const dn_mesh* m) {
     Geom3D g = plan3d(m);
     const char* e = config(CFG_PLAN3D);
     int TX, TY, E, R;
-    if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY >= 64 && E == 1 && R >= 1 &&
+    if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY >= 64 && (E == 1 || (E == 2 && m->ngp == 2)) && R >= 1 &&
         TX * TY <= 256) {
         const int nelz = m->nz - 1;
         g.TX = TX; g.TY = TY; g.E = E; g.R = R > nelz ? nelz : R;
