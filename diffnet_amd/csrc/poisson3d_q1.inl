@@ -887,6 +887,282 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
 }
 
 #if DN_NGP == 2
+// =============================================================================================================
+// Fourth form (round 3): the node-owner form with TWO ELEMENTS PER THREAD along x, for the exact 2-point rule.  The node-owner kernel above
+// is bound by instructions, and a third of them are per THREAD, not per element: the requests (8 vector-memory instructions per layer), the
+// LDS records (4 reads, 2 writes), the hand-over (2 lane exchanges, slot write / read), the barrier, the Dirichlet selects, the store.  Here a
+// thread owns the nodes x = nx0 + 2 tx, + 1 of row ny0 + ty (one 8-byte load per field and plane, one 8-byte store) and the two elements to
+// their right; the tile is 32 x 16 elements (31 x 15 of them not shared with a neighbouring tile).  Records live in two LDS arrays, even and
+// odd node columns, so that the three records a thread reads per node row are conflict-free b128 reads (lane stride 16 bytes).  The halo -- node
+// row 16 (33 nodes) and node column 32 (16 nodes) -- is loaded 13 nodes per wave.  Needs an even nx (8-byte aligned pairs).
+// =============================================================================================================
+#ifndef DN_Q1N2_WAVES
+#define DN_Q1N2_WAVES 3
+#endif
+template <int FL>
+__global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
+    constexpr int NGP = 2;
+    constexpr bool UW = true;
+    constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, BC_U8C = (FL & FL3_BC_U8C) != 0;
+    constexpr int NMASK = !BC_U8C ? 0 : ((FL & FL3_BC_ONE) ? 1 : 2);
+    constexpr bool MASK_F32 = (FL & FL3_BC_F32) != 0;
+    constexpr bool E1G = (FL & FL3_E1G) != 0;
+    static_assert((FL & (FL3_FGP | FL3_BC)) == 0, "node-owner form: nodal forcing, constant-value conditions");
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * 16 + tx;
+    unsigned lid = blockIdx.x;                    // XCD-aware decode, see poisson3d_q1w_kernel
+    {
+        const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
+        lid = xcd * base + min(xcd, rem) + idx;
+    }
+    const int chunk = (int)(lid % (unsigned)chunks_x);
+    lid /= (unsigned)chunks_x;
+    const int tile = (int)(lid % (unsigned)tiles_y);
+    lid /= (unsigned)tiles_y;
+    const int strip = selected_strip(p, (int)(lid % (unsigned)strips_z)), b = (int)(lid / (unsigned)strips_z);
+    const int nx0 = chunk * 30, ny0 = tile * 15;               // first node of the tile (chunks overlap by one thread column = two elements)
+    const int x0 = nx0 + 2 * tx, ey = ny0 + ty;                // the thread's first node == lower-left node of its first element
+    const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);
+    const unsigned npl = (unsigned)(p.nx * p.ny);
+    const int64_t nps = (int64_t)npl * p.nz;
+    const SampleBases sb = sample_bases(p, b, nps);
+    const int R = p.rows_per_strip;
+    const int ez_own = strip * R;
+    const int ez_begin = ez_own > 0 ? ez_own - 1 : 0;
+    const int ez_end = min(ez_own + R, p.nelz);
+    const bool noderow_ok = ey < p.ny;
+    const float okf[2] = {(ey < p.nely && x0 < p.nelx) ? 1.f : 0.f, (ey < p.nely && x0 + 1 < p.nelx) ? 1.f : 0.f};
+    const ElemTab& TV = p.T;
+
+    __shared__ float4 recE[2][17][17];            // [plane parity][node row][even node column / 2] = {u after Dirichlet, nu, f, keep}
+    __shared__ float4 recO[2][17][16];
+    __shared__ float xch[2][2][256];
+    __shared__ double red[2 * (256 / 64)];
+    __shared__ int last_flag;
+
+    // own pair (clamped into the mesh: nx is even, so a pair is inside or outside as a whole) and the halo node this thread fetches
+    const unsigned own_off = (unsigned)min(ey, p.ny - 1) * (unsigned)p.nx + (unsigned)min(x0, p.nx - 2);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hidx = min(wave * 13 + min(lane, 12), 48);       // 49 halo nodes, 13 per wave (lanes 0..12; the other lanes repeat lane 12)
+    const int hrow = hidx < 33 ? 16 : hidx - 33, hcol = hidx < 33 ? hidx : 32;
+    const unsigned halo_off = (unsigned)min(ny0 + hrow, p.ny - 1) * (unsigned)p.nx + (unsigned)min(nx0 + hcol, p.nx - 1);
+    const bool halo_lane = lane < 13 && wave * 13 + lane < 49;
+    float4* const halo_rec0 = (hcol & 1) ? &recO[0][hrow][hcol >> 1] : &recE[0][hrow][hcol >> 1];
+    const unsigned halo_par_stride = (hcol & 1) ? 17u * 16u : 17u * 17u;
+
+    const bool has_mask[2] = {sb.mask[0] != nullptr, sb.mask[1] != nullptr};
+    const uint8_t* mask8[2];
+    mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);
+    mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);
+    const float* mask32[2] = {reinterpret_cast<const float*>(mask8[0]), reinterpret_cast<const float*>(mask8[1])};
+    const float bcval[2] = {NMASK == 1 ? (has_mask[0] ? p.bc[0].value : p.bc[1].value) : p.bc[0].value, p.bc[1].value};
+
+    struct RawNodes2 {
+        float2 u, n, f;               // own pair
+        float hu, hn, hf;             // halo node
+        uint16_t m[2];                // uint8 masks of the own pair (two bytes), per condition
+        float2 mf[2];                 // fp32 masks of the own pair
+        uint8_t hm[2];
+        float hmf[2];
+    };
+    auto plane_request = [&](int zreq, RawNodes2& W) {
+        const unsigned zoff = (unsigned)min(zreq, p.nz - 1) * npl;
+        const unsigned oo = zoff + own_off, oh = zoff + halo_off;
+        W.u = ld_at<float2>(sb.u, oo);
+        if constexpr (HAS_NU) W.n = ld_at<float2>(sb.nu, oo);
+        if constexpr (HAS_F) W.f = ld_at<float2>(sb.f, oo);
+        W.hu = ld_at<float>(sb.u, oh);
+        if constexpr (HAS_NU) W.hn = ld_at<float>(sb.nu, oh);
+        if constexpr (HAS_F) W.hf = ld_at<float>(sb.f, oh);
+        if constexpr (BC_U8C) {
+#pragma unroll
+            for (int k = 0; k < NMASK; ++k) {
+                if constexpr (MASK_F32) { W.mf[k] = ld_at<float2>(mask32[k], oo); W.hmf[k] = ld_at<float>(mask32[k], oh); }
+                else { W.m[k] = ld_at<uint16_t>(mask8[k], oo); W.hm[k] = ld_at<uint8_t>(mask8[k], oh); }
+            }
+        }
+    };
+    auto record = [&](float uu, float nn, float ff, const bool (&set)[2]) {
+        float keep = 1.f;
+        if constexpr (BC_U8C) {
+#pragma unroll
+            for (int k = 0; k < NMASK; ++k) {
+                const bool s = (NMASK == 1 || has_mask[k]) && set[k];
+                uu = s ? bcval[k] : uu;
+                keep = s ? 0.f : keep;
+            }
+        }
+        return make_float4(uu, HAS_NU ? nn : 1.f, HAS_F ? ff : 0.f, keep);
+    };
+    auto plane_publish = [&](const RawNodes2& W, int zpl) {
+        bool s0[2] = {false, false}, s1[2] = {false, false}, sh[2] = {false, false};
+        if constexpr (BC_U8C) {
+#pragma unroll
+            for (int k = 0; k < NMASK; ++k) {
+                if constexpr (MASK_F32) { s0[k] = W.mf[k].x > 0.5f; s1[k] = W.mf[k].y > 0.5f; sh[k] = W.hmf[k] > 0.5f; }
+                else { s0[k] = (W.m[k] & 0xffu) != 0; s1[k] = (W.m[k] >> 8) != 0; sh[k] = W.hm[k] != 0; }
+            }
+        }
+        const int par = zpl & 1;
+        recE[par][ty][tx] = record(W.u.x, W.n.x, W.f.x, s0);
+        recO[par][ty][tx] = record(W.u.y, W.n.y, W.f.y, s1);
+        if (halo_lane) halo_rec0[par * halo_par_stride] = record(W.hu, W.hn, W.hf, sh);
+    };
+    float keep_lo[2] = {1.f, 1.f}, keep_up[2] = {1.f, 1.f};
+    float u_lo[2] = {0.f, 0.f}, u_up[2] = {0.f, 0.f}, ut_acc = 0.f;
+    auto plane_gather = [&](int zpl, PlaneW<NGP, 2>& S, float (&keep)[2], float (&uown)[2]) {
+        const int par = zpl & 1;
+        const float4 a0 = recE[par][ty][tx], a1 = recO[par][ty][tx], a2 = recE[par][ty][tx + 1];
+        const float4 b0 = recE[par][ty + 1][tx], b1 = recO[par][ty + 1][tx], b2 = recE[par][ty + 1][tx + 1];
+        keep[0] = a0.w; keep[1] = a1.w;
+        uown[0] = a0.x; uown[1] = a1.x;
+        stage_u3<NGP>(TV, a0.x, a1.x, b0.x, b1.x, S.VU[0], S.VX[0], S.VY[0]);
+        stage_u3<NGP>(TV, a1.x, a2.x, b1.x, b2.x, S.VU[1], S.VX[1], S.VY[1]);
+        if constexpr (HAS_NU) {
+            stage_w3<NGP, UW>(TV, a0.y, a1.y, b0.y, b1.y, S.VN[0]);
+            stage_w3<NGP, UW>(TV, a1.y, a2.y, b1.y, b2.y, S.VN[1]);
+        }
+        if constexpr (HAS_F) {
+            stage_w3<NGP, UW>(TV, a0.z, a1.z, b0.z, b1.z, S.VF[0]);
+            stage_w3<NGP, UW>(TV, a1.z, a2.z, b1.z, b2.z, S.VF[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    PlaneW<NGP, 2> SA, SB;
+    float cU[2][NGP][NGP], cX[2][NGP], cY[2][NGP];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) {
+            cX[e][j] = cY[e][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NGP; ++i) {
+                cU[e][j][i] = 0.f;
+                SA.VN[e][j][i] = SB.VN[e][j][i] = 1.f;          // nu absent: the constant field 1 (unit weights)
+                SA.VF[e][j][i] = SB.VF[e][j][i] = 0.f;
+            }
+        }
+
+    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
+    int par = 0;
+
+    // adjoint of stage_u3 for one element: cotangents of a plane's stage values -> contributions to the element's 2 x 2 nodes
+    auto plane_transpose = [&](const float (&tU)[NGP][NGP], const float (&tX)[NGP], const float (&tY)[NGP], float ok, float (&o)[2][2]) {
+        float s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) {
+            float sv = 0.f, t = 0.f;
+#pragma unroll
+            for (int j = 0; j < NGP; ++j) { sv += tU[j][i]; t = fmaf(TV.b[j][1], tU[j][i], t); }
+            const float c1 = t + tY[i], c0 = sv - c1;
+            s0 += c0; t0 = fmaf(TV.b[i][1], c0, t0);
+            s1 += c1; t1 = fmaf(TV.b[i][1], c1, t1);
+        }
+        float sX = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) { sX += tX[j]; d1 = fmaf(TV.b[j][1], tX[j], d1); }
+        const float g01 = t0 + (sX - d1), g11 = t1 + d1;
+        o[0][1] = ok * g01; o[0][0] = ok * (s0 - g01);
+        o[1][1] = ok * g11; o[1][0] = ok * (s1 - g11);
+    };
+
+    const unsigned out_row = (unsigned)ey * (unsigned)p.nx;
+    const int from_left = (int)(((unsigned)tid - 1u) & 63u) << 2;
+    const float nfirst = tx > 0 ? 1.f : 0.f;
+    float2 pend_v = make_float2(0.f, 0.f);
+    unsigned pend_off = 0u;
+    bool pend_st = false;
+    auto flush_store = [&]() {
+        if (pend_st) st_at<float2>(sb.out, pend_off, pend_v);
+        pend_st = false;
+    };
+    // o0 / o1: contributions of the thread's two elements to their 2 x 2 nodes in the plane being finished ([node row][node column]).
+    // Node columns of the thread: c0 = o0[.][0] (+ the left thread's o1[.][1]), c1 = o0[.][1] + o1[.][0]; o1[.][1] goes to the right.
+    auto emit_plane = [&](const float (&o0)[2][2], const float (&o1)[2][2], const float (&keep)[2], const float (&uown)[2], int z, bool owned_plane,
+                          const RawNodes2* W, int zpub) {
+        const float left0 = lane_from_left(o1[0][1], from_left, nfirst);
+        xch[par][0][tid] = o0[1][0] + lane_from_left(o1[1][1], from_left, nfirst);
+        xch[par][1][tid] = o0[1][1] + o1[1][0];
+        if (W != nullptr) plane_publish(*W, zpub);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float t0 = o0[0][0] + left0, t1 = o0[0][1] + o1[0][0];
+        if (ty > 0) { t0 += xch[par][0][tid - 16]; t1 += xch[par][1][tid - 16]; }
+        const bool st = owned_plane && owner && noderow_ok;
+        if constexpr (E1G) ut_acc = st ? fmaf(t1, uown[1], fmaf(t0, uown[0], ut_acc)) : ut_acc;      // before the Dirichlet rows are zeroed
+        t0 *= keep[0];
+        t1 *= keep[1];
+        sq_acc = st ? fmaf(t1, t1, fmaf(t0, t0, sq_acc)) : sq_acc;
+        pend_v = make_float2(t0 * p.out_scale, t1 * p.out_scale);
+        pend_off = (unsigned)z * npl + out_row + (unsigned)x0;
+        pend_st = st && sb.out != nullptr && x0 < p.nx;
+        par ^= 1;
+    };
+    auto layer = [&](int ez, const PlaneW<NGP, 2>& L, const PlaneW<NGP, 2>& U, const float (&keep)[2], const float (&uown)[2], const RawNodes2* W) {
+        const bool own_layer = ez >= ez_own;
+        const float cnt = (own_layer && owner) ? 1.f : 0.f;
+        float o[2][2][2], fg[1] = {0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float tU[NGP][NGP], tX[NGP], tY[NGP], e1, e2;
+            q1_layer_3d_w<NGP, false, HAS_F, UW>(TV, L.VU[e], U.VU[e], L.VX[e], U.VX[e], L.VY[e], U.VY[e], L.VN[e], U.VN[e], L.VF[e], U.VF[e],
+                                                 fg, cU[e], cX[e], cY[e], tU, tX, tY, e1, e2);
+            if constexpr (E1G) {
+                asm volatile("" : "+v"(e2));
+            } else {
+                asm volatile("" : "+v"(e1), "+v"(e2));
+                e1_acc = fmaf(cnt * okf[e], e1, e1_acc);
+            }
+            e2_acc = fmaf(cnt * okf[e], e2, e2_acc);
+            plane_transpose(tU, tX, tY, okf[e], o[e]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the two element streams apart: interleaving them doubles the live set
+        }
+        emit_plane(o[0], o[1], keep, uown, ez, own_layer, W, ez + 2);
+    };
+
+    // prologue: planes ez_begin and ez_begin + 1 into LDS (requested together), the lower one staged
+    RawNodes2 W;
+    {
+        RawNodes2 W0;
+        plane_request(ez_begin, W0);
+        plane_request(ez_begin + 1, W);
+        plane_publish(W0, ez_begin);
+        plane_publish(W, ez_begin + 1);
+    }
+    __syncthreads();
+    plane_gather(ez_begin, SA, keep_lo, u_lo);
+    __syncthreads();
+    int ez = ez_begin;
+#pragma nounroll
+    for (; ez + 1 < ez_end; ez += 2) {
+        plane_request(ez + 2, W);                 // lands while this layer is computed; published before the layer's barrier
+        flush_store();
+        plane_gather(ez + 1, SB, keep_up, u_up);
+        layer(ez, SA, SB, keep_lo, u_lo, &W);
+        plane_request(ez + 3, W);
+        flush_store();
+        plane_gather(ez + 2, SA, keep_lo, u_lo);
+        layer(ez + 1, SB, SA, keep_up, u_up, &W);
+    }
+    bool odd = false;
+    if (ez < ez_end) {
+        flush_store();
+        plane_gather(ez + 1, SB, keep_up, u_up);
+        layer(ez, SA, SB, keep_lo, u_lo, nullptr);
+        odd = true;
+    }
+    flush_store();
+    if (ez_end == p.nelz) {       // the last strip owns the top boundary plane: only the layer below contributes
+        float o[2][2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) plane_transpose(cU[e], cX[e], cY[e], okf[e], o[e]);
+        emit_plane(o[0], o[1], odd ? keep_up : keep_lo, odd ? u_up : u_lo, p.nz - 1, true, nullptr, 0);
+        flush_store();
+    }
+    if constexpr (E1G) e1_acc = (ut_acc / p.T.esc + p.T.beta * e2_acc) / p.T.alpha;
+    if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, 256, red, &last_flag, (double)p.T.esc);
+}
+
 // diagnostic: resident workgroups per CU the runtime grants the default 3-D kernel (tools/occ3d.py prints it)
 extern "C" int dn_debug_occupancy_q1n(void) {
     int n = -1;
@@ -997,12 +1273,49 @@ static void launch3_flags(const PoissonParams& pp, const Geom3D& g, int batch, h
 #undef DN_L3
 }
 
+#if DN_NGP == 2
+template <int FLB>
+static void launch3_n2_bc(const PoissonParams& pp, const dim3& grid, const Geom3D& g, hipStream_t s) {
+    const bool any = pp.bc[0].mask || pp.bc[1].mask;
+    const bool one = (pp.bc[0].mask != nullptr) != (pp.bc[1].mask != nullptr);
+    bool f32 = false;
+    for (int k = 0; k < 2; ++k)
+        if (pp.bc[k].mask && !pp.bc[k].mask_is_u8) f32 = true;
+    const dim3 block(16, 16);
+#define DN_N2(FLAGS) hipLaunchKernelGGL((poisson3d_q1n2_kernel<(FLAGS)>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips)
+    if (!any) DN_N2(FLB);
+    else if (!f32 && one) DN_N2(FLB | FL3_BC_U8C | FL3_BC_ONE);
+    else if (!f32) DN_N2(FLB | FL3_BC_U8C);
+    else if (one) DN_N2(FLB | FL3_BC_U8C | FL3_BC_F32 | FL3_BC_ONE);
+    else DN_N2(FLB | FL3_BC_U8C | FL3_BC_F32);
+#undef DN_N2
+}
+
+static int launch3_n2(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
+    const dim3 grid((unsigned)((long long)g.chunks * g.tiles * g.strips * batch));
+    // energy from the nodal values (FL3_E1G) whenever the launch has a stiffness part and sums are wanted
+    const bool e1g = pp.T.alpha != 0.f && pp.want_sums && config(CFG_Q1_3D_E1SUM) == nullptr;
+    const int sel = (pp.nu ? 1 : 0) | (pp.f ? 2 : 0) | (e1g ? 4 : 0);
+    switch (sel) {
+        case 0: launch3_n2_bc<0>(pp, grid, g, s); break;
+        case 1: launch3_n2_bc<FL3_NU>(pp, grid, g, s); break;
+        case 2: launch3_n2_bc<FL3_F>(pp, grid, g, s); break;
+        case 3: launch3_n2_bc<FL3_NU | FL3_F>(pp, grid, g, s); break;
+        case 4: launch3_n2_bc<FL3_E1G>(pp, grid, g, s); break;
+        case 5: launch3_n2_bc<FL3_NU | FL3_E1G>(pp, grid, g, s); break;
+        case 6: launch3_n2_bc<FL3_F | FL3_E1G>(pp, grid, g, s); break;
+        default: launch3_n2_bc<FL3_NU | FL3_F | FL3_E1G>(pp, grid, g, s); break;
+    }
+    return 0;
+}
+#endif
+
 #define DN_CAT2(a, b) a##b
 #define DN_CAT(a, b) DN_CAT2(a, b)
 int DN_CAT(launch_poisson3d_q1_g, DN_NGP)(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s) {
     if (g.E == 1) { launch3_flags<DN_NGP, 1, false>(pp, g, batch, s); return 0; }
-#if DN_NGP == 2 && defined(DN_Q1W_E2)          // experiment (tools/variant_build.sh): two elements per thread in the generic marching form
-    if (g.E == 2) { if (vec) launch3_flags<DN_NGP, 2, true>(pp, g, batch, s); else launch3_flags<DN_NGP, 2, false>(pp, g, batch, s); return 0; }
+#if DN_NGP == 2
+    if (g.E == 2 && g.TX == 16 && g.TY == 16) return launch3_n2(pp, g, batch, s);       // node-owner form, two elements per thread (dn_poisson_apply checked its preconditions)
 #endif
     return DN_E_UNSUPPORTED;
 }

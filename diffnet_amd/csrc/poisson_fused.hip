@@ -212,9 +212,29 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true, bool chain_o
     return g;
 }
 
-static Geom3D plan3d(const dn_mesh* m) {
+static Geom3D plan3d(const dn_mesh* m, bool allow_e2 = false) {
     Geom3D g;
     const int nx = m->nx, ny = m->ny, nelz = m->nz - 1;
+    if (m->ngp == 2 && allow_e2) {
+        // node-owner form with two elements per thread (poisson3d_q1n2_kernel): tiles of 32 x 16 elements, 3 workgroups per CU (<= 168 VGPRs)
+        g.TX = 16; g.TY = 16; g.E = 2;
+        g.chunks = chunks_for(nx / 2, 16);
+        g.tiles = chunks_for(ny, 16);
+        const double cap = 256.0 * 3.0;
+        const long long wg_per_strip = (long long)g.chunks * g.tiles * m->batch;
+        double bestc = 1e300;
+        g.R = nelz < 1 ? 1 : nelz;
+        for (int R = 4; R <= 64 && R <= (nelz < 4 ? 4 : nelz); ++R) {
+            const int strips = ceil_div(nelz, R);
+            const double rounds = std::max(1.0, std::ceil(2.0 * (double)(wg_per_strip * strips) / cap) / 2.0);
+            const double layers = (strips == 1 ? nelz : R + 1) + 1.5;
+            const double cost = rounds * layers * (1.0 + 0.002 * R);
+            if (cost < bestc) { bestc = cost; g.R = R; }
+        }
+        if (g.R > nelz) g.R = nelz < 1 ? 1 : nelz;
+        g.strips = ceil_div(nelz, g.R);
+        return g;
+    }
     if (m->ngp == 2) {
         // 2 x 2 x 2 points: one element per thread in tiles 16 threads wide (the T16 form of poisson3d_q1w_kernel: DPP hand-over
         // along x, paired loads, next plane's loads in flight).  Tile height: the multiple of 4 rows (whole waves) that wastes
@@ -291,11 +311,11 @@ static Geom2D plan2d_env(const dn_mesh* m, int P, bool allow_e4 = true, bool cha
     return g;
 }
 
-static Geom3D plan3d_env(const dn_mesh* m) {
-    Geom3D g = plan3d(m);
+static Geom3D plan3d_env(const dn_mesh* m, bool allow_e2 = false) {
+    Geom3D g = plan3d(m, allow_e2);
     const char* e = config(CFG_PLAN3D);
     int TX, TY, E, R;
-    if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY >= 64 && (E == 1 || (E == 2 && m->ngp == 2)) && R >= 1 &&
+    if (e && sscanf(e, "%d,%d,%d,%d", &TX, &TY, &E, &R) == 4 && TX * TY >= 64 && (E == 1 || (E == 2 && allow_e2 && TX == 16 && TY == 16)) && R >= 1 &&
         TX * TY <= 256) {
         const int nelz = m->nz - 1;
         g.TX = TX; g.TY = TY; g.E = E; g.R = R > nelz ? nelz : R;
@@ -374,6 +394,26 @@ static int launch2d(const PoissonParams& pp, const Geom2D& g, int P, int ngp, in
 }
 
 }  // namespace dn
+
+// May the launch of (mesh, args) run the 3-D node-owner kernel with two elements per thread?  (exact 2-point rule, even nx, 8-byte aligned
+// node pairs, nodal / absent forcing, constant-value conditions held as images of one kind)
+static bool q1n2_ok(const dn_mesh* m, const dn_poisson_args* a) {
+    if (m->nsd != 3 || m->degree != 1 || m->ngp != 2 || (m->nx & 1) || a->f_gp) return false;
+    if (m->gpw[0] != 1.0f || m->gpw[1] != 1.0f) return false;
+    if (dn::config(dn::CFG_Q1_3D_T16) != nullptr || dn::config(dn::CFG_Q1_3D_E1) != nullptr) return false;
+    auto al = [](const void* p, uintptr_t bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
+    if (!al(a->u, 8) || !al(a->nu, 8) || !al(a->f, 8) || !al(a->out, 8)) return false;
+    int kinds = 0;
+    for (int k = 0; k < 2; ++k) {
+        const dn_dirichlet& d = a->bc[k];
+        if (!d.mask) continue;
+        if (d.field) return false;
+        if (d.mask_kind == DN_MASK_U8) { if (!al(d.mask, 2)) return false; kinds |= 1; }
+        else if (d.mask_kind == DN_MASK_F32) { if (!al(d.mask, 8)) return false; kinds |= 2; }
+        else return false;
+    }
+    return kinds != 3;
+}
 
 namespace dn {
 // Final reduction of a launch's per-workgroup partial sums as its own (one-workgroup) kernel: fixed order -- thread t adds partials
@@ -530,7 +570,7 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         const bool vec = vec_ok(NW);
         rc = launch2d(pp, g, P, m->ngp, m->batch, vec, s);
     } else {
-        Geom3D g = plan3d_env(m);
+        Geom3D g = plan3d_env(m, q1n2_ok(m, a));
         pp.rows_per_strip = g.R;
         pp.nstrips = g.strips;
         g.strips = launched(g.strips);
@@ -563,7 +603,7 @@ static long long launched_workgroups(const dn_mesh* m, const dn_poisson_args* a)
         if (!chain_ok) g.W = 1;
         return (long long)g.chunks * ((sel(g.strips) + g.W - 1) / g.W) * m->batch;
     }
-    Geom3D g = plan3d_env(m);
+    Geom3D g = plan3d_env(m, q1n2_ok(m, a));
     return (long long)g.chunks * g.tiles * sel(g.strips) * m->batch;
 }
 

@@ -39,7 +39,8 @@ extern "C" {
  *   "Q1_RULE_KERNEL" (non-empty: per-Gauss-point 2-D Q1 kernels instead of the closed form),
  *   "GPE_GATHER" (non-empty: per-node gather adjoint of gauss_pt_eval), "GPE_TILED" (non-empty: tiled LDS adjoint instead of the
  *   marching 3-D Q1 adjoint), "Q1_3D_T16" (non-empty: the 3-D Q1 kernel form in which every thread loads its own nodes),
- *   "Q1_3D_E1SUM" (non-empty: 3-D stiffness energy summed Gauss point by Gauss point), "FSDT_GENERIC" (non-empty: the table-driven
+ *   "Q1_3D_E1SUM" (non-empty: 3-D stiffness energy summed Gauss point by Gauss point), "Q1_3D_E1" (non-empty: the 3-D node-owner kernel with one element per thread also where the two-element form applies),
+ *   "FSDT_GENERIC" (non-empty: the table-driven
  *   FSDT element also for Q2 with the symmetric 3-point rule, whose middle point otherwise runs a specialised form),
  *   "PLAN_FSDT" also takes "64,R,W": W one-wave sub-strips chained per workgroup.  value NULL or "" clears the switch.
  * Returns 0, or DN_E_BADARG for an unknown key / over-long value.  Not thread-safe against concurrent launches.

@@ -280,3 +280,46 @@ def test_deferred_sums_on_a_side_stream_equal_the_in_kernel_reduction(kw, B):
     torch.cuda.synchronize()
     assert torch.equal(out, ref2[0])
     np.testing.assert_allclose(sums.cpu().numpy(), ref2[1].cpu().numpy(), rtol=1e-13)
+
+
+@pytest.mark.parametrize("sizes,B", [((16, 16, 40), 3), ((18, 23, 29), 2), ((34, 17, 9), 1), ((64, 64, 64), 1), ((2, 2, 2), 2), ((62, 31, 33), 1), ((128, 48, 20), 1)])
+def test_3d_two_elements_per_thread_equals_one(sizes, B):
+    """The 3-D node-owner kernel with two elements per thread (poisson3d_q1n2_kernel: even nx, exact 2-point rule) against the one-element
+    form (dn_config_set("Q1_3D_E1")) and, on the small meshes, against the oracle: ragged tiles (nx = 18, 34, 62: several chunks with partly
+    empty last threads), more than one tile in y, several strips, every coefficient / condition combination the kernel is instantiated for
+    (uint8 and fp32 masks, one and two conditions, with and without nu / f), both ways of summing the stiffness energy, the residual form."""
+    from diffnet_amd import _lib
+    kw = dict(nsd=3, domain_sizes=sizes, domain_lengths=(1.0, 1.3, 0.7), domain_size=sizes[0], ngp_1d=2)
+    m = module(kw)
+    shape = (B, 1, sizes[2], sizes[1], sizes[0])
+    u, nu, f = cu(seeded(shape, 71)), cu(seeded(shape, 72) + 0.5), cu(seeded(shape, 73))
+    bc = boundary_mask((1,) + shape[1:]).to(torch.uint8).to(dev())
+    src = (seeded(shape, 74) < 0.05).to(torch.uint8).to(dev())
+    cases = {"none": (nu, f, []), "u8": (nu, f, [(bc, 0.0)]), "u8 x2": (nu, f, [(src, 1.0), (bc, 0.0)]), "f32": (nu, f, [(bc.float(), 0.0)]),
+             "f32 x2": (nu, f, [(src.float(), 1.0), (bc.float(), 0.0)]), "no nu": (None, f, [(bc, 0.0)]), "no f": (nu, None, [(bc, 0.0)]),
+             "bare": (None, None, [(bc, 0.0)])}
+    for name, (a, b, d) in cases.items():
+        for esum in ("", "1"):
+            _lib.config_set("Q1_3D_E1SUM", esum)
+            try:
+                l2, g2 = m.energy_loss_and_grad(u, a, b, dirichlet=d, c=0.7)
+                r2 = m.residual_loss(u, a, b, dirichlet=d)
+                _lib.config_set("Q1_3D_E1", "1")
+                l1, g1 = m.energy_loss_and_grad(u, a, b, dirichlet=d, c=0.7)
+                r1 = m.residual_loss(u, a, b, dirichlet=d)
+            finally:
+                _lib.config_set("Q1_3D_E1", "")
+                _lib.config_set("Q1_3D_E1SUM", "")
+            scale = float(g1.abs().max()) + 1e-30
+            assert float((g2 - g1).abs().max()) <= 3e-6 * scale, f"{name} esum={esum!r}"
+            np.testing.assert_allclose(float(l2), float(l1), rtol=5e-6, err_msg=f"{name} esum={esum!r}")
+            np.testing.assert_allclose(float(r2), float(r1), rtol=5e-6, err_msg=f"{name} residual")
+    if sizes[0] * sizes[1] * sizes[2] <= 20000:
+        from oracle.fem_oracle import Oracle
+        o = Oracle(**kw)
+        ur = u.cpu().clone().requires_grad_(True)
+        ref = o.energy(ur, nu.cpu(), f.cpu(), dirichlet=[(src.cpu().float(), 1.0), (bc.cpu().float(), 0.0)], c=0.7)
+        (gref,) = torch.autograd.grad(ref, ur)
+        l2, g2 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(src, 1.0), (bc, 0.0)], c=0.7)
+        np.testing.assert_allclose(float(l2), float(ref), rtol=1e-5)
+        close(g2, gref.numpy(), rtol=1e-4, arel=1e-4)
