@@ -69,6 +69,12 @@ struct CfRow {
                                   // (profiles/r2_plan2d_steady.txt): default plan 46.9 us, PF=1 48.1, PF=2 50.6; strips of 32 rows 54.5 / 48.9 / 46.3.  Off: 79 VGPRs
 #endif
 
+#ifndef DN_CF_PK
+#define DN_CF_PK 0                // 1: the element arithmetic of a layer runs on element PAIRS in packed fp32 registers (v_pk_fma_f32 ...; E even): 722 -> 536 VALU
+                                  // instructions per two rows, but 105 -> 154 VGPRs, i.e. 3 instead of 4 waves per SIMD: the 4096 waves of the bench launch no longer fit one
+                                  // round (69 us); with 22-row strips (one round at 3 waves) 55.2 us against 57.4 for the scalar form on that plan and 55.5 for the scalar
+                                  // form on the default plan -- no gain, off (profiles/r3_2d_packed.txt)
+#endif
 #ifndef DN_CF_W
 #define DN_CF_W 4                 // sub-strips CHAINED per workgroup where the launch plan asks for it ("PLAN2D" "T,E,R,W"; not the default, see plan2d in
 #endif                            // poisson_fused.hip): W x 2 waves march W neighbouring strips; a strip takes the row it shares with the strip below / above
@@ -108,7 +114,7 @@ __device__ __forceinline__ void lds_wait(float (&v)[N]) {
 #ifdef DN_STAMP2D
 // Diagnostic build only (tools/clock2d.py): shader-clock ticks (s_memtime) and constant-100-MHz ticks (s_memrealtime) of every workgroup's
 // lifetime -> the clock the kernel really ran at (the MI355X lowers it under load: profiles/r2_clock_under_load.txt)
-__device__ unsigned long long dn_stamp2d_buf[8192 * 2];
+__device__ unsigned long long dn_stamp2d_buf[8192 * 4];      // per workgroup: shader ticks of its march, then constant-clock (10 ns) stamps: start, end of the march, end of the kernel
 extern "C" int dn_debug_stamps2d(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dn_stamp2d_buf), bytes); }
 #endif
 
@@ -411,6 +417,56 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
                 le2 = fmaf(U.u[n], tup, fmaf(L.u[n], tlo, le2));
             }
         }
+        if constexpr (E % 2 == 0 && DN_CF_PK) {
+            // two elements per instruction: .x = element e, .y = element e + 1 (v2f: poisson_elem.h).  Elements beyond the mesh take part with
+            // their differences of u (and their forcing) zeroed -- every contribution is linear in those --, on data clamped into the mesh
+            v2f le1v = 0.f, le2v = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; e += 2) {
+                const v2f ok = {ex0 + e < p.nelx ? 1.f : 0.f, ex0 + e + 1 < p.nelx ? 1.f : 0.f};
+                const v2f Ll = {L.u[e], L.u[e + 1]}, Lr = {L.u[e + 1], L.u[e + 2]}, Ul = {U.u[e], U.u[e + 1]}, Ur = {U.u[e + 1], U.u[e + 2]};
+                const v2f UX = ok * (Lr - Ll), UY = ok * (Ul - Ll), UXY = ok * (Ur - Ul) - UX;
+                v2f P = mx0, Q = 0.f, Pp = my0, Qp = 0.f;
+                if constexpr (HAS_NU) {
+                    const v2f N0 = {L.n[e], L.n[e + 1]}, Nr = {L.n[e + 1], L.n[e + 2]}, Nu = {U.n[e], U.n[e + 1]}, Nur = {U.n[e + 1], U.n[e + 2]};
+                    const v2f NX = Nr - N0, NY = Nu - N0, NXY = (Nur - Nu) - NX;
+                    P = vfma(mx1, NX, mx0 * N0);
+                    Q = vfma(mx1, NXY, mx0 * NY);
+                    Pp = vfma(my1, NY, my0 * N0);
+                    Qp = vfma(my1, NXY, my0 * NX);
+                }
+                const v2f A0 = vfma(my1, Q, my0 * P), A1 = vfma(my2, Q, my1 * P), A2 = vfma(my3, Q, my2 * P);
+                const v2f B0 = vfma(mx1, Qp, mx0 * Pp), B1 = vfma(mx2, Qp, mx1 * Pp), B2 = vfma(mx3, Qp, mx2 * Pp);
+                const v2f tX0 = vfma(UXY, A1, UX * A0), tX1 = vfma(UXY, A2, UX * A1);
+                const v2f tY0 = vfma(UXY, B1, UY * B0), tY1 = vfma(UXY, B2, UY * B1);
+                le1v += vfma(h1, vfma(UXY, tY1, UY * tY0), h0 * vfma(UXY, tX1, UX * tX0));
+                v2f cU0 = 0.f, cUX = k0 * tX0, cUY = k1 * tY0, cUXY = vfma(k0, tX1, k1 * tY1);
+                if constexpr (HAS_F && !FMASS) {
+                    const v2f U0 = Ll;
+                    const v2f Fl = {L.f[e], L.f[e + 1]}, Fr = {L.f[e + 1], L.f[e + 2]}, Fu = {U.f[e], U.f[e + 1]}, Fur = {U.f[e + 1], U.f[e + 2]};
+                    const v2f F0 = ok * Fl, FX = ok * (Fr - Fl), FY = ok * (Fu - Fl), FXY = ok * (Fur - Fu) - FX;
+                    const v2f S0 = vfma(mx1, FX, mx0 * F0), S1 = vfma(mx1, FXY, mx0 * FY);
+                    const v2f T0 = vfma(mx2, FX, mx1 * F0), T1 = vfma(mx2, FXY, mx1 * FY);
+                    const v2f L0 = vfma(my1, S1, my0 * S0), LX = vfma(my1, T1, my0 * T0);
+                    const v2f LY = vfma(my2, S1, my1 * S0), LXY = vfma(my2, T1, my1 * T0);
+                    le2v += vfma(LXY, UXY, vfma(LY, UY, vfma(LX, UX, L0 * U0)));
+                    cU0 = nb * L0;
+                    cUX = vfma(nb, LX, cUX);
+                    cUY = vfma(nb, LY, cUY);
+                    cUXY = vfma(nb, LXY, cUXY);
+                }
+                const v2f g01 = cUX - cUXY, g10 = cUY - cUXY, g00 = (cU0 - cUX) - g10;
+                o[e] += g00.x;
+                o[e + 1] += g01.x + g00.y;
+                o[e + 2] += g01.y;
+                cout[e] += g10.x;
+                cout[e + 1] += cUXY.x + g10.y;
+                cout[e + 2] += cUXY.y;
+                __builtin_amdgcn_sched_barrier(0);      // one pair at a time: interleaving the pairs doubles the live set
+            }
+            le1 += le1v.x + le1v.y;
+            le2 += le2v.x + le2v.y;
+        } else {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             if (ex0 + e < p.nelx) {       // elements beyond the domain are skipped (and: scheduling fence between elements)
@@ -447,6 +503,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
                 cout[e] += g10;
                 cout[e + 1] += cUXY;
             }
+        }
         }
         e1_acc = fmaf(cnt, le1, e1_acc);
         e2_acc = fmaf(cnt, le2, e2_acc);
@@ -650,12 +707,19 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     if (tid == 0) {
         const unsigned slot = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         if (slot < 8192u) {
-            dn_stamp2d_buf[2 * slot] = __builtin_amdgcn_s_memtime() - stamp_t0;
-            dn_stamp2d_buf[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - stamp_rt0;
+            dn_stamp2d_buf[4 * slot] = __builtin_amdgcn_s_memtime() - stamp_t0;
+            dn_stamp2d_buf[4 * slot + 1] = stamp_rt0;
+            dn_stamp2d_buf[4 * slot + 2] = __builtin_amdgcn_s_memrealtime();
         }
     }
 #endif
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
+#ifdef DN_STAMP2D
+    if (tid == 0) {
+        const unsigned slot = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (slot < 8192u) dn_stamp2d_buf[4 * slot + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 template <int E, bool VEC, int FL>

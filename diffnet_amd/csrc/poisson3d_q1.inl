@@ -57,39 +57,39 @@ struct PlaneW {
     float keep[E];
 };
 
-// in-plane stage of u for one element: nodal values r0[e], r0[e+1] (row ey) and r1[e], r1[e+1] (row ey + 1)
-template <int NGP>
-__device__ __forceinline__ void stage_u3(const ElemTab& T, float a0, float a1, float b0, float b1, float (&VU)[NGP][NGP],
-                                         float (&VX)[NGP], float (&VY)[NGP]) {
-    const float dx0 = a1 - a0, dx1 = b1 - b0, ddx = dx1 - dx0;
+// in-plane stage of u for one element: nodal values r0[e], r0[e+1] (row ey) and r1[e], r1[e+1] (row ey + 1).
+// V = float, or v2f: two elements at once in the halves of packed-fp32 registers (v_pk_fma_f32 ...)
+template <int NGP, typename V = float>
+__device__ __forceinline__ void stage_u3(const ElemTab& T, V a0, V a1, V b0, V b1, V (&VU)[NGP][NGP], V (&VX)[NGP], V (&VY)[NGP]) {
+    const V dx0 = a1 - a0, dx1 = b1 - b0, ddx = dx1 - dx0;
 #pragma unroll
-    for (int j = 0; j < NGP; ++j) VX[j] = fmaf(T.b[j][1], ddx, dx0);
+    for (int j = 0; j < NGP; ++j) VX[j] = vfma(T.b[j][1], ddx, dx0);
 #pragma unroll
     for (int i = 0; i < NGP; ++i) {
-        const float t0 = fmaf(T.b[i][1], dx0, a0);
-        VY[i] = fmaf(T.b[i][1], dx1, b0) - t0;
+        const V t0 = vfma(T.b[i][1], dx0, a0);
+        VY[i] = vfma(T.b[i][1], dx1, b0) - t0;
 #pragma unroll
-        for (int j = 0; j < NGP; ++j) VU[j][i] = fmaf(T.b[j][1], VY[i], t0);
+        for (int j = 0; j < NGP; ++j) VU[j][i] = vfma(T.b[j][1], VY[i], t0);
     }
 }
 
 // weighted in-plane stage of a coefficient field: V[j][i] = w_j w_i * c(gp j, i)
-template <int NGP, bool UW>
-__device__ __forceinline__ void stage_w3(const ElemTab& T, float a0, float a1, float b0, float b1, float (&V)[NGP][NGP]) {
-    const float dx0 = a1 - a0, dx1 = b1 - b0;
+template <int NGP, bool UW, typename V = float>
+__device__ __forceinline__ void stage_w3(const ElemTab& T, V a0, V a1, V b0, V b1, V (&W)[NGP][NGP]) {
+    const V dx0 = a1 - a0, dx1 = b1 - b0;
 #pragma unroll
     for (int i = 0; i < NGP; ++i) {
-        float t0, t1;
+        V t0, t1;
         if constexpr (UW) {
-            t0 = fmaf(T.b[i][1], dx0, a0);
-            t1 = fmaf(T.b[i][1], dx1, b0);
+            t0 = vfma(T.b[i][1], dx0, a0);
+            t1 = vfma(T.b[i][1], dx1, b0);
         } else {
-            t0 = fmaf(T.wb[i], dx0, T.w[i] * a0);
-            t1 = fmaf(T.wb[i], dx1, T.w[i] * b0);
+            t0 = vfma(T.wb[i], dx0, T.w[i] * a0);
+            t1 = vfma(T.wb[i], dx1, T.w[i] * b0);
         }
-        const float dy = t1 - t0;
+        const V dy = t1 - t0;
 #pragma unroll
-        for (int j = 0; j < NGP; ++j) V[j][i] = UW ? fmaf(T.b[j][1], dy, t0) : fmaf(T.wb[j], dy, T.w[j] * t0);
+        for (int j = 0; j < NGP; ++j) W[j][i] = UW ? vfma(T.b[j][1], dy, t0) : vfma(T.wb[j], dy, T.w[j] * t0);
     }
 }
 
@@ -933,10 +933,14 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     const bool noderow_ok = ey < p.ny;
     const float okf[2] = {(ey < p.nely && x0 < p.nelx) ? 1.f : 0.f, (ey < p.nely && x0 + 1 < p.nelx) ? 1.f : 0.f};
     const ElemTab& TV = p.T;
+#if defined(DN_STAMP3D)
+    unsigned long long stamp_A = 0, stamp_B = 0, stamp_C = 0, stamp_D = 0, stamp_E = 0, stamp_n = 0, stamp_last = 0;
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     __shared__ float4 recE[2][17][17];            // [plane parity][node row][even node column / 2] = {u after Dirichlet, nu, f, keep}
     __shared__ float4 recO[2][17][16];
-    __shared__ float xch[2][2][256];
+    __shared__ float2 xch[2][256];
     __shared__ double red[2 * (256 / 64)];
     __shared__ int last_flag;
 
@@ -1008,63 +1012,58 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         recO[par][ty][tx] = record(W.u.y, W.n.y, W.f.y, s1);
         if (halo_lane) halo_rec0[par * halo_par_stride] = record(W.hu, W.hn, W.hf, sh);
     };
-    float keep_lo[2] = {1.f, 1.f}, keep_up[2] = {1.f, 1.f};
-    float u_lo[2] = {0.f, 0.f}, u_up[2] = {0.f, 0.f}, ut_acc = 0.f;
-    auto plane_gather = [&](int zpl, PlaneW<NGP, 2>& S, float (&keep)[2], float (&uown)[2]) {
+    // From here on a value of type v2f holds the same quantity of the thread's two elements (.x: element at node column x0, .y: at x0 + 1) or
+    // of its two nodes: the element arithmetic runs on packed fp32 instructions, one per pair.
+    struct PlaneP { v2f VU[NGP][NGP], VX[NGP], VY[NGP], VN[NGP][NGP], VF[NGP][NGP]; };
+    v2f keep_lo = 1.f, keep_up = 1.f;             // keep of the own node pair in the lower / upper plane of the current layer
+    v2f u_lo = 0.f, u_up = 0.f, ut_acc = 0.f;     // E1G: the own nodes' values after the Dirichlet conditions, sum of u * out over the owned nodes
+    auto plane_gather = [&](int zpl, PlaneP& S, v2f& keep, v2f& uown) {
         const int par = zpl & 1;
         const float4 a0 = recE[par][ty][tx], a1 = recO[par][ty][tx], a2 = recE[par][ty][tx + 1];
         const float4 b0 = recE[par][ty + 1][tx], b1 = recO[par][ty + 1][tx], b2 = recE[par][ty + 1][tx + 1];
-        keep[0] = a0.w; keep[1] = a1.w;
-        uown[0] = a0.x; uown[1] = a1.x;
-        stage_u3<NGP>(TV, a0.x, a1.x, b0.x, b1.x, S.VU[0], S.VX[0], S.VY[0]);
-        stage_u3<NGP>(TV, a1.x, a2.x, b1.x, b2.x, S.VU[1], S.VX[1], S.VY[1]);
-        if constexpr (HAS_NU) {
-            stage_w3<NGP, UW>(TV, a0.y, a1.y, b0.y, b1.y, S.VN[0]);
-            stage_w3<NGP, UW>(TV, a1.y, a2.y, b1.y, b2.y, S.VN[1]);
-        }
-        if constexpr (HAS_F) {
-            stage_w3<NGP, UW>(TV, a0.z, a1.z, b0.z, b1.z, S.VF[0]);
-            stage_w3<NGP, UW>(TV, a1.z, a2.z, b1.z, b2.z, S.VF[1]);
-        }
+        keep = v2f{a0.w, a1.w};
+        uown = v2f{a0.x, a1.x};
+        stage_u3<NGP, v2f>(TV, uown, v2f{a1.x, a2.x}, v2f{b0.x, b1.x}, v2f{b1.x, b2.x}, S.VU, S.VX, S.VY);
+        if constexpr (HAS_NU) stage_w3<NGP, UW, v2f>(TV, v2f{a0.y, a1.y}, v2f{a1.y, a2.y}, v2f{b0.y, b1.y}, v2f{b1.y, b2.y}, S.VN);
+        if constexpr (HAS_F) stage_w3<NGP, UW, v2f>(TV, v2f{a0.z, a1.z}, v2f{a1.z, a2.z}, v2f{b0.z, b1.z}, v2f{b1.z, b2.z}, S.VF);
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    PlaneW<NGP, 2> SA, SB;
-    float cU[2][NGP][NGP], cX[2][NGP], cY[2][NGP];
+    PlaneP SA, SB;
+    v2f cU[NGP][NGP], cX[NGP], cY[NGP];
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int j = 0; j < NGP; ++j) {
-            cX[e][j] = cY[e][j] = 0.f;
-#pragma unroll
-            for (int i = 0; i < NGP; ++i) {
-                cU[e][j][i] = 0.f;
-                SA.VN[e][j][i] = SB.VN[e][j][i] = 1.f;          // nu absent: the constant field 1 (unit weights)
-                SA.VF[e][j][i] = SB.VF[e][j][i] = 0.f;
-            }
-        }
-
-    float e1_acc = 0.f, e2_acc = 0.f, sq_acc = 0.f;
-    int par = 0;
-
-    // adjoint of stage_u3 for one element: cotangents of a plane's stage values -> contributions to the element's 2 x 2 nodes
-    auto plane_transpose = [&](const float (&tU)[NGP][NGP], const float (&tX)[NGP], const float (&tY)[NGP], float ok, float (&o)[2][2]) {
-        float s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
+    for (int j = 0; j < NGP; ++j) {
+        cX[j] = cY[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < NGP; ++i) {
-            float sv = 0.f, t = 0.f;
-#pragma unroll
-            for (int j = 0; j < NGP; ++j) { sv += tU[j][i]; t = fmaf(TV.b[j][1], tU[j][i], t); }
-            const float c1 = t + tY[i], c0 = sv - c1;
-            s0 += c0; t0 = fmaf(TV.b[i][1], c0, t0);
-            s1 += c1; t1 = fmaf(TV.b[i][1], c1, t1);
+            cU[j][i] = 0.f;
+            SA.VN[j][i] = SB.VN[j][i] = 1.f;              // nu absent: the constant field 1 (unit weights)
+            SA.VF[j][i] = SB.VF[j][i] = 0.f;
         }
-        float sX = 0.f, d1 = 0.f;
+    }
+
+    v2f e1_acc2 = 0.f, e2_acc2 = 0.f, sq_acc2 = 0.f;
+    const v2f okv = {okf[0], okf[1]};
+    int par = 0;
+
+    // adjoint of stage_u3: cotangents of a plane's stage values -> contributions to each element's 2 x 2 nodes
+    auto plane_transpose = [&](const v2f (&tU)[NGP][NGP], const v2f (&tX)[NGP], const v2f (&tY)[NGP], v2f (&o)[2][2]) {
+        v2f s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NGP; ++j) { sX += tX[j]; d1 = fmaf(TV.b[j][1], tX[j], d1); }
-        const float g01 = t0 + (sX - d1), g11 = t1 + d1;
-        o[0][1] = ok * g01; o[0][0] = ok * (s0 - g01);
-        o[1][1] = ok * g11; o[1][0] = ok * (s1 - g11);
+        for (int i = 0; i < NGP; ++i) {
+            v2f sv = 0.f, t = 0.f;
+#pragma unroll
+            for (int j = 0; j < NGP; ++j) { sv += tU[j][i]; t = vfma(TV.b[j][1], tU[j][i], t); }
+            const v2f c1 = t + tY[i], c0 = sv - c1;
+            s0 += c0; t0 = vfma(TV.b[i][1], c0, t0);
+            s1 += c1; t1 = vfma(TV.b[i][1], c1, t1);
+        }
+        v2f sX = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NGP; ++j) { sX += tX[j]; d1 = vfma(TV.b[j][1], tX[j], d1); }
+        const v2f g01 = t0 + (sX - d1), g11 = t1 + d1;
+        o[0][1] = okv * g01; o[0][0] = okv * (s0 - g01);
+        o[1][1] = okv * g11; o[1][0] = okv * (s1 - g11);
     };
 
     const unsigned out_row = (unsigned)ey * (unsigned)p.nx;
@@ -1077,47 +1076,45 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         if (pend_st) st_at<float2>(sb.out, pend_off, pend_v);
         pend_st = false;
     };
-    // o0 / o1: contributions of the thread's two elements to their 2 x 2 nodes in the plane being finished ([node row][node column]).
-    // Node columns of the thread: c0 = o0[.][0] (+ the left thread's o1[.][1]), c1 = o0[.][1] + o1[.][0]; o1[.][1] goes to the right.
-    auto emit_plane = [&](const float (&o0)[2][2], const float (&o1)[2][2], const float (&keep)[2], const float (&uown)[2], int z, bool owned_plane,
-                          const RawNodes2* W, int zpub) {
-        const float left0 = lane_from_left(o1[0][1], from_left, nfirst);
-        xch[par][0][tid] = o0[1][0] + lane_from_left(o1[1][1], from_left, nfirst);
-        xch[par][1][tid] = o0[1][1] + o1[1][0];
+    // o[node row][node column of the element]: contributions of the thread's two elements (.x, .y) to their 2 x 2 nodes in the plane being
+    // finished.  The thread's node columns: c0 = o[.][0].x (+ the left thread's o[.][1].y), c1 = o[.][1].x + o[.][0].y; o[.][1].y goes right.
+    auto emit_plane = [&](const v2f (&o)[2][2], v2f keep, v2f uown, int z, bool owned_plane, const RawNodes2* W, int zpub) {
+        DN_STAMP(stamp_C);
+        const float left0 = lane_from_left(o[0][1].y, from_left, nfirst);
+        xch[par][tid] = make_float2(o[1][0].x + lane_from_left(o[1][1].y, from_left, nfirst), o[1][1].x + o[1][0].y);
         if (W != nullptr) plane_publish(*W, zpub);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        float t0 = o0[0][0] + left0, t1 = o0[0][1] + o1[0][0];
-        if (ty > 0) { t0 += xch[par][0][tid - 16]; t1 += xch[par][1][tid - 16]; }
+        DN_STAMP(stamp_D);
+        v2f t = {o[0][0].x + left0, o[0][1].x + o[0][0].y};
+        if (ty > 0) {
+            const float2 up = xch[par][tid - 16];
+            t += v2f{up.x, up.y};
+        }
         const bool st = owned_plane && owner && noderow_ok;
-        if constexpr (E1G) ut_acc = st ? fmaf(t1, uown[1], fmaf(t0, uown[0], ut_acc)) : ut_acc;      // before the Dirichlet rows are zeroed
-        t0 *= keep[0];
-        t1 *= keep[1];
-        sq_acc = st ? fmaf(t1, t1, fmaf(t0, t0, sq_acc)) : sq_acc;
-        pend_v = make_float2(t0 * p.out_scale, t1 * p.out_scale);
+        if constexpr (E1G) ut_acc = st ? vfma(t, uown, ut_acc) : ut_acc;      // before the Dirichlet rows are zeroed
+        t *= keep;
+        sq_acc2 = st ? vfma(t, t, sq_acc2) : sq_acc2;
+        pend_v = make_float2(t.x * p.out_scale, t.y * p.out_scale);
         pend_off = (unsigned)z * npl + out_row + (unsigned)x0;
         pend_st = st && sb.out != nullptr && x0 < p.nx;
         par ^= 1;
     };
-    auto layer = [&](int ez, const PlaneW<NGP, 2>& L, const PlaneW<NGP, 2>& U, const float (&keep)[2], const float (&uown)[2], const RawNodes2* W) {
+    auto layer = [&](int ez, const PlaneP& L, const PlaneP& U, v2f keep, v2f uown, const RawNodes2* W) {
         const bool own_layer = ez >= ez_own;
-        const float cnt = (own_layer && owner) ? 1.f : 0.f;
-        float o[2][2][2], fg[1] = {0.f};
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float tU[NGP][NGP], tX[NGP], tY[NGP], e1, e2;
-            q1_layer_3d_w<NGP, false, HAS_F, UW>(TV, L.VU[e], U.VU[e], L.VX[e], U.VX[e], L.VY[e], U.VY[e], L.VN[e], U.VN[e], L.VF[e], U.VF[e],
-                                                 fg, cU[e], cX[e], cY[e], tU, tX, tY, e1, e2);
-            if constexpr (E1G) {
-                asm volatile("" : "+v"(e2));
-            } else {
-                asm volatile("" : "+v"(e1), "+v"(e2));
-                e1_acc = fmaf(cnt * okf[e], e1, e1_acc);
-            }
-            e2_acc = fmaf(cnt * okf[e], e2, e2_acc);
-            plane_transpose(tU, tX, tY, okf[e], o[e]);
-            __builtin_amdgcn_sched_barrier(0);      // keep the two element streams apart: interleaving them doubles the live set
+        const v2f cnt = ((own_layer && owner) ? 1.f : 0.f) * okv;
+        v2f o[2][2], tU[NGP][NGP], tX[NGP], tY[NGP], e1, e2;
+        float fg[1] = {0.f};
+        q1_layer_3d_w<NGP, false, HAS_F, UW, v2f>(TV, L.VU, U.VU, L.VX, U.VX, L.VY, U.VY, L.VN, U.VN, L.VF, U.VF, fg, cU, cX, cY, tU, tX, tY, e1, e2);
+        if constexpr (E1G) {
+            asm volatile("" : "+v"(e2));
+        } else {
+            asm volatile("" : "+v"(e1), "+v"(e2));
+            e1_acc2 = vfma(cnt, e1, e1_acc2);
         }
-        emit_plane(o[0], o[1], keep, uown, ez, own_layer, W, ez + 2);
+        e2_acc2 = vfma(cnt, e2, e2_acc2);
+        plane_transpose(tU, tX, tY, o);
+        __builtin_amdgcn_sched_barrier(0);
+        emit_plane(o, keep, uown, ez, own_layer, W, ez + 2);
     };
 
     // prologue: planes ez_begin and ez_begin + 1 into LDS (requested together), the lower one staged
@@ -1133,16 +1130,28 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     plane_gather(ez_begin, SA, keep_lo, u_lo);
     __syncthreads();
     int ez = ez_begin;
+#if defined(DN_STAMP3D)
+    stamp_last = __builtin_amdgcn_s_memtime();
+#endif
 #pragma nounroll
     for (; ez + 1 < ez_end; ez += 2) {
         plane_request(ez + 2, W);                 // lands while this layer is computed; published before the layer's barrier
         flush_store();
+        DN_STAMP(stamp_A);
         plane_gather(ez + 1, SB, keep_up, u_up);
+        DN_STAMP(stamp_B);
         layer(ez, SA, SB, keep_lo, u_lo, &W);
+        DN_STAMP(stamp_E);
         plane_request(ez + 3, W);
         flush_store();
+        DN_STAMP(stamp_A);
         plane_gather(ez + 2, SA, keep_lo, u_lo);
+        DN_STAMP(stamp_B);
         layer(ez + 1, SB, SA, keep_up, u_up, &W);
+        DN_STAMP(stamp_E);
+#if defined(DN_STAMP3D)
+        stamp_n += 2;
+#endif
     }
     bool odd = false;
     if (ez < ez_end) {
@@ -1153,13 +1162,27 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     }
     flush_store();
     if (ez_end == p.nelz) {       // the last strip owns the top boundary plane: only the layer below contributes
-        float o[2][2][2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) plane_transpose(cU[e], cX[e], cY[e], okf[e], o[e]);
-        emit_plane(o[0], o[1], odd ? keep_up : keep_lo, odd ? u_up : u_lo, p.nz - 1, true, nullptr, 0);
+        v2f o[2][2];
+        plane_transpose(cU, cX, cY, o);
+        emit_plane(o, odd ? keep_up : keep_lo, odd ? u_up : u_lo, p.nz - 1, true, nullptr, 0);
         flush_store();
     }
-    if constexpr (E1G) e1_acc = (ut_acc / p.T.esc + p.T.beta * e2_acc) / p.T.alpha;
+#if defined(DN_STAMP3D)
+    if (tid == 0) {                               // wave 0 of every workgroup (tools/stamp3d.py)
+        const unsigned slot = blockIdx.x;
+        if (slot < 8192u) {
+            unsigned long long* d = dn_stamp_buf + slot * 8u;
+            const unsigned long long hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+            d[0] = stamp_A; d[1] = stamp_B; d[2] = stamp_C; d[3] = stamp_D;
+            d[4] = stamp_E | ((__builtin_amdgcn_s_memrealtime() - stamp_rt0) << 40);
+            d[5] = stamp_n | (hwid << 16) | ((xcc & 0xffull) << 48);
+            d[6] = stamp_t0; d[7] = __builtin_amdgcn_s_memtime();
+        }
+    }
+#endif
+    float e1_acc = e1_acc2.x + e1_acc2.y;
+    const float e2_acc = e2_acc2.x + e2_acc2.y, sq_acc = sq_acc2.x + sq_acc2.y;
+    if constexpr (E1G) e1_acc = ((ut_acc.x + ut_acc.y) / p.T.esc + p.T.beta * e2_acc) / p.T.alpha;
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, tid, 256, red, &last_flag, (double)p.T.esc);
 }
 

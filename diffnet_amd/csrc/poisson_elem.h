@@ -22,6 +22,15 @@
 
 namespace dn {
 
+// Value types of the element arithmetic: float, or v2f = two independent elements in the halves of a 64-bit register pair.  On gfx950 a
+// packed fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) costs a SIMD ~3.4 cycles per wave whatever its operands, a plain
+// one 2.9 (registers only) to 4.0 (SGPR operand) -- per element-operation 1.7 against ~3.2 at this code's operand mix
+// (tools/micro/valu_pk.hip, profiles/r3_valu_pk.txt).  SGPR table entries broadcast into both halves through op_sel, for free.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f vfma(float a, v2f b, v2f c) { return __builtin_elementwise_fma((v2f)(a), b, c); }
+
 // Kernel-argument resident (SGPR) tables: everything wave-uniform the element code needs.
 struct ElemTab {
     float b[4][4];       // b[ig][ib]  = phi_ib(xi_ig)
@@ -295,20 +304,20 @@ __device__ __forceinline__ void q1_layer_3d(const ElemTab& T, const float (&LU)[
 // Outputs: tU/tX/tY = complete cotangents of the LOWER plane's stage values (carry included), cU/cX/cY (in/out) = carried
 // cotangents: in = from the layer below, out = this layer's contribution to the UPPER plane.  e1, e2 without wscale.
 // ---------------------------------------------------------------------------------------------
-template <int NGP, bool FGP, bool HAS_F, bool UW>
-__device__ __forceinline__ void q1_layer_3d_w(const ElemTab& T, const float (&LU)[NGP][NGP], const float (&UU)[NGP][NGP],
-                                              const float (&LX)[NGP], const float (&UX)[NGP], const float (&LY)[NGP],
-                                              const float (&UY)[NGP], const float (&LN)[NGP][NGP], const float (&UN)[NGP][NGP],
-                                              const float (&LF)[NGP][NGP], const float (&UF)[NGP][NGP],
-                                              const float* fg, float (&cU)[NGP][NGP], float (&cX)[NGP], float (&cY)[NGP],
-                                              float (&tU)[NGP][NGP], float (&tX)[NGP], float (&tY)[NGP], float& e1, float& e2) {
-    float a1z = 0.f, a1x = 0.f, a1y = 0.f, a2 = 0.f;
+template <int NGP, bool FGP, bool HAS_F, bool UW, typename V = float>
+__device__ __forceinline__ void q1_layer_3d_w(const ElemTab& T, const V (&LU)[NGP][NGP], const V (&UU)[NGP][NGP],
+                                              const V (&LX)[NGP], const V (&UX)[NGP], const V (&LY)[NGP],
+                                              const V (&UY)[NGP], const V (&LN)[NGP][NGP], const V (&UN)[NGP][NGP],
+                                              const V (&LF)[NGP][NGP], const V (&UF)[NGP][NGP],
+                                              const float* fg, V (&cU)[NGP][NGP], V (&cX)[NGP], V (&cY)[NGP],
+                                              V (&tU)[NGP][NGP], V (&tX)[NGP], V (&tY)[NGP], V& e1, V& e2) {
+    V a1z = 0.f, a1x = 0.f, a1y = 0.f, a2 = 0.f;
     const float nb = T.nbw;
     // row / column sums of the weighted nu planes (x- and y-moments of nu at the y- / x-Gauss points)
-    float LA[NGP], UA[NGP], LB[NGP], UB[NGP];
+    V LA[NGP], UA[NGP], LB[NGP], UB[NGP];
 #pragma unroll
     for (int j = 0; j < NGP; ++j) {
-        float la = 0.f, ua = 0.f, lb = 0.f, ub = 0.f;
+        V la = 0.f, ua = 0.f, lb = 0.f, ub = 0.f;
 #pragma unroll
         for (int i = 0; i < NGP; ++i) { la += LN[j][i]; ua += UN[j][i]; lb += LN[i][j]; ub += UN[i][j]; }
         LA[j] = la; UA[j] = ua; LB[j] = lb; UB[j] = ub;
@@ -317,31 +326,31 @@ __device__ __forceinline__ void q1_layer_3d_w(const ElemTab& T, const float (&LU
     for (int j = 0; j < NGP; ++j) {
 #pragma unroll
         for (int i = 0; i < NGP; ++i) {
-            const float dzu = UU[j][i] - LU[j][i];
-            const float Qz = fmaf(T.m[1], UN[j][i], T.m01 * LN[j][i]);          // sum_k w_k nu(i,j,k), in-plane weights inside
-            const float qz = Qz * dzu;
-            a1z = fmaf(qz, dzu, a1z);
-            float up = T.kap[2] * qz;                                            // cotangent of UU from the z-derivative term
-            float lo = cU[j][i] - up;
+            const V dzu = UU[j][i] - LU[j][i];
+            const V Qz = vfma(T.m[1], UN[j][i], T.m01 * LN[j][i]);          // sum_k w_k nu(i,j,k), in-plane weights inside
+            const V qz = Qz * dzu;
+            a1z = vfma(qz, dzu, a1z);
+            V up = T.kap[2] * qz;                                            // cotangent of UU from the z-derivative term
+            V lo = cU[j][i] - up;
             if constexpr (FGP) {
-                float cs = 0.f, c1 = 0.f;
+                V cs = 0.f, c1 = 0.f;
 #pragma unroll
                 for (int k = 0; k < NGP; ++k) {
                     const float wf = T.w[k] * T.w[j] * T.w[i] * fg[(k * NGP + j) * NGP + i];
                     cs += wf;
-                    c1 = fmaf(T.b[k][1], wf, c1);
+                    c1 = vfma(T.b[k][1], wf, c1);
                 }
-                a2 = fmaf(cs, LU[j][i], a2);
-                a2 = fmaf(c1, dzu, a2);
-                up = fmaf(nb, c1, up);
-                lo = fmaf(nb, cs - c1, lo);
+                a2 = vfma(cs, LU[j][i], a2);
+                a2 = vfma(c1, dzu, a2);
+                up = vfma(nb, c1, up);
+                lo = vfma(nb, cs - c1, lo);
             } else if constexpr (HAS_F) {
-                const float cs = fmaf(T.m[1], UF[j][i], T.m01 * LF[j][i]);       // m0 FL + m1 (FU - FL)
-                const float c1 = fmaf(T.m[2], UF[j][i], T.m12 * LF[j][i]);       // m1 FL + m2 (FU - FL)
-                a2 = fmaf(cs, LU[j][i], a2);
-                a2 = fmaf(c1, dzu, a2);
-                up = fmaf(nb, c1, up);
-                lo = fmaf(nb, cs - c1, lo);
+                const V cs = vfma(T.m[1], UF[j][i], T.m01 * LF[j][i]);       // m0 FL + m1 (FU - FL)
+                const V c1 = vfma(T.m[2], UF[j][i], T.m12 * LF[j][i]);       // m1 FL + m2 (FU - FL)
+                a2 = vfma(cs, LU[j][i], a2);
+                a2 = vfma(c1, dzu, a2);
+                up = vfma(nb, c1, up);
+                lo = vfma(nb, cs - c1, lo);
             }
             tU[j][i] = lo;
             cU[j][i] = up;
@@ -349,39 +358,39 @@ __device__ __forceinline__ void q1_layer_3d_w(const ElemTab& T, const float (&LU
     }
 #pragma unroll
     for (int j = 0; j < NGP; ++j) {
-        const float dX = UX[j] - LX[j], dA = UA[j] - LA[j];
-        float sx = 0.f, tx = 0.f;
+        const V dX = UX[j] - LX[j], dA = UA[j] - LA[j];
+        V sx = 0.f, tx = 0.f;
 #pragma unroll
         for (int k = 0; k < NGP; ++k) {
-            const float ux = fmaf(T.b[k][1], dX, LX[j]);
-            const float Qx = fmaf(T.b[k][1], dA, LA[j]);
-            const float qx = UW ? Qx * ux : (T.w[k] * Qx) * ux;
-            a1x = fmaf(qx, ux, a1x);
+            const V ux = vfma(T.b[k][1], dX, LX[j]);
+            const V Qx = vfma(T.b[k][1], dA, LA[j]);
+            const V qx = UW ? Qx * ux : (T.w[k] * Qx) * ux;
+            a1x = vfma(qx, ux, a1x);
             sx += qx;
-            tx = fmaf(T.b[k][1], qx, tx);
+            tx = vfma(T.b[k][1], qx, tx);
         }
-        const float up = T.kap[0] * tx;
-        tX[j] = fmaf(T.kap[0], sx, cX[j] - up);
+        const V up = T.kap[0] * tx;
+        tX[j] = vfma(T.kap[0], sx, cX[j] - up);
         cX[j] = up;
     }
 #pragma unroll
     for (int i = 0; i < NGP; ++i) {
-        const float dY = UY[i] - LY[i], dB = UB[i] - LB[i];
-        float sy = 0.f, ty = 0.f;
+        const V dY = UY[i] - LY[i], dB = UB[i] - LB[i];
+        V sy = 0.f, ty = 0.f;
 #pragma unroll
         for (int k = 0; k < NGP; ++k) {
-            const float uy = fmaf(T.b[k][1], dY, LY[i]);
-            const float Qy = fmaf(T.b[k][1], dB, LB[i]);
-            const float qy = UW ? Qy * uy : (T.w[k] * Qy) * uy;
-            a1y = fmaf(qy, uy, a1y);
+            const V uy = vfma(T.b[k][1], dY, LY[i]);
+            const V Qy = vfma(T.b[k][1], dB, LB[i]);
+            const V qy = UW ? Qy * uy : (T.w[k] * Qy) * uy;
+            a1y = vfma(qy, uy, a1y);
             sy += qy;
-            ty = fmaf(T.b[k][1], qy, ty);
+            ty = vfma(T.b[k][1], qy, ty);
         }
-        const float up = T.kap[1] * ty;
-        tY[i] = fmaf(T.kap[1], sy, cY[i] - up);
+        const V up = T.kap[1] * ty;
+        tY[i] = vfma(T.kap[1], sy, cY[i] - up);
         cY[i] = up;
     }
-    e1 = fmaf(T.hs2[2], a1z, fmaf(T.hs2[0], a1x, T.hs2[1] * a1y));
+    e1 = vfma(T.hs2[2], a1z, vfma(T.hs2[0], a1x, T.hs2[1] * a1y));
     e2 = a2;
 }
 

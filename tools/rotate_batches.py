@@ -11,7 +11,7 @@ g = torch.Generator().manual_seed(1)
 scale = 1.0 / (64 * m.geom.nelem_total)
 kw = dict(alpha=2.0, beta=1.0, c=1.0, wscale=1.0, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
 sets = []
-for k in range(8):
+for k in range(int(os.environ.get('NSETS', '8'))):
     u, nu, f = (torch.rand(shape, generator=g).to(dev) for _ in range(3))
     nu += 0.5
     sets.append((u, nu, f))
@@ -22,7 +22,7 @@ form = sys.argv[2] if len(sys.argv) > 2 else "box"
 bc = torch.zeros(shape, dtype=torch.uint8, device=dev)
 bc[..., 0] = 1; bc[..., -1] = 1; bc[..., 0, :] = 1; bc[..., -1, :] = 1
 cond = {"box": lambda: [(BoxFaces(), 0.0)], "bits": lambda: [(PackedMask.pack(bc.clone()), 0.0)], "u8": lambda: [(bc.clone(), 0.0)]}[form]
-for nb in ((1, 2, 4, 8, 1) if len(sys.argv) == 1 else (4, 1)):
+for nb in ([int(v) for v in os.environ['NBS'].split(',')] if 'NBS' in os.environ else ((1, 2, 4, 8, 1) if len(sys.argv) == 1 else (4, 1))):
     plans = [ops.PoissonPlan(m.geom, *sets[k], None, cond(), **kw) for k in range(nb)]
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.04:
