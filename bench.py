@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the FEM hot path: fused energy loss + gradient (one pass) on BASELINE.json configs[1]'s mesh.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--settle S]
+
+The W warm-up + K timed steps are run twice: from an idle GPU (`cold_start` in the line) and again after S = 400 untimed steps (`value`,
+`ms_per_step`): for 1.3-10 ms after load onset the part runs every kernel 10-25 % slower, and W = 5, K = 20 is 1.4 ms of load.
 
 N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the driver's form:
 RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or run plainly -- then this process, which has not touched the GPU
@@ -16,7 +19,8 @@ of the scalar loss).  metric = elements * gauss_pts / s summed over ranks.
 Every launch of the run -- warm-up, timed steps, roofline -- goes through NROT DIFFERENT batches in rotation (own input, mask and
 output arrays each): a training loop never re-reads the same u, and one batch's 268 MB of arrays is about the size of the 256 MB
 Infinity Cache, so re-evaluating ONE batch is cache-assisted (round 2: 47 vs 57 us).  `value`, `ms_per_step` and `roofline` are
-therefore one regime, streaming from HBM; the one-batch kernel time is a side field.  The Dirichlet mask is held as a general
+therefore one regime; the one-batch kernel time is a side field, and so are the same launches over 16 batches (nothing of a batch
+left in the cache at its next turn; with 4, part of u still is) and over 3 streams (`roofline.deeper_rotation`).  The Dirichlet mask is held as a general
 per-sample mask array (one bit per node, diffnet_amd.PackedMask); the geometry-derived form is a side field.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (time of the dominant kernel between timing-only HIP events over the
@@ -219,7 +223,7 @@ def slab_leg(args, rank, world, dev, dist, n, B, ngp, steps, warmup):
 
 
 def slab_main(args, rank, world, dev, dist):
-    out = slab_leg(args, rank, world, dev, dist, args.size, args.batch, args.ngp, args.steps, args.warmup)
+    out = slab_leg(args, rank, world, dev, dist, args.size, args.batch, args.ngp, args.steps, args.warmup + args.settle)
     if rank == 0:
         out["vs_baseline"] = None
         print(json.dumps(out), flush=True)
@@ -324,7 +328,7 @@ def config_rows(dev, budget_s=90.0):
     def fsdt(name, n, B):
         if time.perf_counter() - t_start > budget_s:
             return
-        from diffnet_amd.elasticity import fsdt_loss
+        from diffnet_amd.elasticity import fsdt_loss_and_grad, fsdt_total_loss
         m = DiffNet2DFEM(None, domain_size=n, fem_basis_deg=2, ngp_1d=3).to(dev)
         shape = (B, 1, n, n)
         g = torch.Generator().manual_seed(2)
@@ -333,11 +337,17 @@ def config_rows(dev, budget_s=90.0):
         bc[..., 0] = 1; bc[..., -1] = 1; bc[..., 0, :] = 1; bc[..., -1, :] = 1
 
         def fn():
-            loss = sum(fsdt_loss(m, *fields, bc))
-            torch.autograd.grad(loss, fields)
+            return fsdt_loss_and_grad(m, *fields, bc)
 
         us, host = device_us(fn)
-        add(name, us, host, 68 * B * n * n, B * m.geom.nelem_total * m.geom.ngp_total, "residual norms + gradient: two launches + glue")
+        add(name, us, host, 68 * B * n * n, B * m.geom.nelem_total * m.geom.ngp_total, "fsdt_loss_and_grad: residual norms + gradient, two launches, no autograd graph")
+
+        def fn_autograd():
+            torch.autograd.grad(fsdt_total_loss(m, *fields, bc), fields)
+
+        us, host = device_us(fn_autograd)
+        add(name + " [autograd: fsdt_total_loss + backward]", us, host, 68 * B * n * n, B * m.geom.nelem_total * m.geom.ngp_total,
+            "the same two launches behind torch.autograd (one Function node): host_us_per_call is the eager wall time per step")
 
     def unet(name, n, B):
         if time.perf_counter() - t_start > budget_s:
@@ -384,10 +394,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=400,
-                    help="untimed steps before the timed ones.  Default 400 (about 20 ms of load): between about 1.3 and 10 ms after the "
-                         "GPU leaves idle the launch runs 10-15 %% slower (power-management transient, tools/ramp2d.py, "
-                         "profiles/r2_ramp2d.txt); 400 steps put the default run past it")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps directly before the timed ones")
+    ap.add_argument("--settle", type=int, default=400,
+                    help="untimed steps BEFORE the warm-up + timed steps whose rate is reported as `value` (about 22 ms of load: between about 1.3 and "
+                         "10 ms after the GPU leaves idle the launch runs 10-25 %% slower -- power-management transient, tools/ramp2d.py, "
+                         "profiles/r2_ramp2d.txt).  The same warm-up + timed steps are also run from idle first and reported as `cold_start`; "
+                         "--settle 0 makes the two the same thing")
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ngp", type=int, default=3)
@@ -508,29 +520,40 @@ def main():
         while pending:
             pending.pop(0)[0].wait()
 
-    for _ in range(args.warmup):
+    def timed_steps():
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(args.warmup):
+            step()
+        drain()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # one pair of HIP events on the launch stream around the K timed launches (two records in total, none between the launches)
+        region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        t0 = time.perf_counter()
+        region[0].record()
+        for _ in range(args.steps):
+            step()
+        region[1].record()
+        drain()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax), region[0].elapsed_time(region[1]) / args.steps
+
+    # The GPU leaves idle when the first launch arrives, and between 1.3 and 10 ms after that every kernel runs 10-25 % slower (power-management
+    # ramp, tools/ramp2d.py): the driver's W = 5, K = 20 is 1.4 ms of load, i.e. entirely inside that transient.  The W + K steps are therefore
+    # run twice: once from idle (reported as `cold_start`), then again after --settle untimed steps (default 400: 22 ms of the same load) -- the
+    # steady state a job of more than a few hundred steps is in, and the regime of the roofline launches below.  `value` is the second run.
+    cold_dt, cold_region_ms = timed_steps()
+    for _ in range(args.settle):
         step()
     drain()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # one pair of HIP events on the launch stream around the K timed launches (two records in total, none between the launches)
-    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    t0 = time.perf_counter()
-    region[0].record()
-    for _ in range(args.steps):
-        step()
-    region[1].record()
-    drain()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    region_ms = region[0].elapsed_time(region[1]) / args.steps
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
+    dt, region_ms = timed_steps()
 
     # dominant-kernel time: timing-only HIP events on the launch stream around each dn_poisson_apply (ONE kernel: the fused Poisson
     # kernel, whose last workgroup also does the fixed-order final reduction), K launches over the rotation, each between its own pair
@@ -612,6 +635,58 @@ def main():
             launch_rot()          # the probe wrote into the gradient arrays: leave them as the operator writes them
         torch.cuda.synchronize()
         stream = best
+    # side fields: (a) the same launches over 16 batches in rotation on one stream (4.3 GB of arrays: nothing of a batch survives in the 256 MB
+    # Infinity Cache until its next turn, and the TLB reach is exceeded too -- with 4 batches part of u still does, because nu and f are read
+    # with non-temporal loads and no longer displace it); (b) 12 batches on 3 streams, 4 per stream: independent evaluations issued round-robin,
+    # so that the ramp-up of one launch runs under the tail of another (last strips, final reduction, launch gap)
+    deeper = None
+    if rank == 0 and world == 1 and args.nsd == 2 and not args.no_configs:
+        extra = [make_inputs(shape, dev, 1000 * k + 42) for k in range(NROT, 16)]
+        all_sets = sets + extra
+        mk = lambda st: _ops.PoissonPlan(m.geom, st[0], st[1], st[2], None, forms[bc_form](st[3]), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0,
+                                         out_scale=scale0, want_out=True, want_sums=True, loss_scale=scale0, async_sums=False)
+        pl16 = rot + [mk(st) for st in extra]
+        t = [0]
+
+        def go16():
+            pl16[t[0]].launch()
+            t[0] = (t[0] + 1) % 16
+
+        for _ in range(200):
+            go16()
+        ms16 = sorted(timed_pairs(go16, K)[0])
+        NS, PER = 3, 4
+        streams = [torch.cuda.Stream() for _ in range(NS)]
+        pls = []
+        for k in range(NS * PER):
+            with torch.cuda.stream(streams[k % NS]):
+                pls.append(mk(all_sets[k]))
+        torch.cuda.synchronize()
+
+        def burst(n):
+            for i in range(n):
+                k = i % (NS * PER)
+                with torch.cuda.stream(streams[k % NS]):
+                    pls[k].launch()
+
+        burst(240)
+        torch.cuda.synchronize()
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        for st_ in streams:
+            st_.wait_stream(torch.cuda.current_stream())
+        burst(480)
+        for st_ in streams:
+            torch.cuda.current_stream().wait_stream(st_)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms3 = ev[0].elapsed_time(ev[1]) / 480
+        deeper = {"rotation_16_kernel_avg_ms": sum(ms16) / len(ms16), "rotation_16_kernel_median_ms": ms16[len(ms16) // 2],
+                  "rotation_16_frac": ALG_BYTES_PER_NODE * B * m.geom.nnode_total / (sum(ms16) / len(ms16) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "three_streams_12_batches_ms_per_evaluation": ms3, "three_streams_value": units_per_step / (ms3 * 1e-3),
+                  "note": "rotation_16_*: the roofline launches over 16 instead of %d batches on one stream; three_streams_*: 12 batches, 4 per stream, "
+                          "evaluations issued round-robin on 3 streams (whole-region time / evaluations)" % NROT}
+        del pl16, pls, extra, all_sets
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
     kern_med_ms = kern_ms[len(kern_ms) // 2]
     alg_bytes = ALG_BYTES_PER_NODE * B * m.geom.nnode_total
@@ -633,12 +708,13 @@ def main():
                      'box': 'derived from the geometry (no array)'}[bc_form]
         out = {
             "metric": "elements*gauss_pts/sec (FEM loss+grad)", "value": value, "unit": "elements*gauss_pts/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle": args.settle, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.nsd}-D Poisson energy loss + gradient wrt u, Q1, {args.size}^{args.nsd} nodes, "
                                    f"{args.ngp}^{args.nsd} Gauss pts, batch {B}/GPU, nu+f nodal fields, Dirichlet mask on all boundary faces "
                                    + mask_note + f", fused single pass (BASELINE.json configs[1] mesh); every step evaluates the next of {NROT} "
-                                   "different batches in rotation (inputs stream from HBM, no Infinity-Cache re-use between steps)"
+                                   "different batches in rotation (nu, f and the mask stream from HBM with non-temporal loads; of the 4 x 67 MB of u a part may survive in the 256 MB "
+                                   "Infinity Cache until the batch's next turn: roofline.deeper_rotation has the 16-batch figure)"
                                    + ("; 2-D Q1 element evaluated in closed form: the rule's sums as polynomials of its moments, same value "
                                       "as the per-point sum (dn_config_set(\"Q1_RULE_KERNEL\") runs the per-point kernel)" if args.nsd == 2 else ""),
                        "batch_per_gpu": B, "nodes": list(m.geom.node_shape), "parallelism": f"batch-sharded x{world}",
@@ -669,7 +745,12 @@ def main():
                          "events": event_kind + " pair around each of %d launches, after %d untimed ones" % (K, SETTLE),
                          "timed_region_ms_per_launch": region_ms,
                          "frac_over_timed_region": alg_bytes / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "rotation_kernel_median_us_by_mask_format": bc_forms_us},
+                         "rotation_kernel_median_us_by_mask_format": bc_forms_us, "deeper_rotation": deeper},
+            "cold_start": {"value": units_per_step * world * args.steps / cold_dt, "ms_per_step": cold_dt / args.steps * 1e3,
+                           "timed_region_ms_per_launch": cold_region_ms,
+                           "note": "the same W warm-up + K timed steps started from an idle GPU (no settle steps before them): with the driver's W = 5, K = 20 "
+                                   "all of it falls into the 1.3-10 ms power-management transient after load onset; `value` is the same measurement "
+                                   "repeated after `settle` untimed steps"},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, c)

@@ -209,6 +209,9 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true, bool chain_o
         while (Rc < 16 && waves_per_strip * ceil_div(nely, Rc) > 6144) Rc *= 2;
         if (Rc < 16 && ceil_div(nely, Rc) >= cw) { g.R = Rc; g.strips = ceil_div(nely, Rc); g.W = cw; }
     }
+    // (Measured and not adopted, profiles/r3_2d_graded_launch.txt: giving the workgroups that are dispatched first -- they finish 4 us before the last
+    // ones, tools/timeline2d.py -- more rows, either as taller strips on a strip-major grid or as one strip fewer in the first samples: 57-61 us
+    // against 56.1; a launch lasts as long as its tallest strip's row trips.)
     return g;
 }
 

@@ -917,6 +917,58 @@ def _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num
     return mesh, args, keep, shape
 
 
+class FsdtPlan:
+    """The FSDT plate loss prepared once for FIXED buffers (the FSDT counterpart of PoissonPlan): `launch()` is two ctypes calls --
+    dn_fsdt_apply on the fields (the three assembled residuals and, in the same launch, their Frobenius norms) and dn_fsdt_apply on the
+    residuals as the VJP of sum_k weights[k] * ||R_k|| (the kernel forms weights[k] / ||R_k|| itself, 0 where a norm is 0) -- and returns
+    (norms (3,) float32, [dL/dw, dL/dphi_x, dL/dphi_y]).  No autograd graph, no torch op, ~6 us of host time; outputs are overwritten by
+    every launch.  `want_grad=False` prepares the first launch only.  Reference: e1_plate_bending_fsdt.py:128-232 (residuals, loss) and the
+    backward pass autograd builds for it."""
+
+    def __init__(self, geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), weights=(1.0, 1.0, 1.0), want_grad=True,
+                 D11=1.0, D12=0.0, D22=1.0, D66=1.0, A44=1.0, A55=1.0, q=0.0, wscale=1.0):
+        if geom.nsd != 2:
+            raise DiffNetHipError("FsdtPlan: 2-D meshes only")
+        for t, n in ((w, "w"), (phi_x, "phi_x"), (phi_y, "phi_y")):
+            _require(t, n, 4, True)          # strict: the plan keeps reading THESE buffers
+        dev = w.device
+        consts = tuple(float(x) for x in (D11, D12, D22, D66, A44, A55, q, wscale))
+        self.mesh, self.args, self.keep, shape = _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, None, None, None, True)
+        self.residuals = torch.empty((3, *shape), dtype=torch.float32, device=dev)
+        self.norms = torch.empty(3, dtype=torch.float32, device=dev)
+        step = 4 * self.residuals[0].numel()
+        for k in range(3):
+            self.args.out[k] = self.residuals.data_ptr() + k * step
+        self.args.norms = self.norms.data_ptr()
+        self.grads = None
+        self._refs = [(C.byref(self.mesh), C.byref(self.args))]
+        if want_grad:
+            self.weights = torch.tensor([float(x) for x in weights], dtype=torch.float32, device=dev)
+            vconsts = consts[:6] + (0.0, consts[7])          # J = M K M, K symmetric: the VJP is the operator itself on the masked cotangents, q = 0
+            R = list(self.residuals.unbind(0))
+            self.vmesh, self.vargs, vkeep, _ = _prepare_fsdt(geom, R[0], R[1], R[2], bc, (0.0, 0.0, 0.0), vconsts, None, self.weights, self.norms, False)
+            self.keep += vkeep
+            self.grads = torch.empty((3, *shape), dtype=torch.float32, device=dev)
+            for k in range(3):
+                self.vargs.out[k] = self.grads.data_ptr() + k * step
+            self._refs.append((C.byref(self.vmesh), C.byref(self.vargs)))
+        self.device = dev
+        self.stream = _raw_stream(dev)           # the reduction workspace belongs to this stream
+        self._fn = _lib.lib().dn_fsdt_apply
+        self.result = (self.norms, None if self.grads is None else list(self.grads.unbind(0)))
+
+    def launch(self):
+        cur = _raw_stream(self.device)
+        if cur != self.stream:
+            raise DiffNetHipError("FsdtPlan.launch: prepared on another stream (its reduction workspace is per stream); prepare one plan per stream")
+        s = C.c_void_p(cur)
+        for mref, aref in self._refs:
+            rc = self._fn(mref, aref, s)
+            if rc:
+                _lib.check(rc, "dn_fsdt_apply")
+        return self.result
+
+
 def compute_winding_nodes(points, normals, area, q):
     """Drop-in for `compute_winding_nodes` of IBN/poisson-2d/parametric/IBN_2D.py:89-104 (same argument shapes:
     points / normals (B,1,Npts,2), area (B,1,Npts,1) -- unused by the reference too --, q = stack((xx, yy)) (2,Ny,Nx));

@@ -323,3 +323,56 @@ def test_3d_two_elements_per_thread_equals_one(sizes, B):
         l2, g2 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(src, 1.0), (bc, 0.0)], c=0.7)
         np.testing.assert_allclose(float(l2), float(ref), rtol=1e-5)
         close(g2, gref.numpy(), rtol=1e-4, arel=1e-4)
+
+
+@pytest.mark.parametrize("deg,ngp,n,B", [(1, 2, 48, 2), (2, 3, 65, 1), (2, 3, 129, 2)])
+def test_fsdt_loss_and_grad_and_plan_equal_the_autograd_path(deg, ngp, n, B):
+    """fsdt_loss_and_grad (two launches, no graph), fsdt_total_loss (one autograd node) and ops.FsdtPlan (prepared launches on fixed
+    buffers) against sum(fsdt_loss(...)).backward(): the same two kernels on the same data, so the same bits; weighted norms; the plan
+    follows in-place updates of its input buffers and refuses non-contiguous fields and a foreign stream."""
+    from diffnet_amd import ops
+    from diffnet_amd.elasticity import _constants, fsdt_loss, fsdt_loss_and_grad, fsdt_total_loss
+    m = module(dict(domain_size=n, fem_basis_deg=deg, ngp_1d=ngp))
+    shape = (B, 1, n, n)
+    flds = [cu(seeded(shape, 30 + i)).requires_grad_(True) for i in range(3)]
+    bc = boundary_mask(shape).to(dev())
+    norms_ref = fsdt_loss(m, *flds, bc, w_bc=0.0, phi_x_bc=0.1, phi_y_bc=-0.1)
+    grads_ref = torch.autograd.grad(sum(norms_ref), flds)
+    norms, grads = fsdt_loss_and_grad(m, *flds, bc, w_bc=0.0, phi_x_bc=0.1, phi_y_bc=-0.1)
+    assert torch.equal(norms, torch.stack(norms_ref))
+    for g, r in zip(grads, grads_ref):
+        assert torch.equal(g, r)
+    total = fsdt_total_loss(m, *flds, bc, w_bc=0.0, phi_x_bc=0.1, phi_y_bc=-0.1)
+    np.testing.assert_allclose(float(total), float(sum(norms_ref)), rtol=1e-6)
+    for g, r in zip(torch.autograd.grad(total, flds), grads_ref):
+        assert torch.equal(g, r)
+    wts = torch.tensor([0.5, 2.0, -1.5], device=dev())
+    _, gw = fsdt_loss_and_grad(m, *flds, bc, w_bc=0.0, phi_x_bc=0.1, phi_y_bc=-0.1, weights=wts)
+    gw_ref = torch.autograd.grad(sum(w * x for w, x in zip(wts, fsdt_loss(m, *flds, bc, w_bc=0.0, phi_x_bc=0.1, phi_y_bc=-0.1))), flds)
+    for g, r in zip(gw, gw_ref):
+        close(g, r.cpu().numpy(), rtol=1e-5, arel=1e-6)
+    # prepared launches: fixed buffers, two ctypes calls
+    bufs = [f.detach().clone() for f in flds]
+    consts = _constants(1.0, 0.25, 0.1, 1.0)
+    plan = ops.FsdtPlan(m.geom, *bufs, bc, (0.0, 0.1, -0.1), q=1.0, wscale=(0.5 * m.h) * (0.5 * m.h), **consts)
+    pn, pg = plan.launch()
+    assert torch.equal(pn, norms)
+    for g, r in zip(pg, grads_ref):
+        assert torch.equal(g, r)
+    with torch.no_grad():
+        bufs[0].mul_(1.5)
+        bufs[2].add_(0.25)
+    pn, pg = plan.launch()
+    n2, g2 = fsdt_loss_and_grad(m, *bufs, bc, w_bc=0.0, phi_x_bc=0.1, phi_y_bc=-0.1)
+    assert torch.equal(pn, n2)
+    for g, r in zip(pg, g2):
+        assert torch.equal(g, r)
+    only = ops.FsdtPlan(m.geom, *bufs, bc, (0.0, 0.1, -0.1), want_grad=False, q=1.0, wscale=(0.5 * m.h) * (0.5 * m.h), **consts)
+    on, og = only.launch()
+    assert og is None and torch.equal(on, n2)
+    with pytest.raises(ops.DiffNetHipError):
+        ops.FsdtPlan(m.geom, bufs[0].transpose(2, 3), bufs[1], bufs[2], bc)
+    with pytest.raises(ops.DiffNetHipError):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            plan.launch()
+    torch.cuda.synchronize()

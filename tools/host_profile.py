@@ -4,7 +4,7 @@ of the FSDT loss + backward."""
 import cProfile, os, pstats, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffnet_amd import DiffNet2DFEM, DiffNet3DFEM, ops
-from diffnet_amd.elasticity import fsdt_loss
+from diffnet_amd.elasticity import _constants, fsdt_loss, fsdt_loss_and_grad, fsdt_total_loss
 dev = torch.device("cuda:0")
 
 
@@ -49,6 +49,11 @@ def fs():
 
 
 print("fsdt_loss + autograd.grad 513^2 Q2   : %.1f us/call" % wall(fs))
+print("fsdt_total_loss + autograd.grad       : %.1f us/call" % wall(lambda: torch.autograd.grad(fsdt_total_loss(mq, *flds, bcf), flds)))
+print("fsdt_loss_and_grad (no graph)         : %.1f us/call" % wall(lambda: fsdt_loss_and_grad(mq, *flds, bcf)))
+bufs = [t.detach().clone() for t in flds]
+plan = ops.FsdtPlan(mq.geom, *bufs, bcf, q=1.0, wscale=(0.5 * mq.h) * (0.5 * mq.h), **_constants(1.0, 0.25, 0.1, 1.0))
+print("FsdtPlan.launch (prepared)            : %.1f us/call" % wall(plan.launch))
 print("call cache:", ops._CALL_STATS)
 pr = cProfile.Profile()
 pr.enable()

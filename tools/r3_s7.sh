@@ -10,7 +10,7 @@ import json
 d = json.loads(open("gpurun_out/r3_s7/bench.json").read().strip().splitlines()[-1])
 r = d["roofline"]
 print("value %.4g ms/step %.4f frac %.3f kern_avg %.2f us one_batch %.2f us stream %s" % (d["value"], d["ms_per_step"], r["frac"], r["kernel_avg_ms"] * 1e3, r["one_batch_kernel_avg_ms"] * 1e3, r["stream_ceiling"]))
-print(r["rotation_kernel_median_us_by_mask_format"])
+print(r["rotation_kernel_median_us_by_mask_format"]); print(r.get("deeper_rotation"))
 for c in d.get("configs", []):
     print(c)
 print(d.get("slab_3d"))
