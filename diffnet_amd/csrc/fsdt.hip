@@ -470,6 +470,25 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
 #pragma unroll
                     for (int ib = 0; ib < NB; ++ib) g[k][jb][ib] = 0.f;
             fsdt_elem<P, NGP, MID>(p, cu, g);
+#ifdef DN_FSDT_TWICE                  // diagnostic (tools/variant_build.sh): the element arithmetic a second time -- is the launch bound by it?
+            {
+                float cu2[3][NB][NB];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                        for (int ib = 0; ib < NB; ++ib) { cu2[k][jb][ib] = cu[k][jb][ib] + g[k][jb][ib]; asm volatile("" : "+v"(cu2[k][jb][ib])); }
+                float g2[3][NB][NB] = {};
+                fsdt_elem<P, NGP, MID>(p, cu2, g2);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                        for (int ib = 0; ib < NB; ++ib) g[k][jb][ib] = fmaf(1e-30f, g2[k][jb][ib], g[k][jb][ib]);
+            }
+#endif
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
