@@ -334,8 +334,15 @@ static long long num_workgroups(const dn_mesh* m, bool allow_e4 = true) {
         Geom2D g = plan2d_env(m, m->degree, allow_e4);
         return (long long)g.chunks * g.strips * m->batch;
     }
-    Geom3D g = plan3d_env(m);
-    return (long long)g.chunks * g.tiles * g.strips * m->batch;
+    // 3-D: the launch is either the one-element forms or, where q1n2_ok() holds, the two-element node-owner form with its own tiling and strip
+    // height (and its own "PLAN3D" overrides): the partial-sum arrays are laid out for whichever has more workgroups
+    const Geom3D g = plan3d_env(m, false);
+    long long n = (long long)g.chunks * g.tiles * g.strips * m->batch;
+    if (m->ngp == 2) {
+        const Geom3D g2 = plan3d_env(m, true);
+        n = std::max(n, (long long)g2.chunks * g2.tiles * g2.strips * m->batch);
+    }
+    return n;
 }
 
 static int validate_mesh(const dn_mesh* m) {

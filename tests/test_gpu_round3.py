@@ -376,3 +376,46 @@ def test_fsdt_loss_and_grad_and_plan_equal_the_autograd_path(deg, ngp, n, B):
         with torch.cuda.stream(torch.cuda.Stream()):
             plan.launch()
     torch.cuda.synchronize()
+
+
+def test_3d_two_elements_per_thread_edge_shapes():
+    """poisson3d_q1n2_kernel at the edges of its tiling: one or two elements along an axis, nx / ny around the 30-element chunk and 15-row tile
+    widths (tiles overlap by one thread), strips of 1 .. 5 layers through "PLAN3D" "16,16,2,R" (seam layers, a single layer, a last strip with one
+    layer), several samples with different masks, one condition present in either slot -- against the one-element kernel and the oracle."""
+    from diffnet_amd import _lib
+    from oracle.fem_oracle import Oracle
+    shapes = [(2, 2, 2), (4, 2, 3), (2, 17, 2), (30, 15, 4), (32, 16, 5), (34, 17, 3), (60, 31, 2), (62, 32, 6), (64, 2, 9), (6, 46, 7), (92, 3, 4)]
+    for si, sizes in enumerate(shapes):
+        kw = dict(nsd=3, domain_sizes=sizes, domain_lengths=(1.0, 0.7, 1.4), domain_size=sizes[0], ngp_1d=2)
+        m = module(kw)
+        B = 1 + si % 3
+        shape = (B, 1, sizes[2], sizes[1], sizes[0])
+        u, nu, f = cu(seeded(shape, 500 + si)), cu(seeded(shape, 600 + si) + 0.5), cu(seeded(shape, 700 + si))
+        bc = (seeded(shape, 800 + si) < 0.15).to(torch.uint8).to(dev())
+        bc[..., 0] = 1
+        src = (seeded(shape, 900 + si) < 0.05).to(torch.uint8).to(dev())
+        conds = [[(bc, 0.3)], [(src, 1.0), (bc, 0.0)], [(bc.float(), -0.2)]]
+        nelz = sizes[2] - 1
+        try:
+            for plan in [""] + [f"16,16,2,{R}" for R in (1, 2, 3, 5) if R <= max(nelz, 1)]:
+                for d in conds:
+                    _lib.config_set("PLAN3D", plan)
+                    l2, g2 = m.energy_loss_and_grad(u, nu, f, dirichlet=d, c=0.5)
+                    _lib.config_set("PLAN3D", "")
+                    _lib.config_set("Q1_3D_E1", "1")
+                    l1, g1 = m.energy_loss_and_grad(u, nu, f, dirichlet=d, c=0.5)
+                    _lib.config_set("Q1_3D_E1", "")
+                    scale = float(g1.abs().max()) + 1e-30
+                    assert float((g2 - g1).abs().max()) <= 4e-6 * scale, f"{sizes} plan {plan!r}"
+                    np.testing.assert_allclose(float(l2), float(l1), rtol=1e-5, atol=1e-7, err_msg=f"{sizes} plan {plan!r}")
+        finally:
+            _lib.config_set("PLAN3D", "")
+            _lib.config_set("Q1_3D_E1", "")
+        if sizes[0] * sizes[1] * sizes[2] <= 6000:
+            o = Oracle(**kw)
+            ur = u.cpu().clone().requires_grad_(True)
+            ref = o.energy(ur, nu.cpu(), f.cpu(), dirichlet=[(src.cpu().float(), 1.0), (bc.cpu().float(), 0.0)], c=0.5)
+            (gref,) = torch.autograd.grad(ref, ur)
+            l2, g2 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(src, 1.0), (bc, 0.0)], c=0.5)
+            np.testing.assert_allclose(float(l2), float(ref), rtol=2e-5, atol=1e-7)
+            close(g2, gref.numpy(), rtol=1e-4, arel=1e-4)
