@@ -129,6 +129,8 @@ __device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&
 // Sum-factorised one x-Gauss point at a time: x-stage of the three fields for that point (value / x-derivative per node
 // row), the NGP y-points with the constitutive law and the y-transpose, then the x-transpose of that point straight into
 // g -- the live set is one point's stage values and cotangents (36 registers at Q2) instead of all points' (108).
+// (Round 3, measured and removed -- profiles/r3_fsdt_packed_fields.txt: phi_x and phi_y as the halves of packed fp32 registers, 851 -> 700 VALU
+// instructions per element, but 166 -> 188 VGPRs plus 84 bytes of scratch per thread in the marching kernel: 27.6 -> 38.9 us at B = 1, 95 -> 156 at B = 8.)
 // MID (Q2 with the symmetric 3-point rule, checked on the host): the middle Gauss point sits on the middle node, where the basis is
 // (0, 1, 0) and its derivative (-d, 0, +d).  A third of all 1-D contractions then are a copy or one difference instead of three
 // fused multiply-adds: 171 of the element's 954 instructions (fmaf(0, x, a) cannot be folded by the compiler -- x may be a NaN --, so
