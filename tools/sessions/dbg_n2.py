@@ -1,6 +1,6 @@
 import os, sys, torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from test_gpu_parity import cu, dev, module, seeded
 from diffnet_amd import _lib, ops
 for sizes in [(34, 17, 3), (34, 16, 3), (32, 17, 3), (34, 17, 4), (34, 17, 2), (62, 32, 6)]:

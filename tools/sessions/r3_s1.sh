@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 1: chained strips -- parity first, then the rotation timings of the chain lengths, then the bench line
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 O=gpurun_out/r3_s1
 mkdir -p $O

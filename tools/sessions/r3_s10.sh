@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r3_s10
 mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_gpu_round3.py -x -q -k "two_elements" > $O/pytest_n2.log 2>&1 || { tail -40 $O/pytest_n2.log; exit 1; }

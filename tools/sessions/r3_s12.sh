@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r3_s12
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_plans.py -x -q > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }

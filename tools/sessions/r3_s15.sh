@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r3_s15
 mkdir -p $O
 export DN_LIB_PATH=variants/libdn_pk0.so

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r3_s19
 mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_gpu_plans.py -x -q -k "graded" > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }

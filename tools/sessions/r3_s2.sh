@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 2: strip height sweep on rotating batches (is the 16-row strip = 32 KB spacing a DRAM-channel pathology?)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r3_s2
 mkdir -p $O
 export DN_LIB_PATH=$PWD/variants/libdn_w1.so

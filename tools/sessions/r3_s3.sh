@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 3: shared node from the neighbouring lane + non-temporal row loads, with and without chained strips
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r3_s3
 mkdir -p $O
 for lib in w4_lane_nt w1_lane_nt; do

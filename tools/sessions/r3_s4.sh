@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r3_s4
 mkdir -p $O
 for lib in w1 w1_ntc w1_ntall w4_ntc w4_ntall; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 5: full GPU suite on the new defaults, FSDT chain sweep, bench
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r3_s5
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -40 $O/pytest_gpu.log; exit 1; }

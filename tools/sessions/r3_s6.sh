@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r3_s6
 mkdir -p $O
 timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "fsdt" > $O/pytest_fsdt.log 2>&1 || { tail -40 $O/pytest_fsdt.log; exit 1; }
