@@ -14,7 +14,7 @@ One "step" = one evaluation of the Poisson energy loss AND its gradient wrt u (f
 reference's loss body IBN_2D.py:116-134 / e2_cib_neumann-style nu field) over one batch of synthetic nodal
 fields already resident in HBM: 2-D Q1, 512 x 512 nodes, 3 x 3 Gauss points, B samples per GPU (weak
 scaling: each rank owns its own batch shard, like the reference's DDP; the only exchange is the all-reduce
-of the scalar loss).  metric = elements * gauss_pts / s summed over ranks.
+of the scalar losses, one collective per four steps).  metric = elements * gauss_pts / s summed over ranks.
 
 Every launch of the run -- warm-up, timed steps, roofline -- goes through NROT DIFFERENT batches in rotation (own input, mask and
 output arrays each): a training loop never re-reads the same u, and one batch's 268 MB of arrays is about the size of the 256 MB
@@ -457,10 +457,15 @@ def main():
     c = 1.0
     units_per_step = B * m.geom.nelem_total * m.geom.ngp_total
     scale0 = 1.0 / (B * m.geom.nelem_total)
-    # NROT batches in rotation, each with its own u, nu, f, mask and output arrays.  With N > 1 also: PIPE + 1 of them, so that a loss
-    # whose all-reduce is still in flight is never overwritten by a later launch.
-    NROT = 4 if dist is None else PIPE + 1
+    # NROT batches in rotation, each with its own u, nu, f, mask and output arrays.  With N > 1: two GROUPS of PIPE batches whose losses lie next
+    # to each other in one buffer -- the path's only exchange step, the all-reduce of the 4-byte loss, is issued ONCE PER GROUP over the group's PIPE
+    # losses (asynchronously; waited one group later, before the group's slots are written again; all drained before a timed region closes, so
+    # every step's loss IS reduced inside it).  One collective per step would put an RCCL workgroup onto the chip during every launch, and
+    # the launch is exactly one round of resident waves: whichever of its workgroups finds its slot taken starts when the collective ends.
+    grouped = dist is not None and args.sync_sums
+    NROT = 4 if dist is None else (2 * PIPE if grouped else PIPE + 1)
     sets = [make_inputs(shape, dev, 1000 * k + 42 + rank) for k in range(NROT)]
+    loss_buf = torch.zeros(NROT, dtype=torch.float32, device=dev) if grouped else None
     # The Dirichlet condition of BASELINE.md section 3 ("mask on all boundary faces") as the dataset keeps it in HBM:
     #   bits  one bit per node, per sample (diffnet_amd.PackedMask: packed once when the dataset is placed on the device; ANY mask) [default]
     #   u8    one byte per node     f32  the reference's fp32 image     box  no array: derived from the geometry (this workload only)
@@ -474,8 +479,9 @@ def main():
         # the gradient and its per-workgroup partial sums; the loss is formed from them by a one-workgroup kernel on a side stream, i.e.
         # under the NEXT step's launch
         return [_ops.PoissonPlan(m.geom, u, nu, f, None, forms[form](bc), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale0,
-                                 want_out=True, want_sums=True, loss_scale=scale0, async_sums=(not args.sync_sums) if async_sums is None else async_sums)
-                for (u, nu, f, bc) in sets]
+                                 want_out=True, want_sums=True, loss_scale=scale0, async_sums=(not args.sync_sums) if async_sums is None else async_sums,
+                                 loss_out=loss_buf[k:k + 1] if (loss_buf is not None and form == bc_form and async_sums is None) else None)
+                for k, (u, nu, f, bc) in enumerate(sets)]
 
     rot = make_plans(bc_form)
     turn = [0]
@@ -488,7 +494,28 @@ def main():
         last[0] = rot[k]
         return rot[k].launch()
 
+    first_unreduced = [0]          # grouped: the first slot of the current group whose loss no collective has taken yet
+
+    def reduce_slots(a, b):
+        view = loss_buf[a:b]
+        if backend == "nccl":                              # mean over ranks inside the collective: no extra launch
+            work = dist.all_reduce(view, op=dist.ReduceOp.AVG, async_op=True)
+        else:
+            view.div_(world)
+            work = dist.all_reduce(view, async_op=True)
+        pending.append((work, view))
+
     def step():
+        if grouped:
+            k = turn[0]
+            if k % PIPE == 0:
+                while len(pending) > 1:                    # the collective that read this group's slots last (issued PIPE steps ago) is done
+                    pending.pop(0)[0].wait()
+            grad, _, loss = launch_rot()
+            if (k + 1) % PIPE == 0:
+                reduce_slots(first_unreduced[0], k + 1)
+                first_unreduced[0] = (k + 1) % NROT
+            return loss, grad
         grad, _, loss = launch_rot()
         if dist is not None and last[0].async_sums:
             # the loss lives on the side stream: its all-reduce is issued there too, so that the launch stream never waits for it
@@ -517,6 +544,9 @@ def main():
         return loss, grad
 
     def drain():
+        if grouped and first_unreduced[0] != turn[0]:      # a group that is not full yet: its losses so far
+            reduce_slots(first_unreduced[0], turn[0])
+            first_unreduced[0] = turn[0]
         while pending:
             pending.pop(0)[0].wait()
 

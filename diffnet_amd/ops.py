@@ -404,7 +404,7 @@ class PoissonPlan:
 
     def __init__(self, geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
                  out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None, strict=True, strip_select=0, continues=None,
-                 async_sums=False):
+                 async_sums=False, loss_out=None):
         """async_sums: the launch leaves per-workgroup partial sums; the final scalars are formed by a one-workgroup kernel on a SIDE stream
         (dn_poisson_finish_sums), i.e. under whatever the launch stream runs next -- the in-kernel final reduction is a ~3 us serial tail
         of every launch.  The gradient is ready in launch-stream order as always; the sums / the loss are ready on the side stream: call
@@ -420,6 +420,16 @@ class PoissonPlan:
         self.mesh, self.args, self.keep, self.result = _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale,
                                                                         want_out, want_sums, loss_scale, out, strict=strict,
                                                                         reuse=None if continues is None else continues.result)
+        if loss_out is not None:
+            # the float32 loss goes into the caller's one-element tensor (e.g. a slot of a buffer that one collective reduces for several steps)
+            if loss_scale is None or continues is not None:
+                raise ValueError("loss_out needs loss_scale and is not for the second launch of a split evaluation")
+            if not (isinstance(loss_out, torch.Tensor) and loss_out.is_cuda and loss_out.dtype == torch.float32 and loss_out.numel() == 1
+                    and loss_out.device == u.device):
+                raise DiffNetHipError("loss_out must be a one-element float32 tensor on the device of u")
+            self.args.energy_f32 = loss_out.data_ptr()
+            self.keep.append(loss_out)
+            self.result = (self.result[0], self.result[1], loss_out)
         self.args.strip_select = int(strip_select)
         self.args.accumulate_sums = int(continues is not None)
         self.async_sums = bool(async_sums) and self.args.workspace is not None and self.args.workspace != 0

@@ -419,3 +419,27 @@ def test_3d_two_elements_per_thread_edge_shapes():
             l2, g2 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(src, 1.0), (bc, 0.0)], c=0.5)
             np.testing.assert_allclose(float(l2), float(ref), rtol=2e-5, atol=1e-7)
             close(g2, gref.numpy(), rtol=1e-4, arel=1e-4)
+
+
+def test_plan_writes_its_loss_into_a_callers_slot():
+    """PoissonPlan(loss_out=...): the float32 loss of every launch lands in the caller's one-element tensor -- e.g. a slot of a buffer that ONE
+    collective reduces for several steps (bench.py, N > 1) -- and nowhere else; wrong tensors are refused."""
+    from diffnet_amd import ops
+    m = module(dict(domain_size=96, ngp_1d=3))
+    shape = (3, 1, 96, 96)
+    u, nu, f = cu(seeded(shape, 11)), cu(seeded(shape, 12) + 0.5), cu(seeded(shape, 13))
+    bc = boundary_mask(shape).to(torch.uint8).to(dev())
+    kw = dict(alpha=2.0, beta=1.0, c=1.0, wscale=1.0, out_scale=0.5, want_out=True, want_sums=True, loss_scale=0.25)
+    ref = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], **kw).launch()
+    buf = torch.full((4,), -7.0, device=dev())
+    plan = ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], loss_out=buf[2:3], **kw)
+    out, sums, loss = plan.launch()
+    assert loss.data_ptr() == buf[2:3].data_ptr()
+    assert torch.equal(buf[2], ref[2]) and torch.equal(out, ref[0]) and torch.equal(sums, ref[1])
+    assert buf[0] == -7.0 and buf[1] == -7.0 and buf[3] == -7.0
+    with pytest.raises(ops.DiffNetHipError):
+        ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], loss_out=torch.zeros(1), **kw)
+    with pytest.raises(ops.DiffNetHipError):
+        ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], loss_out=buf[0:2], **kw)
+    with pytest.raises(ValueError):
+        ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], loss_out=buf[0:1], **{**kw, "loss_scale": None})
