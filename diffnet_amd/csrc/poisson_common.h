@@ -318,4 +318,9 @@ int launch_poisson3d_q1_g2(const PoissonParams& pp, const Geom3D& g, int batch, 
 int launch_poisson3d_q1_g3(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);
 int launch_poisson3d_q1_g4(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);
 
+// 3-D Q2 / Q3 (poisson3d_gen.hip): element vectors + fixed-order gather assembly; its workspace lies behind the common header
+static constexpr int64_t DN_WS_HEADER = 64 * (1 + 64);   // top counter + DN_NSHARD shard counters, one 64-B line each
+void gen3d_layout(const dn_mesh* m, long long& n1, long long& n2, long long& elem_floats);
+int launch_poisson3d_gen(const PoissonParams& pp, const dn_mesh* m, void* workspace, int64_t workspace_bytes, hipStream_t s);
+
 }  // namespace dn

@@ -158,7 +158,6 @@ namespace dn {
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // workspace layout: [arrival counters][partial energies: nwg doubles][partial sumsq: nwg doubles]
-static constexpr int64_t DN_WS_HEADER = 64 * (1 + 64);   // top counter + DN_NSHARD shard counters, one 64-B line each
 
 static int chunks_for(int logical_threads, int T) {
     return logical_threads <= T ? 1 : ceil_div(logical_threads - 1, T - 1);
@@ -448,6 +447,11 @@ using namespace dn;
 
 extern "C" int64_t dn_poisson_workspace_bytes(const dn_mesh* mesh) {
     if (validate_mesh(mesh) != 0) return DN_E_BADARG;
+    if (mesh->nsd == 3 && mesh->degree > 1) {             // Q2 / Q3 in 3-D: partial sums of its two kernels + the element vectors
+        long long n1, n2, ef;
+        gen3d_layout(mesh, n1, n2, ef);
+        return DN_WS_HEADER + (int64_t)sizeof(double) * (n1 + n2) + (int64_t)sizeof(float) * ef;
+    }
     const long long n = std::max(num_workgroups(mesh, true), num_workgroups(mesh, false));   // either launch plan fits
     return DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * n;
 }
@@ -458,8 +462,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     if (!a || !a->u) return DN_E_BADARG;
     if (a->f && a->f_gp) return DN_E_BADARG;
     if (!a->out && !a->energy && !a->sumsq && !a->energy_f32) return DN_E_BADARG;
-    if (m->nsd == 3 && m->degree != 1) return DN_E_UNSUPPORTED;
     const int P = m->degree;
+    const bool gen3d = m->nsd == 3 && P != 1;            // Q2 / Q3 in 3-D: poisson3d_gen.hip (needs its workspace even without sums)
     if (m->ngp < (P == 1 ? 2 : 3)) return DN_E_UNSUPPORTED;
     bool packed_bc = false;                   // bit-packed / geometry-derived conditions: 2-D Q1, nodal or absent forcing, constant values
     for (int k = 0; k < 2; ++k) {
@@ -491,9 +495,9 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         return ok;
     };
     const bool allow_e4 = vec_ok(4);
-    const long long nwg = num_workgroups(m, allow_e4);
+    const long long nwg = gen3d ? 1 : num_workgroups(m, allow_e4);
     if (nwg >= (1ll << 31)) return DN_E_UNSUPPORTED;                  // the 3-D launch is a 1-D grid
-    if (want_red && (!a->workspace || a->workspace_bytes < DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
+    if (!gen3d && want_red && (!a->workspace || a->workspace_bytes < DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
     if ((int64_t)m->nx * m->ny * (m->nsd == 3 ? m->nz : 1) >= (1ll << 30)) return DN_E_UNSUPPORTED;   // 32-bit in-sample offsets
 
     PoissonParams pp;
@@ -567,6 +571,13 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.acc_sums = (a->accumulate_sums && want_red && !a->defer_sums) ? 1 : 0;      // (deferred: dn_poisson_finish_sums accumulates)
     pp.defer_sums = (a->defer_sums && want_red) ? 1 : 0;
     auto launched = [&](int total) { return a->strip_select == 1 ? std::min(total, 2) : (a->strip_select == 2 ? std::max(total - 2, 0) : total); };
+    if (gen3d) {
+        if (a->strip_select != 0 || a->accumulate_sums || a->defer_sums) return DN_E_UNSUPPORTED;      // no split evaluation of this form
+        rc = launch_poisson3d_gen(pp, m, a->workspace, a->workspace_bytes, s);
+        if (rc) return rc;
+        DN_LAUNCH_CHECK();
+        return 0;
+    }
     if (m->nsd == 2) {
         // chained strips: only the closed-form Q1 kernel has them, and a split evaluation selects whole strips
         const bool chain_ok = P == 1 && a->f_gp == nullptr && config(CFG_Q1_RULE_KERNEL) == nullptr && a->strip_select == 0;

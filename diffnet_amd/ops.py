@@ -576,8 +576,7 @@ def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, ou
     sums = None
     if out is not None:
         args.out = out.data_ptr()
-    if want_sums:
-        sums = reuse[1] if reuse is not None else torch.empty(2, dtype=torch.float64, device=u.device)
+    if want_sums or (mesh.nsd == 3 and mesh.degree > 1):       # (3-D Q2 / Q3: the workspace also holds the element vectors)
         key = (mesh.nsd, mesh.degree, mesh.ngp, mesh.nx, mesh.ny, mesh.nz, B)
         nbytes = _POISSON_WS_BYTES.get(key)
         if nbytes is None:
@@ -587,9 +586,11 @@ def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, ou
             _POISSON_WS_BYTES[key] = nbytes
         ws = _workspace(u.device, nbytes)
         keep.append(ws)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    if want_sums:
+        sums = reuse[1] if reuse is not None else torch.empty(2, dtype=torch.float64, device=u.device)
         args.energy = sums.data_ptr()
         args.sumsq = sums.data_ptr() + 8
-        args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
     loss32 = None
     if loss_scale is not None:
         if not want_sums:

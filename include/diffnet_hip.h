@@ -170,6 +170,9 @@ int dn_probe_march(const float *a, const float *b, const float *c, float *out, i
 int dn_probe_tile(const float *a, const float *b, const float *c, float *out, int32_t B, int32_t ny, int32_t rows_per_tile, int32_t threads,
                   int32_t flags, void *stream);
 
+/* Meshes: nsd = 2, degree 1..3 (ngp 2..4, >= 3 for degree > 1); nsd = 3, degree 1 (marching kernels) and degree 2 / 3 with ngp 3 / 4 (element
+ * vectors + fixed-order gather assembly: the workspace then also holds (degree + 1)^3 floats per element and is needed for every call, with
+ * or without sums; no strip_select / accumulate_sums / defer_sums in that form).  dn_poisson_workspace_bytes says what a mesh needs. */
 int64_t dn_poisson_workspace_bytes(const dn_mesh *mesh);
 int dn_poisson_apply(const dn_mesh *mesh, const dn_poisson_args *args, void *stream);
 /* Second half of a dn_poisson_apply launch with args->defer_sums set (same mesh, same args): the final scalars from the partial sums. */

@@ -443,3 +443,48 @@ def test_plan_writes_its_loss_into_a_callers_slot():
         ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], loss_out=buf[0:2], **kw)
     with pytest.raises(ValueError):
         ops.PoissonPlan(m.geom, u, nu, f, None, [(bc, 0.0)], loss_out=buf[0:1], **{**kw, "loss_scale": None})
+
+
+@pytest.mark.parametrize("kw,B", [(dict(nsd=3, domain_sizes=(9, 7, 5), domain_lengths=(1.0, 0.8, 0.6), domain_size=9, fem_basis_deg=2), 2),
+                                  (dict(nsd=3, domain_sizes=(13, 9, 11), domain_lengths=(1.0, 0.7, 0.9), domain_size=13, fem_basis_deg=2, ngp_1d=4), 1),
+                                  (dict(nsd=3, domain_sizes=(7, 10, 4), domain_lengths=(1.0, 1.2, 0.5), domain_size=7, fem_basis_deg=3), 2),
+                                  (dict(nsd=3, domain_sizes=(10, 7, 13), domain_lengths=(1.0, 0.6, 1.1), domain_size=10, fem_basis_deg=3, ngp_1d=4), 1),
+                                  (dict(nsd=3, domain_size=17, fem_basis_deg=2), 3)])
+def test_fused_3d_q2_q3_vs_oracle(kw, B):
+    """dn_poisson_apply on 3-D meshes of Q2 / Q3 elements (poisson3d_gen.hip: element vectors + fixed-order gather assembly) against the
+    oracle: energy loss and its gradient (nodal forcing, forcing at the Gauss points, no forcing / no nu), weak-form residual and the
+    residual loss with its gradient, Dirichlet conditions with constant values and value fields, uint8 and fp32 masks, per sample; runs
+    of the same call are bitwise equal (no atomics)."""
+    from oracle.fem_oracle import Oracle
+    m, o = module(kw), Oracle(**kw)
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = seeded(shape, 5), seeded(shape, 6, 0.5), seeded(shape, 7)
+    bc = boundary_mask(shape)
+    bc[0, 0, shape[2] // 2, 1:3, 2:4] = 1.0
+    ubc = seeded(shape[2:], 8)
+    fgp = seeded((B, m.geom.ngp_total, *m.geom.elem_shape), 9)
+    ud, nud, fd = u.to(dev()), nu.to(dev()), f.to(dev())
+    for name, (nn, ff, fg, dl) in {"nodal f, value field": (nu, f, None, [(bc, ubc[None, None])]), "f at the Gauss points": (nu, None, fgp, [(bc, 0.3)]),
+                                   "bare": (None, None, None, [(bc, 0.0)]), "two conditions": (nu, f, None, [((seeded(shape, 10) < 0.1).float(), 1.0), (bc, 0.0)])}.items():
+        ur = u.clone().requires_grad_(True)
+        ref = o.energy(ur, nn, ff, f_gp=fg, dirichlet=dl, c=0.5, jac=0.7)
+        (gref,) = torch.autograd.grad(ref, ur)
+        cuo = lambda t: None if t is None else t.to(dev())
+        for u8 in (False, True):
+            dd = [((mk.to(torch.uint8) if u8 else mk).to(dev()), v.to(dev()) if isinstance(v, torch.Tensor) else v) for mk, v in dl]
+            loss, g = m.energy_loss_and_grad(ud, cuo(nn), cuo(ff), f_gp=cuo(fg), dirichlet=dd, c=0.5, jac=0.7)
+            np.testing.assert_allclose(float(loss), float(ref), rtol=2e-5, atol=1e-7, err_msg=name)
+            close(g, gref.numpy(), rtol=1e-4, arel=1e-4)
+            loss2, g2 = m.energy_loss_and_grad(ud, cuo(nn), cuo(ff), f_gp=cuo(fg), dirichlet=dd, c=0.5, jac=0.7)
+            assert torch.equal(g, g2) and torch.equal(loss, loss2), name
+    ur = u.clone().requires_grad_(True)
+    Rref = o.residual_any_degree(ur, nu, f, dirichlet=[(bc, ubc[None, None])], jac=0.25, zero_masks=[bc])
+    (gref,) = torch.autograd.grad(torch.sum(Rref ** 2), ur)
+    d = [(bc.to(dev()), ubc.to(dev()))]
+    R = m.residual(ud, nud, fd, dirichlet=d, jac=0.25)
+    close(R, Rref.detach().numpy(), rtol=1e-4, arel=2e-5)
+    ug = ud.clone().requires_grad_(True)
+    v = m.residual_loss(ug, nud, fd, dirichlet=d, jac=0.25)
+    (g,) = torch.autograd.grad(v, ug)
+    np.testing.assert_allclose(float(v), float(torch.sum(Rref ** 2)), rtol=2e-5)
+    close(g, gref.numpy(), rtol=1e-4, arel=1e-4)

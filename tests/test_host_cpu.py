@@ -45,6 +45,12 @@ def test_launch_planner_rejects_bad_meshes_without_a_gpu():
     assert h.dn_poisson_workspace_bytes(C.byref(m)) > 0
     m.nx = 1
     assert h.dn_poisson_workspace_bytes(C.byref(m)) == -1
+    # 3-D Q2 / Q3 (element vectors + gather assembly): header + partial sums of its two kernels + (P+1)^3 floats per element
+    m.nsd, m.degree, m.ngp, m.batch, m.nx, m.ny, m.nz = 3, 2, 3, 2, 9, 7, 5
+    nel, nnode = 4 * 3 * 2, 9 * 7 * 5
+    assert h.dn_poisson_workspace_bytes(C.byref(m)) == 64 * 65 + 8 * (-(-nel * 2 // 64) + -(-nnode * 2 // 256)) + 4 * 27 * nel * 2
+    m.nx = 10                                                # (nx - 1) not a multiple of the degree
+    assert h.dn_poisson_workspace_bytes(C.byref(m)) == -1
     assert h.dn_poisson_apply(C.byref(m), None, None) == -1          # validation happens before any launch
 
 
