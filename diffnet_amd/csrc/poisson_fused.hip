@@ -587,6 +587,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         pp.nstrips = g.strips;
         g.strips = launched(g.strips);
         if (g.strips == 0) return 0;                         // fewer than three strips: the other launch did everything
+        // (the partial-sum arrays were laid out for nwg workgroups: never launch more than that)
+        if (want_red && (long long)g.chunks * ((g.strips + g.W - 1) / g.W) * m->batch > nwg) return DN_E_WORKSPACE;
         const int NW = g.E * P;
         const bool vec = vec_ok(NW);
         rc = launch2d(pp, g, P, m->ngp, m->batch, vec, s);
@@ -596,6 +598,7 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         pp.nstrips = g.strips;
         g.strips = launched(g.strips);
         if (g.strips == 0) return 0;
+        if (want_red && (long long)g.chunks * g.tiles * g.strips * m->batch > nwg) return DN_E_WORKSPACE;
         const int NW = g.E;
         const bool vec = vec_ok(NW);
         switch (m->ngp) {
