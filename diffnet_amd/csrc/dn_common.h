@@ -151,10 +151,16 @@ __device__ __forceinline__ void load_seg(const T* __restrict__ base, unsigned ro
 template <int NW, bool VEC, typename T>
 __device__ __forceinline__ void load_seg_stream(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[NW + 1]) {
     if constexpr (VEC && NW == 4 && sizeof(T) == 4) {
-        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef T v4t __attribute__((ext_vector_type(4)));
         const unsigned xl = (unsigned)min(x0, nx - NW);
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(base) + (rowoff + xl) * 4u));
+        const v4t v = __builtin_nontemporal_load(reinterpret_cast<const v4t*>(reinterpret_cast<const char*>(base) + (rowoff + xl) * 4u));
         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        dst[NW] = ld_at<T>(base, rowoff + (unsigned)min(x0 + NW, nx - 1));
+    } else if constexpr (VEC && NW == 4 && sizeof(T) == 1) {       // byte masks: the four own nodes as one non-temporal dword
+        const unsigned xl = (unsigned)min(x0, nx - NW);
+        const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + (rowoff + xl)));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = (T)((w >> (8 * k)) & 0xffu);
         dst[NW] = ld_at<T>(base, rowoff + (unsigned)min(x0 + NW, nx - 1));
     } else {
         load_seg<NW, VEC>(base, rowoff, x0, nx, dst);

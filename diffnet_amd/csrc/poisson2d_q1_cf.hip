@@ -281,7 +281,11 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
             for (int k = 0; k < 2; ++k) {
                 if (DN_CF_PF || has_mask[k]) {        // not pipelined: an absent condition costs no load (wave-uniform branch)
                     uint8_t t[NW + 1];
+#if DN_NT_MASK
+                    load_seg_stream<NW, VEC>(mask8[k], rowoff, x0, p.nx, t);
+#else
                     lseg(mask8[k], rowoff, t, NT_NO);
+#endif
                     uint32_t w = 0u;
 #pragma unroll
                     for (int n = 0; n < NW; ++n) w |= (uint32_t)t[n] << (8 * n);

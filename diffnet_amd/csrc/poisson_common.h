@@ -214,6 +214,9 @@ struct BcRaw {
     float fv[2][NW + 1];     // Dirichlet value fields
 };
 
+#ifndef DN_NT_MASK
+#define DN_NT_MASK 1                  // mask images (read once per launch) with non-temporal vector loads, like nu and f (section 4.0 of DESIGN.md)
+#endif
 template <int NW, bool VEC>
 __device__ __forceinline__ void bc_issue(const PoissonParams& p, const SampleBases& sb, unsigned rowoff, int x0, BcRaw<NW>& r) {
 #pragma unroll
@@ -221,11 +224,19 @@ __device__ __forceinline__ void bc_issue(const PoissonParams& p, const SampleBas
         if (sb.mask[k] != nullptr) {
             if (p.bc[k].mask_is_u8) {
                 uint8_t t[NW + 1];
+#if DN_NT_MASK
+                load_seg_stream<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, t);
+#else
                 load_seg<NW, VEC>(reinterpret_cast<const uint8_t*>(sb.mask[k]), rowoff, x0, p.nx, t);
+#endif
 #pragma unroll
                 for (int n = 0; n <= NW; ++n) r.m[k][n] = t[n];
             } else {
+#if DN_NT_MASK
+                load_seg_stream<NW, VEC>(reinterpret_cast<const uint32_t*>(sb.mask[k]), rowoff, x0, p.nx, r.m[k]);
+#else
                 load_seg<NW, VEC>(reinterpret_cast<const uint32_t*>(sb.mask[k]), rowoff, x0, p.nx, r.m[k]);
+#endif
             }
             if (sb.field[k]) load_seg<NW, VEC>(sb.field[k], rowoff, x0, p.nx, r.fv[k]);
         }

@@ -21,7 +21,8 @@ if len(sys.argv) > 1 and sys.argv[1] != "default":
 form = sys.argv[2] if len(sys.argv) > 2 else "box"
 bc = torch.zeros(shape, dtype=torch.uint8, device=dev)
 bc[..., 0] = 1; bc[..., -1] = 1; bc[..., 0, :] = 1; bc[..., -1, :] = 1
-cond = {"box": lambda: [(BoxFaces(), 0.0)], "bits": lambda: [(PackedMask.pack(bc.clone()), 0.0)], "u8": lambda: [(bc.clone(), 0.0)]}[form]
+cond = {"box": lambda: [(BoxFaces(), 0.0)], "bits": lambda: [(PackedMask.pack(bc.clone()), 0.0)], "u8": lambda: [(bc.clone(), 0.0)],
+        "f32": lambda: [(bc.float(), 0.0)]}[form]
 for nb in ([int(v) for v in os.environ['NBS'].split(',')] if 'NBS' in os.environ else ((1, 2, 4, 8, 1) if len(sys.argv) == 1 else (4, 1))):
     plans = [ops.PoissonPlan(m.geom, *sets[k], None, cond(), **kw) for k in range(nb)]
     t0 = time.perf_counter()
