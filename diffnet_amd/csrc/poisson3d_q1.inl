@@ -947,12 +947,17 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     // own pair (clamped into the mesh: nx is even, so a pair is inside or outside as a whole) and the halo node this thread fetches
     const unsigned own_off = (unsigned)min(ey, p.ny - 1) * (unsigned)p.nx + (unsigned)min(x0, p.nx - 2);
     const int lane = tid & 63, wave = tid >> 6;
-    const int hidx = min(wave * 13 + min(lane, 12), 48);       // 49 halo nodes, 13 per wave (lanes 0..12; the other lanes repeat lane 12)
+    // 49 halo nodes, 13 per wave, and ONE load instruction for their u, nu and f: lanes 0..12 fetch u, 13..25 nu, 26..38 f of the wave's 13 nodes
+    // through per-lane 64-bit addresses (a vector-memory instruction costs a wave ~64 cycles of issue whatever its active lanes: three
+    // instructions for 13 lanes each were a third of the kernel's vector-memory issue time); the other lanes repeat lane 38
+    const int hgrp = min(lane / 13, 2), hsub = min(lane - 13 * hgrp, 12);
+    const int hidx = min(wave * 13 + hsub, 48);
     const int hrow = hidx < 33 ? 16 : hidx - 33, hcol = hidx < 33 ? hidx : 32;
     const unsigned halo_off = (unsigned)min(ny0 + hrow, p.ny - 1) * (unsigned)p.nx + (unsigned)min(nx0 + hcol, p.nx - 1);
-    const bool halo_lane = lane < 13 && wave * 13 + lane < 49;
-    float4* const halo_rec0 = (hcol & 1) ? &recO[0][hrow][hcol >> 1] : &recE[0][hrow][hcol >> 1];
-    const unsigned halo_par_stride = (hcol & 1) ? 17u * 16u : 17u * 17u;
+    const bool halo_lane = lane < 39 && wave * 13 + hsub < 49 && (hgrp == 0 || (hgrp == 1 ? HAS_NU : HAS_F));
+    float* const halo_rec0 = reinterpret_cast<float*>((hcol & 1) ? &recO[0][hrow][hcol >> 1] : &recE[0][hrow][hcol >> 1]) + hgrp;      // component .x / .y / .z
+    const unsigned halo_par_stride = 4u * ((hcol & 1) ? 17u * 16u : 17u * 17u);                                                        // floats
+    const float* const halo_src = (hgrp == 1 && HAS_NU) ? sb.nu : ((hgrp == 2 && HAS_F) ? sb.f : sb.u);                               // per lane
 
     const bool has_mask[2] = {sb.mask[0] != nullptr, sb.mask[1] != nullptr};
     const uint8_t* mask8[2];
@@ -963,7 +968,7 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
 
     struct RawNodes2 {
         float2 u, n, f;               // own pair
-        float hu, hn, hf;             // halo node
+        float h;                      // halo node: u, nu or f by lane group
         uint16_t m[2];                // uint8 masks of the own pair (two bytes), per condition
         float2 mf[2];                 // fp32 masks of the own pair
         uint8_t hm[2];
@@ -975,9 +980,7 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         W.u = ld_at<float2>(sb.u, oo);
         if constexpr (HAS_NU) W.n = ld_at<float2>(sb.nu, oo);
         if constexpr (HAS_F) W.f = ld_at<float2>(sb.f, oo);
-        W.hu = ld_at<float>(sb.u, oh);
-        if constexpr (HAS_NU) W.hn = ld_at<float>(sb.nu, oh);
-        if constexpr (HAS_F) W.hf = ld_at<float>(sb.f, oh);
+        W.h = halo_src[oh];
         if constexpr (BC_U8C) {
 #pragma unroll
             for (int k = 0; k < NMASK; ++k) {
@@ -1010,7 +1013,16 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         const int par = zpl & 1;
         recE[par][ty][tx] = record(W.u.x, W.n.x, W.f.x, s0);
         recO[par][ty][tx] = record(W.u.y, W.n.y, W.f.y, s1);
-        if (halo_lane) halo_rec0[par * halo_par_stride] = record(W.hu, W.hn, W.hf, sh);
+        if (halo_lane) {
+            float hv = W.h;
+            if constexpr (BC_U8C) {
+                if (hgrp == 0) {
+#pragma unroll
+                    for (int k = 0; k < NMASK; ++k) hv = ((NMASK == 1 || has_mask[k]) && sh[k]) ? bcval[k] : hv;
+                }
+            }
+            halo_rec0[par * halo_par_stride] = hv;       // (the .w of a halo record is never read; absent nu / f keep the 1 / 0 of the prologue)
+        }
     };
     // From here on a value of type v2f holds the same quantity of the thread's two elements (.x: element at node column x0, .y: at x0 + 1) or
     // of its two nodes: the element arithmetic runs on packed fp32 instructions, one per pair.
@@ -1118,6 +1130,13 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     };
 
     // prologue: planes ez_begin and ez_begin + 1 into LDS (requested together), the lower one staged
+    if (lane < 13 && wave * 13 + lane < 49) {          // the constant components of the halo records (both parities): nu = 1, f = 0, keep = 1
+        float4* const r0 = (hcol & 1) ? &recO[0][hrow][hcol >> 1] : &recE[0][hrow][hcol >> 1];
+        const unsigned st4 = (hcol & 1) ? 17u * 16u : 17u * 17u;
+        r0[0] = make_float4(0.f, 1.f, 0.f, 1.f);
+        r0[st4] = make_float4(0.f, 1.f, 0.f, 1.f);
+    }
+    __syncthreads();
     RawNodes2 W;
     {
         RawNodes2 W0;
