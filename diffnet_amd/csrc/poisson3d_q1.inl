@@ -641,11 +641,16 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
     // in-plane offsets (nodes, clamped into the mesh) of the node this thread owns and of the halo node it fetches
     const unsigned own_off = (unsigned)min(ey, p.ny - 1) * (unsigned)p.nx + (unsigned)min(x0, p.nx - 1);
     const int lane = tid & 63, wave = tid >> 6;
-    const int hidx = min(wave * 9 + min(lane, 8), 32);         // 33 halo nodes, 9 per wave (lanes 0..8; the other lanes repeat lane 8)
+    // 33 halo nodes, 9 per wave; their u, nu and f come from ONE load instruction: lanes 0..8 fetch u, 9..17 nu, 18..26 f of the wave's nine nodes
+    // through per-lane 64-bit addresses (round 3: a vector-memory instruction costs a wave ~64 cycles of issue whatever its active lanes); the
+    // other lanes repeat lane 26.  Each lane writes its one component of the halo record.
+    const int hgrp = min(lane / 9, 2), hsub = min(lane - 9 * hgrp, 8);
+    const int hidx = min(wave * 9 + hsub, 32);
     const int hrow = hidx < 16 ? hidx : 16, hcol = hidx < 16 ? 16 : hidx - 16;
     const unsigned halo_off = (unsigned)min(ny0 + hrow, p.ny - 1) * (unsigned)p.nx + (unsigned)min(nx0 + hcol, p.nx - 1);
-    const bool halo_lane = lane < 9 && wave * 9 + lane < 33;
+    const bool halo_lane = lane < 27 && wave * 9 + hsub < 33 && (hgrp == 0 || (hgrp == 1 ? HAS_NU : HAS_F));
     const int own_rec = ty * 17 + tx, halo_rec = hrow * 17 + hcol;
+    const float* const halo_src = (hgrp == 1 && HAS_NU) ? sb.nu : ((hgrp == 2 && HAS_F) ? sb.f : sb.u);       // per lane
 
     const bool has_mask[2] = {sb.mask[0] != nullptr, sb.mask[1] != nullptr};
     const uint8_t* mask8[2];
@@ -655,15 +660,16 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
 
     // with one condition, slot 0 of mask8 / bcval is the one that is present
     const float bcval[2] = {NMASK == 1 ? (has_mask[0] ? p.bc[0].value : p.bc[1].value) : p.bc[0].value, p.bc[1].value};
-    struct RawNodes { float u[2], n[2], f[2]; uint8_t m[2][2]; float mf[2][2]; };       // [0] own node, [1] halo node
+    struct RawNodes { float u, n, f, h; uint8_t m[2][2]; float mf[2][2]; };       // own node: u, n, f; halo node: h (u, nu or f by lane group); masks [0] own, [1] halo
     auto plane_request = [&](int zreq, RawNodes& W) {
         const unsigned zoff = (unsigned)min(zreq, p.nz - 1) * npl;
         const unsigned o[2] = {zoff + own_off, zoff + halo_off};
+        W.u = ld_at<float>(sb.u, o[0]);
+        if constexpr (HAS_NU) W.n = ld_at<float>(sb.nu, o[0]);
+        if constexpr (HAS_F) W.f = ld_at<float>(sb.f, o[0]);
+        W.h = halo_src[o[1]];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            W.u[h] = ld_at<float>(sb.u, o[h]);
-            if constexpr (HAS_NU) W.n[h] = ld_at<float>(sb.nu, o[h]);
-            if constexpr (HAS_F) W.f[h] = ld_at<float>(sb.f, o[h]);
             if constexpr (BC_U8C) {
 #pragma unroll
                 for (int k = 0; k < NMASK; ++k) {
@@ -674,22 +680,20 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
         }
     };
     auto plane_publish = [&](const RawNodes& W, int zpl) {
-        float4 r[2];
+        float uu = W.u, keep = 1.f, hv = W.h;
+        if constexpr (BC_U8C) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float uu = W.u[h], keep = 1.f;
-            if constexpr (BC_U8C) {
-#pragma unroll
-                for (int k = 0; k < NMASK; ++k) {
-                    const bool set = (NMASK == 1 || has_mask[k]) && (MASK_F32 ? W.mf[h][k] > 0.5f : W.m[h][k] != 0);
-                    uu = set ? bcval[k] : uu;
-                    keep = set ? 0.f : keep;
-                }
+            for (int k = 0; k < NMASK; ++k) {
+                const bool set = (NMASK == 1 || has_mask[k]) && (MASK_F32 ? W.mf[0][k] > 0.5f : W.m[0][k] != 0);
+                uu = set ? bcval[k] : uu;
+                keep = set ? 0.f : keep;
+                const bool seth = hgrp == 0 && (NMASK == 1 || has_mask[k]) && (MASK_F32 ? W.mf[1][k] > 0.5f : W.m[1][k] != 0);
+                hv = seth ? bcval[k] : hv;
             }
-            r[h] = make_float4(uu, HAS_NU ? W.n[h] : 1.f, HAS_F ? W.f[h] : 0.f, keep);
         }
-        rec[zpl & 1][own_rec] = r[0];
-        if (halo_lane) rec[zpl & 1][halo_rec] = r[1];
+        rec[zpl & 1][own_rec] = make_float4(uu, HAS_NU ? W.n : 1.f, HAS_F ? W.f : 0.f, keep);
+        // (the .w of a halo record is never read; absent nu / f keep the 1 / 0 the prologue put there)
+        if (halo_lane) reinterpret_cast<float*>(&rec[zpl & 1][halo_rec])[hgrp] = hv;
     };
     float keep_lo = 1.f, keep_up = 1.f;           // keep of the own node in the lower / upper plane of the current layer
     float u_lo = 0.f, u_up = 0.f, ut_acc = 0.f;   // E1G: the own node's value after the Dirichlet conditions, sum of u * out over the owned nodes
@@ -790,6 +794,11 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
 
     // prologue: planes ez_begin and ez_begin + 1 into LDS (both requested before the first is consumed: one memory latency and one barrier
     // instead of two -- a workgroup of a 128^3 launch marches only ~10 layers), the lower one staged
+    if (lane < 9 && wave * 9 + lane < 33) {          // the constant components of the halo records (both parities): nu = 1, f = 0, keep = 1
+        rec[0][halo_rec] = make_float4(0.f, 1.f, 0.f, 1.f);
+        rec[1][halo_rec] = make_float4(0.f, 1.f, 0.f, 1.f);
+    }
+    __syncthreads();
     RawNodes W;
     {
         RawNodes W0;
