@@ -1036,15 +1036,12 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     // From here on a value of type v2f holds the same quantity of the thread's two elements (.x: element at node column x0, .y: at x0 + 1) or
     // of its two nodes: the element arithmetic runs on packed fp32 instructions, one per pair.
     struct PlaneP { v2f VU[NGP][NGP], VX[NGP], VY[NGP], VN[NGP][NGP], VF[NGP][NGP]; };
-    v2f keep_lo = 1.f, keep_up = 1.f;             // keep of the own node pair in the lower / upper plane of the current layer
-    v2f u_lo = 0.f, u_up = 0.f, ut_acc = 0.f;     // E1G: the own nodes' values after the Dirichlet conditions, sum of u * out over the owned nodes
-    auto plane_gather = [&](int zpl, PlaneP& S, v2f& keep, v2f& uown) {
+    v2f ut_acc = 0.f;                             // E1G: sum of u * out over the owned nodes
+    auto plane_gather = [&](int zpl, PlaneP& S) {
         const int par = zpl & 1;
         const float4 a0 = recE[par][ty][tx], a1 = recO[par][ty][tx], a2 = recE[par][ty][tx + 1];
         const float4 b0 = recE[par][ty + 1][tx], b1 = recO[par][ty + 1][tx], b2 = recE[par][ty + 1][tx + 1];
-        keep = v2f{a0.w, a1.w};
-        uown = v2f{a0.x, a1.x};
-        stage_u3<NGP, v2f>(TV, uown, v2f{a1.x, a2.x}, v2f{b0.x, b1.x}, v2f{b1.x, b2.x}, S.VU, S.VX, S.VY);
+        stage_u3<NGP, v2f>(TV, v2f{a0.x, a1.x}, v2f{a1.x, a2.x}, v2f{b0.x, b1.x}, v2f{b1.x, b2.x}, S.VU, S.VX, S.VY);
         if constexpr (HAS_NU) stage_w3<NGP, UW, v2f>(TV, v2f{a0.y, a1.y}, v2f{a1.y, a2.y}, v2f{b0.y, b1.y}, v2f{b1.y, b2.y}, S.VN);
         if constexpr (HAS_F) stage_w3<NGP, UW, v2f>(TV, v2f{a0.z, a1.z}, v2f{a1.z, a2.z}, v2f{b0.z, b1.z}, v2f{b1.z, b2.z}, S.VF);
         __builtin_amdgcn_sched_barrier(0);
@@ -1099,8 +1096,13 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     };
     // o[node row][node column of the element]: contributions of the thread's two elements (.x, .y) to their 2 x 2 nodes in the plane being
     // finished.  The thread's node columns: c0 = o[.][0].x (+ the left thread's o[.][1].y), c1 = o[.][1].x + o[.][0].y; o[.][1].y goes right.
-    auto emit_plane = [&](const v2f (&o)[2][2], v2f keep, v2f uown, int z, bool owned_plane, const RawNodes2* W, int zpub) {
+    auto emit_plane = [&](const v2f (&o)[2][2], int z, bool owned_plane, const RawNodes2* W, int zpub) {
         DN_STAMP(stamp_C);
+        // keep and (E1G) the value of the own node pair in the plane being finished: re-read from the thread's own records rather than carried in
+        // eight registers through the layer (the kernel sits at its register cap).  The reads are issued BEFORE this call's publish overwrites the
+        // records of the same parity (a wave's LDS accesses execute in order) and land under the barrier.
+        const float4 own0 = recE[z & 1][ty][tx], own1 = recO[z & 1][ty][tx];
+        const v2f keep = {own0.w, own1.w}, uown = {own0.x, own1.x};
         const float left0 = lane_from_left(o[0][1].y, from_left, nfirst);
         xch[par][tid] = make_float2(o[1][0].x + lane_from_left(o[1][1].y, from_left, nfirst), o[1][1].x + o[1][0].y);
         if (W != nullptr) plane_publish(*W, zpub);
@@ -1120,7 +1122,7 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         pend_st = st && sb.out != nullptr && x0 < p.nx;
         par ^= 1;
     };
-    auto layer = [&](int ez, const PlaneP& L, const PlaneP& U, v2f keep, v2f uown, const RawNodes2* W) {
+    auto layer = [&](int ez, const PlaneP& L, const PlaneP& U, const RawNodes2* W) {
         const bool own_layer = ez >= ez_own;
         const v2f cnt = ((own_layer && owner) ? 1.f : 0.f) * okv;
         v2f o[2][2], tU[NGP][NGP], tX[NGP], tY[NGP], e1, e2;
@@ -1135,7 +1137,7 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         e2_acc2 = vfma(cnt, e2, e2_acc2);
         plane_transpose(tU, tX, tY, o);
         __builtin_amdgcn_sched_barrier(0);
-        emit_plane(o, keep, uown, ez, own_layer, W, ez + 2);
+        emit_plane(o, ez, own_layer, W, ez + 2);
     };
 
     // prologue: planes ez_begin and ez_begin + 1 into LDS (requested together), the lower one staged
@@ -1155,7 +1157,7 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         plane_publish(W, ez_begin + 1);
     }
     __syncthreads();
-    plane_gather(ez_begin, SA, keep_lo, u_lo);
+    plane_gather(ez_begin, SA);
     __syncthreads();
     int ez = ez_begin;
 #if defined(DN_STAMP3D)
@@ -1166,16 +1168,16 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         plane_request(ez + 2, W);                 // lands while this layer is computed; published before the layer's barrier
         flush_store();
         DN_STAMP(stamp_A);
-        plane_gather(ez + 1, SB, keep_up, u_up);
+        plane_gather(ez + 1, SB);
         DN_STAMP(stamp_B);
-        layer(ez, SA, SB, keep_lo, u_lo, &W);
+        layer(ez, SA, SB, &W);
         DN_STAMP(stamp_E);
         plane_request(ez + 3, W);
         flush_store();
         DN_STAMP(stamp_A);
-        plane_gather(ez + 2, SA, keep_lo, u_lo);
+        plane_gather(ez + 2, SA);
         DN_STAMP(stamp_B);
-        layer(ez + 1, SB, SA, keep_up, u_up, &W);
+        layer(ez + 1, SB, SA, &W);
         DN_STAMP(stamp_E);
 #if defined(DN_STAMP3D)
         stamp_n += 2;
@@ -1184,15 +1186,15 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     bool odd = false;
     if (ez < ez_end) {
         flush_store();
-        plane_gather(ez + 1, SB, keep_up, u_up);
-        layer(ez, SA, SB, keep_lo, u_lo, nullptr);
+        plane_gather(ez + 1, SB);
+        layer(ez, SA, SB, nullptr);
         odd = true;
     }
     flush_store();
     if (ez_end == p.nelz) {       // the last strip owns the top boundary plane: only the layer below contributes
         v2f o[2][2];
         plane_transpose(cU, cX, cY, o);
-        emit_plane(o, odd ? keep_up : keep_lo, odd ? u_up : u_lo, p.nz - 1, true, nullptr, 0);
+        emit_plane(o, p.nz - 1, true, nullptr, 0);
         flush_store();
     }
 #if defined(DN_STAMP3D)
