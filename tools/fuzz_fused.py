@@ -93,8 +93,58 @@ def _one(case, rng, dev, failures, verbose):
             print("EXC  " + desc + f"  {type(ex).__name__}: {str(ex)[:200]}", flush=True)
 
 
+def run_fsdt(ncases=40, seed=0, verbose=True):
+    """The fused FSDT plate residuals (dn_fsdt_apply: one launch, in-kernel sums and norms) against the same residuals composed from the
+    single-launch operators (elasticity.fsdt_residuals_composed): random sizes, degrees, rules, masks, boundary values, launch plans."""
+    from diffnet_amd.elasticity import _constants, fsdt_residuals_composed
+    dev = torch.device("cuda:0")
+    rng = random.Random(seed)
+    failures = []
+    for case in range(ncases):
+        deg = rng.choice([1, 2, 2, 3])
+        ngp = rng.choice([2, 3, 4]) if deg == 1 else rng.choice([3, 4])
+        nel = [rng.choice([1, 2, 3, 5, 31, 63, 64, 65, 127, 190, 191, 192, 200]), rng.choice([1, 2, 3, 4, 7, 16, 33, 50])]
+        sizes = tuple(e * deg + 1 for e in nel)
+        B = rng.choice([1, 1, 2, 3])
+        m = DiffNet2DFEM(None, nsd=2, domain_sizes=sizes + (1,), domain_lengths=(1.0, rng.choice([1.0, 0.6]), 1.0), domain_size=sizes[0], fem_basis_deg=deg,
+                         ngp_1d=ngp).to(dev)
+        shape = (B, 1, sizes[1], sizes[0])
+        g = torch.Generator().manual_seed(1000 + case)
+        flds = [torch.rand(shape, generator=g).to(dev) for _ in range(3)]
+        mode = rng.choice(["f32", "u8", "f32"])
+        bc = (torch.rand(shape if rng.random() < 0.6 else (1,) + shape[1:], generator=g) < 0.2).float().to(dev)
+        bcm = bc if mode == "f32" else bc.to(torch.uint8)
+        vals = [rng.choice([0.0, 0.1, -0.2]) for _ in range(3)]
+        plan = rng.choice(["", "", "192,%d" % rng.choice([1, 2, 3, 7]), "64,%d,%d" % (rng.choice([1, 2, 3, 5]), rng.choice([2, 3, 4, 7, 12])), "128,%d" % rng.choice([2, 4])])
+        kw = dict(E=rng.choice([1.0, 2.5]), v=0.25, h=rng.choice([0.1, 0.3]), K_s=rng.choice([1.0, 5.0 / 6.0]), q=rng.choice([1.0, 0.0, -2.0]))
+        desc = f"fsdt case {case}: deg={deg} ngp={ngp} sizes={sizes} B={B} mask={mode} shared={bc.shape[0] == 1 and B > 1} values={vals} plan={plan!r}"
+        try:
+            ref = fsdt_residuals_composed(m, *flds, bc.expand(shape) if bc.shape[0] != B else bc, *vals, hx=m.hx, hy=m.hy, **kw)
+            _lib.config_set("PLAN_FSDT", plan)
+            got, sums, norms = ops.fsdt_apply(m.geom, *flds, bcm, tuple(vals), q=kw["q"], wscale=(0.5 * m.hx) * (0.5 * m.hy), want_norms=True,
+                                              **_constants(kw["E"], kw["v"], kw["h"], kw["K_s"]))
+            _lib.config_set("PLAN_FSDT", "")
+            errs = [float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12) for a, b in zip(got, ref)]
+            serr = [abs(float(sums[k]) - float((ref[k].double() ** 2).sum())) / (float((ref[k].double() ** 2).sum()) + 1e-30) for k in range(3)]
+            nerr = [abs(float(norms[k]) ** 2 - float(sums[k])) / (float(sums[k]) + 1e-30) for k in range(3)]
+            ok = max(errs) < 3e-4 and max(serr) < 1e-4 and max(nerr) < 1e-5
+            if not ok:
+                failures.append(desc + f"  out {max(errs):.1e} sums {max(serr):.1e} norms {max(nerr):.1e}")
+            if verbose:
+                print(("ok   " if ok else "FAIL ") + desc + f"  out {max(errs):.1e} sums {max(serr):.1e} norms {max(nerr):.1e}", flush=True)
+        except Exception as ex:                        # noqa: BLE001
+            _lib.config_set("PLAN_FSDT", "")
+            failures.append("EXC  " + desc + f"  {type(ex).__name__}: {str(ex)[:200]}")
+            print("EXC  " + desc + f"  {type(ex).__name__}: {str(ex)[:200]}", flush=True)
+    return failures
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    fails = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    fails = run(n, seed)
     print(f"{n - len(fails)} of {n} cases agree")
+    fails2 = run_fsdt(max(n // 2, 1), seed)
+    print(f"{max(n // 2, 1) - len(fails2)} of {max(n // 2, 1)} FSDT cases agree")
+    fails += fails2
     sys.exit(1 if fails else 0)
