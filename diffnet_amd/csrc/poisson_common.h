@@ -171,7 +171,7 @@ __device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, fl
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        // the last arriver's loop sits on the critical path of the whole launch (every other workgroup has finished): eight partials of
+        // the last arriver's loop sits on the critical path of the whole launch (every other workgroup has finished): sixteen partials of
         // each sum are requested before the first is added (one L2 round trip per 16 partials instead of per 1; 2048 workgroups x 128
         // threads: 1 trip instead of 16).  Same per-thread order of additions as the plain loop: bitwise the same sums.
         double e = 0.0, s = 0.0;
