@@ -273,7 +273,7 @@ __device__ __forceinline__ void load_own(const T* __restrict__ base, unsigned ro
 template <int NW, bool VEC>
 __device__ __forceinline__ void store_seg(float* __restrict__ base, unsigned rowoff, int x0, int nx, const float (&src)[NW]) {
     if constexpr (VEC && (NW == 2 || NW == 4)) {
-        if (x0 < nx) {
+        if (x0 + NW <= nx) {                          // (== x0 < nx where rows are a multiple of NW nodes wide; rows of 4 k + 1 nodes: the thread column past the last full one stores nothing)
             using V = typename VecT<NW>::type;
             V v;
             float* vf = reinterpret_cast<float*>(&v);

@@ -24,13 +24,17 @@ namespace dn {
 
 // CF_BC_PACKED: bit-packed masks / box faces with constant values; CF_PK_NB1 / CF_PK_NB2: one / two of the conditions are bit arrays
 // (compile-time: a load inside a wave-uniform branch costs an s_waitcnt vmcnt(0) where the branch joins)
-enum : int { CF_NU = 1, CF_F = 2, CF_BC = 8, CF_BC_U8C = 16, CF_BC_PACKED = 32, CF_PK_NB1 = 64, CF_PK_NB2 = 128 };
+enum : int { CF_NU = 1, CF_F = 2, CF_BC = 8, CF_BC_U8C = 16, CF_BC_PACKED = 32, CF_PK_NB1 = 64, CF_PK_NB2 = 128, CF_UA = 256 };
+// CF_UA (E = 4, vector accesses, one strip per workgroup): rows of 4 k + 1 nodes -- the 2^n + 1 meshes.  The 16-byte row accesses are then aligned to 4 bytes
+// only (the hardware takes that), and the mesh's LAST node column belongs to the last full thread column (its node x0 + 4) instead of to a thread column of
+// its own: the launch has the geometry of the 4 k mesh (513^2 x 64: 112.9 -> the time of 512^2, tools/time_2d_sizes.py).
 
 template <int E>
 struct CfRow {
     float u[E + 1], n[E + 1], f[E + 1];
     float g[E + 1];          // x-stage of the forcing term: (1-D element mass matrix in x) applied to f over the thread's own elements
     float keep[E];
+    float keepx;             // CF_UA: keep of the node x0 + E (the mesh's last node column in the last thread column)
     BcRaw<E> bc;
     uint32_t m8[2][2];
     uint32_t mb[2];          // CF_BC_PACKED: bits of the row's nodes x0, x0 + 1, ... from the bit arrays (bit n = node x0 + n)
@@ -126,6 +130,8 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     constexpr int NW = E;
     constexpr bool HAS_NU = (FL & CF_NU) != 0, HAS_F = (FL & CF_F) != 0;
     constexpr bool BC_ANY = (FL & (CF_BC | CF_BC_U8C | CF_BC_PACKED)) != 0, BC_U8C = (FL & CF_BC_U8C) != 0, BC_PACKED = (FL & CF_BC_PACKED) != 0;
+    constexpr bool UA = (FL & CF_UA) != 0;
+    static_assert(!UA || (E == 4 && VEC && W == 1 && !DN_CF_REV && !DN_CF_PF && DN_CF_DPPX == 0), "CF_UA: four elements per thread, vector accesses, plain upward march");
     static_assert(W == 1 || (!DN_CF_REV && !DN_CF_PF), "chained sub-strips: plain upward march only");
     // W > 1: the workgroup holds W sub-strips of CF_TS threads each; sub (wave-uniform) is this thread's sub-strip
     const int T = W > 1 ? CF_TS : (int)blockDim.x;
@@ -150,6 +156,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     const int ex0 = q * E;
     const int x0 = ex0;
     const bool col_owner = !(chunk > 0 && tid == 0);
+    const bool lastcol = UA && x0 + NW == p.nx - 1;      // this thread's shared node is the mesh's last node column: nobody to the right owns it
     const int64_t nps = (int64_t)p.nx * p.ny;
     const SampleBases sb = sample_bases(p, b, nps);
     const int R = p.rows_per_strip;
@@ -301,6 +308,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     auto row_bc = [&](CfRow<E>& r) {
 #pragma unroll
         for (int n = 0; n < NW; ++n) r.keep[n] = 1.f;
+        if constexpr (UA) r.keepx = 1.f;
         if constexpr (BC_PACKED) {
             unsigned b0 = r.bx[0], b1 = r.bx[1];
             if constexpr (NB == 2) { b0 |= r.mb[0] & bsel[0]; b1 |= r.mb[1] & bsel[1]; }
@@ -312,6 +320,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
                 r.u[n] = (b1 & (1u << n)) ? v1 : r.u[n];
                 if (n < NW) r.keep[n] = ((b0 | b1) & (1u << n)) ? 0.f : 1.f;
             }
+            if constexpr (UA) r.keepx = ((b0 | b1) & (1u << NW)) ? 0.f : 1.f;
         } else if constexpr (BC_U8C) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -322,11 +331,20 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
                         const bool set = has_mask[k] && (n < NW ? ((r.m8[k][0] >> (8 * n)) & 0xffu) != 0u : r.m8[k][1] != 0u);
                         r.u[n] = set ? val : r.u[n];
                         if (n < NW) r.keep[n] = set ? 0.f : r.keep[n];
+                        else if constexpr (UA) r.keepx = set ? 0.f : r.keepx;
                     }
                 }
             }
         } else if constexpr (BC_ANY) {
-            bc_apply<NW>(p, sb, r.bc, r.u, r.keep);
+            if constexpr (UA) {
+                float k5[NW + 1];
+                bc_apply_all<NW>(p, sb, r.bc, r.u, k5);
+#pragma unroll
+                for (int n = 0; n < NW; ++n) r.keep[n] = k5[n];
+                r.keepx = k5[NW];
+            } else {
+                bc_apply<NW>(p, sb, r.bc, r.u, r.keep);
+            }
         }
     };
 
@@ -339,11 +357,15 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     float pend_v[NW];
     unsigned pend_row = 0u;
     bool pend_st = false;
+    float pend_x = 0.f;          // CF_UA: the last node column's value (last thread column)
     auto flush_store = [&]() {
         if (pend_st) store_seg<NW, VEC>(sb.out, pend_row, x0, p.nx, pend_v);
+        if constexpr (UA) {
+            if (pend_st && lastcol) st_at<float>(sb.out, pend_row + (unsigned)(p.nx - 1), pend_x);
+        }
         pend_st = false;
     };
-    auto emit_row = [&](const float (&o)[NW + 1], const float (&keep)[NW], int yr, bool owned_row) {
+    auto emit_row = [&](const float (&o)[NW + 1], const float (&keep)[NW], int yr, bool owned_row, float keepx = 1.f) {
         float left;
         if constexpr (W > 1) {
             // inside a wave: lane l takes o[NW] of lane l - 1 (ds_bpermute); across the two waves: one LDS word per row + a row counter
@@ -364,12 +386,18 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
             left = (tid > 0) ? xch[par][tid - 1] : 0.f;
             par ^= 1;
         }
-        const bool st = owned_row && col_owner;
+        // (CF_UA: the thread column right of the last full one receives the last node column's contribution over the hand-over, but does not own it)
+        const bool st = owned_row && col_owner && (!UA || x0 + NW <= p.nx - 1);
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             const float t = (o[n] + (n == 0 ? left : 0.f)) * keep[n];
             sq_acc = st ? fmaf(t, t, sq_acc) : sq_acc;       // nodes beyond the domain receive no contribution: t == 0
             pend_v[n] = t * p.out_scale;
+        }
+        if constexpr (UA) {               // the mesh's last node column: finished by the thread column left of it (no thread to hand it to)
+            const float t = o[NW] * keepx;
+            sq_acc = (st && lastcol) ? fmaf(t, t, sq_acc) : sq_acc;
+            pend_x = t * p.out_scale;
         }
         pend_row = (unsigned)(ysgn * yr + yoff) * (unsigned)p.nx;
         pend_st = st && sb.out != nullptr;
@@ -520,7 +548,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
 #pragma unroll
             for (int n = 0; n < NW; ++n) lds_st(s0 + (5 * NW + 5 + n) * CF_TS * 4, L.keep[n]);
         } else {
-            emit_row(o, L.keep, ey, ey >= r_from);
+            emit_row(o, L.keep, ey, ey >= r_from, L.keepx);
         }
     };
     // chained strips: row / carry hand-over with the neighbouring strip of the workgroup.  Thread t of one strip talks to thread t of the
@@ -682,7 +710,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
         for (int n = 0; n <= NW; ++n) o[n] = odd ? carryB[n] : carryA[n];
 #pragma unroll
         for (int n = 0; n < NW; ++n) keep[n] = odd ? RB.keep[n] : RA.keep[n];
-        emit_row(o, keep, p.ny - 1, true);
+        emit_row(o, keep, p.ny - 1, true, odd ? RB.keepx : RA.keepx);
         flush_store();
     }
     if constexpr (W > 1) {
@@ -728,7 +756,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
 
 template <int E, bool VEC, int FL>
 static void cf_launch_one(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
-    if constexpr (E == 4 && VEC && DN_CF_W > 1) {
+    if constexpr (E == 4 && VEC && DN_CF_W > 1 && (FL & CF_UA) == 0) {
         if (g.W == DN_CF_W) {         // chained sub-strips (plan2d): W strips per workgroup
             hipLaunchKernelGGL((poisson2d_q1_cf_kernel<E, VEC, FL, DN_CF_W>), dim3(g.chunks, (g.strips + DN_CF_W - 1) / DN_CF_W, batch),
                                dim3(CF_TS * DN_CF_W), 0, s, pp);
@@ -738,7 +766,7 @@ static void cf_launch_one(const PoissonParams& pp, const Geom2D& g, int batch, h
     hipLaunchKernelGGL((poisson2d_q1_cf_kernel<E, VEC, FL, 1>), dim3(g.chunks, g.strips, batch), dim3(g.T), 0, s, pp);
 }
 
-template <int E, bool VEC>
+template <int E, bool VEC, int UAF = 0>
 static void cf_launch_flags(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
     const bool any = pp.bc[0].kind >= 0 || pp.bc[1].kind >= 0;
     bool u8c = any, packed = false;
@@ -749,12 +777,12 @@ static void cf_launch_flags(const PoissonParams& pp, const Geom2D& g, int batch,
     const int nbits = (pp.bc[0].kind == DN_MASK_BITS) + (pp.bc[1].kind == DN_MASK_BITS);
     const int nf = (pp.nu ? CF_NU : 0) | (pp.f ? CF_F : 0);
 #define DN_CF(FLAGS)                                                                         \
-    (!any ? cf_launch_one<E, VEC, (FLAGS)>(pp, g, batch, s)                                  \
-          : packed ? (nbits == 2 ? cf_launch_one<E, VEC, (FLAGS) | CF_BC_PACKED | CF_PK_NB2>(pp, g, batch, s)          \
-                     : nbits == 1 ? cf_launch_one<E, VEC, (FLAGS) | CF_BC_PACKED | CF_PK_NB1>(pp, g, batch, s)        \
-                                  : cf_launch_one<E, VEC, (FLAGS) | CF_BC_PACKED>(pp, g, batch, s))                   \
-          : u8c ? cf_launch_one<E, VEC, (FLAGS) | CF_BC_U8C>(pp, g, batch, s)                \
-                : cf_launch_one<E, VEC, (FLAGS) | CF_BC>(pp, g, batch, s))
+    (!any ? cf_launch_one<E, VEC, (FLAGS) | UAF>(pp, g, batch, s)                                  \
+          : packed ? (nbits == 2 ? cf_launch_one<E, VEC, (FLAGS) | UAF | CF_BC_PACKED | CF_PK_NB2>(pp, g, batch, s)          \
+                     : nbits == 1 ? cf_launch_one<E, VEC, (FLAGS) | UAF | CF_BC_PACKED | CF_PK_NB1>(pp, g, batch, s)        \
+                                  : cf_launch_one<E, VEC, (FLAGS) | UAF | CF_BC_PACKED>(pp, g, batch, s))                   \
+          : u8c ? cf_launch_one<E, VEC, (FLAGS) | UAF | CF_BC_U8C>(pp, g, batch, s)                \
+                : cf_launch_one<E, VEC, (FLAGS) | UAF | CF_BC>(pp, g, batch, s))
     switch (nf) {
         case 0: DN_CF(0); break;
         case CF_NU: DN_CF(CF_NU); break;
@@ -768,6 +796,11 @@ int poisson2d_q1_cf_chain() { return DN_CF_W > 1 && !DN_CF_REV && !DN_CF_PF ? DN
 
 int launch_poisson2d_q1_cf(const PoissonParams& pp, const Geom2D& g, int batch, bool vec, hipStream_t s) {
     if (g.W > 1 && !(g.W == poisson2d_q1_cf_chain() && g.E == 4 && vec && g.T == CF_TS && g.R + 3 <= CF_NSLOT)) return DN_E_BADARG;
+    if (g.ua) {                   // rows of 4 k + 1 nodes (plan2d): the vector kernel on 4-byte aligned rows, last node column in the last thread column
+        if (g.E != 4 || g.W != 1 || (pp.nx & 3) != 1 || pp.nx < 9) return DN_E_BADARG;
+        cf_launch_flags<4, true, CF_UA>(pp, g, batch, s);
+        return 0;
+    }
     if (g.E == 4 && vec) { cf_launch_flags<4, true>(pp, g, batch, s); return 0; }
     if (g.E == 2 && vec) { cf_launch_flags<2, true>(pp, g, batch, s); return 0; }
     if (g.E == 2) { cf_launch_flags<2, false>(pp, g, batch, s); return 0; }

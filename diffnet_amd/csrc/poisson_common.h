@@ -314,7 +314,7 @@ __device__ __forceinline__ void bc_nodes(const PoissonParams& p, const SampleBas
     }
 }
 
-struct Geom2D { int T, E, chunks, strips, R, W = 1; };     // W: strips chained per workgroup (closed-form Q1 kernel only)
+struct Geom2D { int T, E, chunks, strips, R, W = 1; bool ua = false; };     // W: strips chained per workgroup; ua: rows of 4 k + 1 nodes on the vector kernel (closed-form Q1 kernel only)
 struct Geom3D { int TX, TY, E, chunks, tiles, strips, R; };
 
 // 2-D Q1 marching kernels are compiled one translation unit per NGP (poisson2d_q1_g{2,3,4}.hip)

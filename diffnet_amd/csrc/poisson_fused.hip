@@ -166,17 +166,23 @@ static int chunks_for(int logical_threads, int T) {
 // Pick elements-per-thread, block width and strip height so that (a) the x extent wastes few lanes,
 // (b) the launch has >= ~4 workgroups per CU when the problem allows it, (c) the marched strips are
 // long enough that the one recomputed layer per strip stays a small fraction.
-static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true, bool chain_ok = false) {
+// allow_ua: the launch goes to the closed-form Q1 kernel, which also takes rows of 4 k + 1 nodes (the 2^n + 1 meshes) four elements per thread: unaligned
+// 16-byte row accesses, the last node column owned by the last thread column -- the geometry of the 4 k mesh (poisson2d_q1_cf.hip, CF_UA)
+static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true, bool chain_ok = false, bool allow_ua = false) {
     Geom2D g;
     const int nx = m->nx, nely = (m->ny - 1) / P;
+    // (from 321 nodes per row on: below that the narrower geometry costs more in strip seams than the vector accesses save -- 257^2 x 64: 26.2 against
+    // 23.4 us, 321^2: 42.0 against 45.7, 513^2: 76 against 108, 1025^2 x 15: 63.5 against 85.6; tools/time_2d_sizes.py, profiles/r3_2d_widths.txt)
+    const bool ua = allow_ua && P == 1 && (nx & 3) == 1 && nx >= 321;
     const int maxE = (P == 1) ? 4 : (P == 2 ? 2 : 1);
     const int minE = (P == 1) ? 2 : 1;                  // the Q1 marching kernel is built for E = 2 and 4
     double best = -1.0;
     g.T = 64; g.E = minE; g.chunks = 1;
     for (int E = minE; E <= maxE; E *= 2) {
         const int NW = E * P;
-        if (P == 1 && E == 4 && (nx % 4 != 0 || !allow_e4)) continue;   // E = 4 exists only with aligned vector rows
-        const int Q = (nx - 1) / NW + 1;                 // logical thread columns
+        if (ua && E != 4) continue;
+        if (P == 1 && E == 4 && !ua && (nx % 4 != 0 || !allow_e4)) continue;   // E = 4 exists only with aligned vector rows (or as the CF_UA form)
+        const int Q = ua ? (nx - 1) / NW : (nx - 1) / NW + 1;                   // logical thread columns
         for (int T = 64; T <= 256; T += 64) {            // whole waves: 64, 128, 192, 256 threads
             const int chunks = chunks_for(Q, T);
             const double util = (double)Q / ((double)chunks * T);
@@ -202,8 +208,9 @@ static Geom2D plan2d(const dn_mesh* m, int P, bool allow_e4 = true, bool chain_o
     //    layers and halo rows: chained strips of 2-4 rows win 12-18 % at B <= 4 and 2-5 % up to B = 24 (profiles/r3_plan2d_small.txt).  Strip
     //    height: the smallest of 2, 4, 8 that keeps the launch within 1.5 rounds of waves.
     g.W = 1;
+    g.ua = ua;
     const int cw = poisson2d_q1_cf_chain();
-    if (chain_ok && P == 1 && cw > 1 && g.E == 4 && g.T == 128 && g.R < 16) {
+    if (chain_ok && !ua && P == 1 && cw > 1 && g.E == 4 && g.T == 128 && g.R < 16) {
         int Rc = 2;
         while (Rc < 16 && waves_per_strip * ceil_div(nely, Rc) > 6144) Rc *= 2;
         if (Rc < 16 && ceil_div(nely, Rc) >= cw) { g.R = Rc; g.strips = ceil_div(nely, Rc); g.W = cw; }
@@ -297,18 +304,18 @@ static Geom3D plan3d(const dn_mesh* m, bool allow_e2 = false) {
 }
 
 // dn_config_set("PLAN2D", "T,E,R") / ("PLAN3D", "TX,TY,E,R") override the launch geometry (tuning experiments only).
-static Geom2D plan2d_env(const dn_mesh* m, int P, bool allow_e4 = true, bool chain_ok = false) {
-    Geom2D g = plan2d(m, P, allow_e4, chain_ok);
+static Geom2D plan2d_env(const dn_mesh* m, int P, bool allow_e4 = true, bool chain_ok = false, bool allow_ua = false) {
+    Geom2D g = plan2d(m, P, allow_e4, chain_ok, allow_ua);
     const char* e = config(CFG_PLAN2D);
     int T, E, R, W = 0;
     if (e && sscanf(e, "%d,%d,%d,%d", &T, &E, &R, &W) >= 3 && T >= 64 && T <= 256 && (E == 1 || E == 2 || E == 4) && R >= 1 &&
-        !(P == 1 && (E == 1 || (E == 4 && (m->nx % 4 != 0 || !allow_e4))))) {
+        !(P == 1 && (E == 1 || (E == 4 && !g.ua && (m->nx % 4 != 0 || !allow_e4)) || (g.ua && E != 4)))) {
         const int nely = (m->ny - 1) / P;
         g.T = T; g.E = E; g.R = R > nely ? nely : R;
-        g.chunks = chunks_for((m->nx - 1) / (E * P) + 1, T);
+        g.chunks = chunks_for(g.ua ? (m->nx - 1) / 4 : (m->nx - 1) / (E * P) + 1, T);
         g.strips = ceil_div(nely, g.R);
         const int cw = poisson2d_q1_cf_chain();        // "T,E,R,W": W = 1 (or absent) one strip per workgroup, W >= 2 the library's chain length where it applies
-        g.W = (W >= 2 && cw > 1 && P == 1 && E == 4 && T == 128 && g.R + 3 <= 64 && g.R >= 2) ? cw : 1;
+        g.W = (W >= 2 && !g.ua && cw > 1 && P == 1 && E == 4 && T == 128 && g.R + 3 <= 64 && g.R >= 2) ? cw : 1;
     }
     return g;
 }
@@ -330,8 +337,9 @@ static Geom3D plan3d_env(const dn_mesh* m, bool allow_e2 = false) {
 
 static long long num_workgroups(const dn_mesh* m, bool allow_e4 = true) {
     if (m->nsd == 2) {
-        Geom2D g = plan2d_env(m, m->degree, allow_e4);
-        return (long long)g.chunks * g.strips * m->batch;
+        const Geom2D g = plan2d_env(m, m->degree, allow_e4);
+        const Geom2D gu = plan2d_env(m, m->degree, allow_e4, false, true);          // (the CF_UA form of 4 k + 1 wide meshes has its own geometry)
+        return std::max((long long)g.chunks * g.strips, (long long)gu.chunks * gu.strips) * m->batch;
     }
     // 3-D: the launch is either the one-element forms or, where q1n2_ok() holds, the two-element node-owner form with its own tiling and strip
     // height (and its own "PLAN3D" overrides): the partial-sum arrays are laid out for whichever has more workgroups
@@ -581,7 +589,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     if (m->nsd == 2) {
         // chained strips: only the closed-form Q1 kernel has them, and a split evaluation selects whole strips
         const bool chain_ok = P == 1 && a->f_gp == nullptr && config(CFG_Q1_RULE_KERNEL) == nullptr && a->strip_select == 0;
-        Geom2D g = plan2d_env(m, P, allow_e4, chain_ok);
+        const bool cf_kernel = P == 1 && a->f_gp == nullptr && config(CFG_Q1_RULE_KERNEL) == nullptr;      // (launch2d)
+        Geom2D g = plan2d_env(m, P, allow_e4, chain_ok, cf_kernel);
         if (!chain_ok) g.W = 1;                          // (a "PLAN2D" override may ask for chained strips where they do not exist)
         pp.rows_per_strip = g.R;
         pp.nstrips = g.strips;
@@ -623,7 +632,8 @@ static long long launched_workgroups(const dn_mesh* m, const dn_poisson_args* a)
     auto sel = [&](int total) { return a->strip_select == 1 ? std::min(total, 2) : (a->strip_select == 2 ? std::max(total - 2, 0) : total); };
     if (m->nsd == 2) {
         const bool chain_ok = m->degree == 1 && a->f_gp == nullptr && config(CFG_Q1_RULE_KERNEL) == nullptr && a->strip_select == 0;
-        Geom2D g = plan2d_env(m, m->degree, e4, chain_ok);
+        const bool cf_kernel = m->degree == 1 && a->f_gp == nullptr && config(CFG_Q1_RULE_KERNEL) == nullptr;
+        Geom2D g = plan2d_env(m, m->degree, e4, chain_ok, cf_kernel);
         if (!chain_ok) g.W = 1;
         return (long long)g.chunks * ((sel(g.strips) + g.W - 1) / g.W) * m->batch;
     }

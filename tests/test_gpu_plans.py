@@ -164,3 +164,41 @@ def test_2d_chained_strips_equal_single_strips(sizes, ngp, B):
     finally:
         _lib.config_set("PLAN2D", "")
         ops._POISSON_WS_BYTES.clear()
+
+
+@pytest.mark.parametrize("sizes,B", [((321, 9), 3), ((513, 40), 2), ((385, 17), 1), ((1025, 5), 2), ((325, 33), 2)])
+def test_2d_rows_of_4k_plus_1_nodes_on_the_vector_kernel(sizes, B):
+    """Rows of 4 k + 1 nodes (>= 321): the closed-form kernel runs them four elements per thread with 16-byte accesses on 4-byte aligned rows, and the
+    mesh's last node column is finished by the last full thread column (CF_UA).  Against the per-point marching kernels
+    (dn_config_set("Q1_RULE_KERNEL"), two elements per thread, scalar accesses): energy, gradient, residual and its sum of squares, every mask format,
+    one and two conditions, value fields, launch-plan overrides (several chunks per row, strips of 1 .. 32 rows)."""
+    from diffnet_amd import BoxFaces, PackedMask, _lib
+    m = module(dict(nsd=2, domain_sizes=sizes, domain_lengths=(1.0, 0.6), domain_size=sizes[0], ngp_1d=3))
+    shape = (B, 1, sizes[1], sizes[0])
+    u, nu, f = cu(seeded(shape, 21)), cu(seeded(shape, 22) + 0.5), cu(seeded(shape, 23))
+    bc = boundary_mask(shape).to(torch.uint8).to(dev())
+    bc[:, 0, sizes[1] // 2, -7:] = 1                      # (Dirichlet nodes in the last columns, the last one included)
+    src = (seeded(shape, 24) < 0.1).to(torch.uint8).to(dev())
+    src[..., -1] = (seeded(shape[:-1], 25) < 0.5).to(torch.uint8).to(dev())
+    field = cu(seeded(shape, 26))
+    conds = {"none": [], "bits": [(PackedMask.pack(bc), 0.25)], "u8 x2": [(src, 1.0), (bc, 0.0)], "f32": [(bc.float(), -0.5)], "box": [(BoxFaces("all"), 0.0)],
+             "value field": [(bc, field)], "bits x2": [(PackedMask.pack(src), 1.0), (PackedMask.pack(bc), 0.0)]}
+    try:
+        for name, d in conds.items():
+            _lib.config_set("Q1_RULE_KERNEL", "1")
+            l0, g0 = m.energy_loss_and_grad(u, nu, f, dirichlet=d, c=0.7)
+            R0 = m.residual(u, nu, f, dirichlet=d)
+            r0 = m.residual_loss(u, nu, f, dirichlet=d)
+            _lib.config_set("Q1_RULE_KERNEL", "")
+            for plan in ("", "64,4,1", "128,4,3", "256,4,32", "192,4,5"):
+                _lib.config_set("PLAN2D", plan)
+                l1, g1 = m.energy_loss_and_grad(u, nu, f, dirichlet=d, c=0.7)
+                R1 = m.residual(u, nu, f, dirichlet=d)
+                r1 = m.residual_loss(u, nu, f, dirichlet=d)
+                assert float((g1 - g0).abs().max()) <= 3e-6 * float(g0.abs().max()), f"{name} plan {plan!r}"
+                assert float((R1 - R0).abs().max()) <= 3e-6 * float(R0.abs().max()), f"{name} plan {plan!r}"
+                np.testing.assert_allclose(float(l1), float(l0), rtol=3e-6, err_msg=f"{name} plan {plan!r}")
+                np.testing.assert_allclose(float(r1), float(r0), rtol=3e-6, err_msg=f"{name} plan {plan!r} residual loss")
+    finally:
+        _lib.config_set("PLAN2D", "")
+        _lib.config_set("Q1_RULE_KERNEL", "")

@@ -24,7 +24,7 @@ def _one(case, rng, dev, failures, verbose):
         deg = rng.choice([1, 1, 1, 2, 3])
         ngp = rng.choice([2, 3, 4]) if deg == 1 else rng.choice([3, 4])
         if nsd == 2:
-            nel = [rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 63, 64, 127, 128, 130, 255]) for _ in range(2)]
+            nel = [rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 63, 64, 127, 128, 130, 255, 320, 384, 512]), rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 63, 64, 127, 128, 130, 255])]
         else:
             nel = [rng.choice([1, 2, 3, 5, 14, 15, 16, 17, 29, 30, 31, 33, 47]) for _ in range(3)]
             if deg > 1:
