@@ -9,9 +9,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DN_LIB_PATH") or os.path.join(HERE, "libdiffnet_hip.so")     # DN_LIB_PATH: a variant build (tools/variant_build.sh)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
-DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE"}
+DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE", -4: "DN_E_HANDOVER"}
 
 
 class DnMesh(C.Structure):
@@ -66,6 +66,7 @@ SYMBOLS = {
     "dn_poisson_workspace_bytes": (C.c_int64, [C.POINTER(DnMesh)]),
     "dn_poisson_apply": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnPoissonArgs), C.c_void_p]),
     "dn_poisson_finish_sums": (C.c_int, [C.POINTER(DnMesh), C.POINTER(DnPoissonArgs), C.c_void_p]),
+    "dn_workspace_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dn_gauss_pt_eval_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_void_p]),
     "dn_gauss_pt_eval_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, I32x3, C.c_int32,
@@ -185,6 +186,8 @@ def check(rc, what):
     if rc == 0:
         return
     if rc < 0:
+        if rc == -4:
+            raise DiffNetHipError(f"{what}: DN_E_HANDOVER (a chained-strip launch ran a bounded LDS hand-over poll to its limit: its results are NaN)")
         raise DiffNetHipError(f"{what}: {DN_E.get(rc, rc)} (argument not supported by the HIP kernels)")
     raise DiffNetHipError(f"{what}: hipError_t {rc}")
 

@@ -16,7 +16,7 @@ extern "C" const char* dn_build_info(void) {
 
 // ---- tuning switches: one table, filled from DN_<KEY> when the library is loaded, changed only through dn_config_set ----
 namespace {
-const char* const kKeys[dn::CFG_COUNT] = {"PLAN2D", "PLAN3D", "PLAN_FSDT", "Q1_RULE_KERNEL", "GPE_GATHER", "GPE_TILED", "Q1_3D_T16", "Q1_3D_E1SUM", "FSDT_GENERIC", "Q1_3D_E1"};
+const char* const kKeys[dn::CFG_COUNT] = {"PLAN2D", "PLAN3D", "PLAN_FSDT", "Q1_RULE_KERNEL", "GPE_GATHER", "GPE_TILED", "Q1_3D_T16", "Q1_3D_E1SUM", "FSDT_GENERIC", "Q1_3D_E1", "HANDOVER_SPIN_LIMIT"};
 char g_cfg[dn::CFG_COUNT][64];
 
 int key_index(const char* key) {
@@ -55,6 +55,22 @@ extern "C" int dn_config_set(const char* key, const char* value) {
 extern "C" const char* dn_config_get(const char* key) {
     const int k = key_index(key);
     return k < 0 ? nullptr : g_cfg[k];
+}
+
+// ---- sticky error word of a launch workspace (poisson_common.h: DN_WS_ERRWORD) ------------------------------------------------
+extern "C" int dn_workspace_status(void* workspace, void* stream) {
+    if (!workspace) return DN_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned* word = reinterpret_cast<unsigned*>(workspace) + 8;          // DN_WS_ERRWORD
+    unsigned v = 0u;
+    hipError_t e = hipMemcpyAsync(&v, word, sizeof(v), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return (int)e;
+    if (v == 0u) return 0;
+    e = hipMemsetAsync(word, 0, sizeof(v), s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return (int)e;
+    return DN_E_HANDOVER;
 }
 
 // ---- Dirichlet mask images <-> DN_MASK_BITS (include/diffnet_hip.h) ----------------------------------------------------------

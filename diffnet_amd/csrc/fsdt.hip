@@ -40,7 +40,8 @@ __device__ __forceinline__ unsigned fs_lds_ld_u(unsigned a) {
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(a) : "memory");
     return d;
 }
-constexpr unsigned FS_SPIN_MAX = 1u << 20;     // bound of every LDS flag poll: a protocol error must end in wrong numbers, not in a hung GPU
+constexpr unsigned FS_SPIN_MAX = 1u << 20;     // bound of every LDS flag poll: a producer that never arrives must not hang the GPU; reaching it poisons the wave's
+                                               // outputs and sums with NaN and sets the workspace's sticky error word (dn_workspace_status) -- see poisson2d_q1_cf.hip
 constexpr int FS_CH_MAXW = 12;                 // sub-strips (waves) per chained workgroup: 12 waves = 3 per SIMD at <= 168 VGPRs
 
 struct FsdtParams {
@@ -61,7 +62,7 @@ struct FsdtParams {
     double* part;                          // [3][nblocks] partial sums of squares
     unsigned* counter;
     double* sumsq;                         // 3 doubles
-    int nx, ny, nelx, nely, rows_per_strip, want_sums;
+    int nx, ny, nelx, nely, rows_per_strip, want_sums, spin_limit;
 };
 
 // Deterministic in-kernel final reduction of three scalars (same protocol as finish_sums in poisson_common.h).
@@ -307,12 +308,16 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
         if ((int)threadIdx.x < 2 * (nsub - 1)) flag_base[threadIdx.x] = 0u;
         __syncthreads();
     }
+    float spin_poison = 0.f;          // NaN once a poll has run into its bound: everything the wave writes afterwards, its sums included, is NaN
     auto spin_until = [&](const unsigned* flag) {
         const unsigned fa = fs_lds_addr(flag);
-        for (unsigned n = 0; n < FS_SPIN_MAX; ++n) {
+        const unsigned lim = p.spin_limit > 0 ? (unsigned)p.spin_limit : FS_SPIN_MAX;
+        unsigned n = 0;
+        for (; n < lim; ++n) {
             if (__builtin_amdgcn_readfirstlane((int)fs_lds_ld_u(fa)) != 0) break;
             __builtin_amdgcn_s_sleep(1);
         }
+        if (n == lim) spin_poison = __builtin_nanf("");
     };
 
     float cu[3][NB][NW + 1], acc[3][NB][NW + 1];
@@ -414,6 +419,7 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
             for (int n = 0; n < NW; ++n) {
                 float v = acc[k][r][n] + (n == 0 ? left : 0.f);
                 v = (fixed[r] & (1u << n)) ? cu[k][r][n] : v;
+                if constexpr (CH) v += spin_poison;
                 sq[k] = (st && x0 + n < p.nx) ? fmaf(v, v, sq[k]) : sq[k];
                 pend[slot][k][n] = v;
             }
@@ -559,6 +565,11 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
     }
     }                                 // active
 
+    if constexpr (CH) {               // a hand-over poll ran into its bound: NaN sums + the sticky error word of the workspace (never silent)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sq[k] += spin_poison;
+        if (spin_poison != spin_poison && p.counter != nullptr && (threadIdx.x & 63u) == 0u) atomicOr(p.counter + 8, 1u);      // DN_WS_ERRWORD
+    }
     if (p.want_sums) finish_sums3(p, sq, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
 }
 
@@ -718,6 +729,7 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     pp.nelx = (m->nx - 1) / m->degree; pp.nely = (m->ny - 1) / m->degree;
     pp.rows_per_strip = g.R;
     pp.want_sums = want_red ? 1 : 0;
+    pp.spin_limit = config(CFG_HANDOVER_SPIN_LIMIT) ? std::atoi(config(CFG_HANDOVER_SPIN_LIMIT)) : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (m->degree) {
         case 1: rc = fsdt_launch<1>(pp, g, m->ngp, m->batch, false, s); break;

@@ -86,7 +86,9 @@ struct CfRow {
                                   // W R + 2 rows instead of W (R + 2)
 constexpr int CF_TS = 128;        // threads per chained sub-strip (two waves: 128 x 4 elements = one 512-node row segment)
 constexpr int CF_NSLOT = 64;      // hand-over slots between the two waves of a sub-strip: one per emitted row, never reused (R + 3 <= 64)
-constexpr unsigned CF_SPIN_MAX = 1u << 20;   // bound of every LDS flag poll (a protocol error ends in wrong numbers, which the parity tests catch, not in a hung GPU)
+constexpr unsigned CF_SPIN_MAX = 1u << 20;   // bound of every LDS flag poll: a producer wave that never arrives must not hang the GPU.  Reaching the bound is NOT
+                                             // silent: the wave poisons everything it writes afterwards with NaN (output rows, its partial sums -> the
+                                             // launch's energy / sumsq are NaN) and sets the sticky error word of the workspace header (dn_workspace_status)
 
 // LDS hand-overs of the chained strips are spelled as inline asm: a `volatile` LDS access makes the compiler wait for EVERY outstanding
 // memory operation around it (s_waitcnt vmcnt(0) lgkmcnt(0): 237 of them in the first build of the chained kernel, i.e. the row loads
@@ -198,12 +200,16 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
         if (threadIdx.x < 4u * (W - 1)) (&cf_sflag[0][0][0])[threadIdx.x] = 0u;
         __syncthreads();
     }
+    float spin_poison = 0.f;                                              // NaN once a poll has run into its bound (wave-uniform)
     auto spin_until = [&](const unsigned* flag, unsigned want) {          // wave-uniform poll of an LDS word
         const unsigned fa = lds_addr(flag);
-        for (unsigned n = 0; n < CF_SPIN_MAX; ++n) {
+        const unsigned lim = p.spin_limit > 0 ? (unsigned)p.spin_limit : CF_SPIN_MAX;
+        unsigned n = 0;
+        for (; n < lim; ++n) {
             if ((unsigned)__builtin_amdgcn_readfirstlane((int)lds_ld_u(fa)) >= want) break;
             __builtin_amdgcn_s_sleep(1);
         }
+        if (n == lim) spin_poison = __builtin_nanf("");
     };
 
     const bool has_mask[2] = {sb.mask[0] != nullptr, sb.mask[1] != nullptr};
@@ -393,6 +399,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
             const float t = (o[n] + (n == 0 ? left : 0.f)) * keep[n];
             sq_acc = st ? fmaf(t, t, sq_acc) : sq_acc;       // nodes beyond the domain receive no contribution: t == 0
             pend_v[n] = t * p.out_scale;
+            if constexpr (W > 1) pend_v[n] += spin_poison;
         }
         if constexpr (UA) {               // the mesh's last node column: finished by the thread column left of it (no thread to hand it to)
             const float t = o[NW] * keepx;
@@ -745,6 +752,11 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
         }
     }
 #endif
+    if constexpr (W > 1) {            // a hand-over poll that ran into its bound: NaN sums + the sticky error word (never silent)
+        e1_acc += spin_poison;
+        sq_acc += spin_poison;
+        if (spin_poison != spin_poison && p.counter != nullptr && (threadIdx.x & 63u) == 0u) atomicOr(p.counter + DN_WS_ERRWORD, 1u);
+    }
     if (p.want_sums) finish_sums(p, e1_acc, e2_acc, sq_acc, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
 #ifdef DN_STAMP2D
     if (tid == 0) {

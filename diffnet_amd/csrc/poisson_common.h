@@ -41,6 +41,7 @@ struct PoissonParams {
     int acc_sums;          // the final scalars are ADDED to what energy / sumsq hold (the second launch of a split evaluation)
     int defer_sums;        // the launch only writes its per-workgroup partial sums; dn_poisson_finish_sums adds them up (on any stream ordered after it)
     int want_sums;
+    int spin_limit;        // bound of the chained strips' LDS hand-over polls (0: the kernels' default; "HANDOVER_SPIN_LIMIT": test hook for the error path)
 };
 
 // strip index of the idx-th launched strip (split evaluations launch a subset of the strips: PoissonParams::strip_sel)
@@ -331,6 +332,9 @@ int launch_poisson3d_q1_g4(const PoissonParams& pp, const Geom3D& g, int batch, 
 
 // 3-D Q2 / Q3 (poisson3d_gen.hip): element vectors + fixed-order gather assembly; its workspace lies behind the common header
 static constexpr int64_t DN_WS_HEADER = 64 * (1 + 64);   // top counter + DN_NSHARD shard counters, one 64-B line each
+static constexpr int DN_WS_ERRWORD = 8;                    // word 8 of the top counter's line: sticky error bits of the launches that used this workspace
+                                                          // (bit 0: a bounded LDS hand-over poll of a chained-strip kernel ran out -- its results are NaN); read and
+                                                          // cleared by dn_workspace_status
 void gen3d_layout(const dn_mesh* m, long long& n1, long long& n2, long long& elem_floats);
 int launch_poisson3d_gen(const PoissonParams& pp, const dn_mesh* m, void* workspace, int64_t workspace_bytes, hipStream_t s);
 

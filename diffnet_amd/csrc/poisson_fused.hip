@@ -464,6 +464,19 @@ extern "C" int64_t dn_poisson_workspace_bytes(const dn_mesh* mesh) {
     return DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * n;
 }
 
+// Vector loads / stores of NW nodes are legal when every row segment of every array of the call starts NW-element aligned.  ONE definition:
+// dn_poisson_apply picks the launch geometry with it, dn_poisson_finish_sums / launched_workgroups must arrive at the same geometry (the
+// stride between the two partial-sum arrays is the launch's workgroup count).
+static bool poisson_vec_ok(const dn_mesh* m, const dn_poisson_args* a, int NW) {
+    auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
+    bool ok = (NW == 2 || NW == 4) && (m->nx % NW == 0) && aligned(a->u, 4 * NW) && aligned(a->nu, 4 * NW) && aligned(a->f, 4 * NW) &&
+              aligned(a->out, 4 * NW);
+    for (int k = 0; k < 2; ++k)
+        if (a->bc[k].mask_kind == DN_MASK_F32 || a->bc[k].mask_kind == DN_MASK_U8)
+            ok = ok && aligned(a->bc[k].mask, a->bc[k].mask_kind == DN_MASK_U8 ? NW : 4 * NW) && aligned(a->bc[k].field, 4 * NW);
+    return ok;
+}
+
 extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void* stream) {
     int rc = validate_mesh(m);
     if (rc) return rc;
@@ -492,16 +505,7 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
         }
     }
     const bool want_red = a->energy || a->sumsq || a->energy_f32;
-    auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
-    // vector loads/stores of NW nodes are legal when every row segment start is NW-element aligned
-    auto vec_ok = [&](int NW) {
-        bool ok = (NW == 2 || NW == 4) && (m->nx % NW == 0) && aligned(a->u, 4 * NW) && aligned(a->nu, 4 * NW) &&
-                  aligned(a->f, 4 * NW) && aligned(a->out, 4 * NW);
-        for (int k = 0; k < 2; ++k)
-            if (a->bc[k].mask_kind == DN_MASK_F32 || a->bc[k].mask_kind == DN_MASK_U8)
-                ok = ok && aligned(a->bc[k].mask, a->bc[k].mask_kind == DN_MASK_U8 ? NW : 4 * NW) && aligned(a->bc[k].field, 4 * NW);
-        return ok;
-    };
+    auto vec_ok = [&](int NW) { return poisson_vec_ok(m, a, NW); };
     const bool allow_e4 = vec_ok(4);
     const long long nwg = gen3d ? 1 : num_workgroups(m, allow_e4);
     if (nwg >= (1ll << 31)) return DN_E_UNSUPPORTED;                  // the 3-D launch is a 1-D grid
@@ -570,6 +574,7 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.nx = m->nx; pp.ny = m->ny; pp.nz = m->nsd == 3 ? m->nz : 1;
     pp.nelx = (m->nx - 1) / P; pp.nely = (m->ny - 1) / P; pp.nelz = m->nsd == 3 ? (m->nz - 1) / P : 1;
     pp.want_sums = want_red ? 1 : 0;
+    pp.spin_limit = config(CFG_HANDOVER_SPIN_LIMIT) ? std::atoi(config(CFG_HANDOVER_SPIN_LIMIT)) : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
     // split evaluation (dn_poisson_args.strip_select): a launch over the first and the last strip of the marched axis, or over the rest
@@ -624,11 +629,7 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
 
 // Workgroups the launch of (mesh, args) consists of = number of per-workgroup partial sums it leaves in the workspace.
 static long long launched_workgroups(const dn_mesh* m, const dn_poisson_args* a) {
-    auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
-    bool e4 = (m->nx % 4 == 0) && aligned(a->u, 16) && aligned(a->nu, 16) && aligned(a->f, 16) && aligned(a->out, 16);
-    for (int k = 0; k < 2; ++k)
-        if (a->bc[k].mask_kind == DN_MASK_F32 || a->bc[k].mask_kind == DN_MASK_U8)
-            e4 = e4 && aligned(a->bc[k].mask, a->bc[k].mask_kind == DN_MASK_U8 ? 4 : 16) && aligned(a->bc[k].field, 16);
+    const bool e4 = poisson_vec_ok(m, a, 4);
     auto sel = [&](int total) { return a->strip_select == 1 ? std::min(total, 2) : (a->strip_select == 2 ? std::max(total - 2, 0) : total); };
     if (m->nsd == 2) {
         const bool chain_ok = m->degree == 1 && a->f_gp == nullptr && config(CFG_Q1_RULE_KERNEL) == nullptr && a->strip_select == 0;
@@ -645,6 +646,8 @@ extern "C" int dn_poisson_finish_sums(const dn_mesh* m, const dn_poisson_args* a
     int rc = validate_mesh(m);
     if (rc) return rc;
     if (!a || !a->workspace || !(a->energy || a->sumsq || a->energy_f32)) return DN_E_BADARG;
+    if (!a->defer_sums) return DN_E_BADARG;                               // only a launch with defer_sums leaves partials behind the header
+    if (m->nsd == 3 && m->degree > 1) return DN_E_UNSUPPORTED;            // poisson3d_gen.hip: own workspace layout, no deferred sums
     if (a->accumulate_sums && !(a->energy && a->sumsq)) return DN_E_BADARG;
     const long long n = launched_workgroups(m, a);
     if (n <= 0) return 0;
@@ -652,12 +655,7 @@ extern "C" int dn_poisson_finish_sums(const dn_mesh* m, const dn_poisson_args* a
     if (a->workspace_bytes < DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * nall) return DN_E_WORKSPACE;
     const double* pe = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a->workspace) + DN_WS_HEADER);
     // the partial arrays are laid out for the launch's own workgroup count (dn_poisson_apply: part_sumsq = part_energy + nwg)
-    auto aligned = [](const void* p, int bytes) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % bytes) == 0; };
-    bool e4 = (m->nx % 4 == 0) && aligned(a->u, 16) && aligned(a->nu, 16) && aligned(a->f, 16) && aligned(a->out, 16);
-    for (int k = 0; k < 2; ++k)
-        if (a->bc[k].mask_kind == DN_MASK_F32 || a->bc[k].mask_kind == DN_MASK_U8)
-            e4 = e4 && aligned(a->bc[k].mask, a->bc[k].mask_kind == DN_MASK_U8 ? 4 : 16) && aligned(a->bc[k].field, 16);
-    const long long stride = num_workgroups(m, e4);
+    const long long stride = num_workgroups(m, poisson_vec_ok(m, a, 4));
     hipLaunchKernelGGL(poisson_finish_sums_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pe, pe + stride, (int)n, a->energy,
                        a->sumsq, a->energy_f32, a->energy_scale, (int)(a->accumulate_sums != 0));
     DN_LAUNCH_CHECK();

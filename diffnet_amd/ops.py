@@ -259,8 +259,10 @@ def _norm_dirichlet(dirichlet):
     return out
 
 
+_threading = __import__("threading")
 _WS = {}
-_WS_LOCK = __import__("threading").Lock()
+_WS_LOCK = _threading.Lock()
+_FSDT_LAUNCH_LOCK = _threading.Lock()
 _POISSON_WS_BYTES = {}
 
 
@@ -286,6 +288,17 @@ def _workspace(dev, nbytes):
             ws = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)   # ABI: zero-filled once
             _WS[key] = ws
     return ws
+
+
+def workspace_status(device=None):
+    """Health check of the shared launch workspaces of `device` (every stream that has used one): synchronises those streams and raises
+    DiffNetHipError if a launch ran a bounded LDS hand-over poll to its limit (chained-strip plans; such a launch's outputs and sums are
+    NaN -- never silently wrong).  Cheap enough for once per epoch; not for the launch path."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with _WS_LOCK:
+        items = [(k, w) for k, w in _WS.items() if k[0] == dev.index]
+    for (_, stream), ws in items:
+        _lib.check(_lib.lib().dn_workspace_status(C.c_void_p(ws.data_ptr()), C.c_void_p(stream)), "dn_workspace_status")
 
 
 # ---- one-shot calls: prepared launches cached behind the public API ------------------------------------------------------------
@@ -358,7 +371,9 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
         plan = PoissonPlan(geom, u, nu, f, f_gp, dl, alpha, beta, c, wscale, out_scale, want_out, want_sums, loss_scale, out, strict=True)
         res = plan.launch()
         # keep the structs, the workspace and the condition objects' own cached images; drop the caller's tensors and this call's outputs
-        plan.keep = [t for t in plan.keep if any(t is w for w in _WS.values())] + [d.mask for d in dl if not isinstance(d.mask, torch.Tensor)]
+        with _WS_LOCK:
+            live_ws = list(_WS.values())
+        plan.keep = [t for t in plan.keep if any(t is w for w in live_ws)] + [d.mask for d in dl if not isinstance(d.mask, torch.Tensor)]
         plan.result = None
         plan.fresh = (want_out and out is None, want_sums, loss_scale is not None)
         with _WS_LOCK:
@@ -370,18 +385,24 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
     a = ent.args
     new_out, has_sums, has_loss = ent.fresh
     o = out
+    sums = loss32 = None
     if new_out:
         o = torch.empty_like(u)
-        a.out = o.data_ptr()
-    sums = loss32 = None
     if has_sums:
         sums = torch.empty(2, dtype=torch.float64, device=u.device)
-        a.energy = sums.data_ptr()
-        a.sumsq = a.energy + 8
     if has_loss:
         loss32 = torch.empty((), dtype=torch.float32, device=u.device)
-        a.energy_f32 = loss32.data_ptr()
-    rc = ent._fn(ent._mesh_ref, ent._args_ref, C.c_void_p(key[2]))
+    # the entry's argument struct is shared by every caller that hits this key: the output pointers are patched and the launch is issued
+    # under the entry's lock, so two Python threads on the same (stream, buffers) cannot interleave them
+    with ent.lock:
+        if new_out:
+            a.out = o.data_ptr()
+        if has_sums:
+            a.energy = sums.data_ptr()
+            a.sumsq = a.energy + 8
+        if has_loss:
+            a.energy_f32 = loss32.data_ptr()
+        rc = ent._fn(ent._mesh_ref, ent._args_ref, C.c_void_p(key[2]))
     if rc:
         _lib.check(rc, "dn_poisson_apply")
     return (o, sums, loss32) if has_loss else (o, sums)
@@ -437,6 +458,7 @@ class PoissonPlan:
             self.args.defer_sums = 1
             ws = torch.zeros(int(self.args.workspace_bytes), dtype=torch.uint8, device=u.device)      # its own: the partials wait for the side stream
             self.keep.append(ws)
+            self._own_ws = ws
             self.args.workspace = ws.data_ptr()
             self.sums_stream = _side_stream(u.device)
             self._side = self.sums_stream.cuda_stream
@@ -448,6 +470,29 @@ class PoissonPlan:
         self.stream = _raw_stream(u.device)      # the reduction workspace belongs to this stream
         self._fn = _lib.lib().dn_poisson_apply
         self._mesh_ref, self._args_ref = C.byref(self.mesh), C.byref(self.args)
+        self.lock = _threading.Lock()            # guards the shared argument struct of a cached call (ops.poisson_apply)
+        if self.async_sums:
+            # the partials, the sums and the loss are allocated on the launch stream but read / written by the finish kernel on the side
+            # stream: tell the caching allocator, or a dropped plan's blocks could be handed to launch-stream work while that kernel is pending
+            for t in [self._own_ws] + [r for r in self.result[1:] if isinstance(r, torch.Tensor)]:
+                t.record_stream(self.sums_stream)
+
+    def __del__(self):
+        if getattr(self, "async_sums", False):
+            try:
+                hip = self._hip
+                if getattr(self, "_launched", False):
+                    hip.hipEventSynchronize(self._ev_done)       # the finish kernel still reads the plan's workspace
+                hip.hipEventDestroy(self._ev_main)
+                hip.hipEventDestroy(self._ev_done)
+            except Exception:                                     # interpreter shutdown: the runtime may already be gone
+                pass
+
+    def check(self):
+        """Health check of the plan's workspace (synchronises the stream): raises if a launch that used it ran a bounded hand-over poll
+        to its limit (its results are NaN then; include/diffnet_hip.h: dn_workspace_status)."""
+        if self.args.workspace:
+            _lib.check(_lib.lib().dn_workspace_status(C.c_void_p(self.args.workspace), C.c_void_p(_raw_stream(self.device))), "dn_workspace_status")
 
     def launch(self):
         cur = _raw_stream(self.device)
@@ -838,7 +883,9 @@ def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.
     if ent is None:
         _CALL_STATS["miss" if key is not None else "uncached"] += 1
         mesh, args, keep, shape = _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num, in_den, want_sums or want_norms)
-        ent = (mesh, args, C.byref(mesh), C.byref(args), shape, [t for t in keep if any(t is x for x in _WS.values())])
+        with _WS_LOCK:
+            live_ws = list(_WS.values())
+        ent = (mesh, args, C.byref(mesh), C.byref(args), shape, [t for t in keep if any(t is x for x in live_ws)])
         if key is not None:
             with _WS_LOCK:
                 _FSDT_CACHE[key] = ent
@@ -852,15 +899,19 @@ def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.
     if want_out:
         o3 = torch.empty((3, *shape), dtype=torch.float32, device=dev)      # one allocation, three views
         outs = list(o3.unbind(0))
-        p0, step = o3.data_ptr(), 4 * o3[0].numel()
-        args.out[0], args.out[1], args.out[2] = p0, p0 + step, p0 + 2 * step
     if want_sums:
         sums = torch.empty(3, dtype=torch.float64, device=dev)
-        args.sumsq = sums.data_ptr()
     if want_norms:
         norms = torch.empty(3, dtype=torch.float32, device=dev)
-        args.norms = norms.data_ptr()
-    rc = _lib.lib().dn_fsdt_apply(mref, aref, _stream(w))
+    with _FSDT_LAUNCH_LOCK:          # pointer patch + launch of the (possibly shared, cached) argument struct as one step
+        if want_out:
+            p0, step = o3.data_ptr(), 4 * o3[0].numel()
+            args.out[0], args.out[1], args.out[2] = p0, p0 + step, p0 + 2 * step
+        if want_sums:
+            args.sumsq = sums.data_ptr()
+        if want_norms:
+            args.norms = norms.data_ptr()
+        rc = _lib.lib().dn_fsdt_apply(mref, aref, _stream(w))
     if rc:
         _lib.check(rc, "dn_fsdt_apply")
     return (outs, sums, norms) if want_norms else (outs, sums)

