@@ -417,10 +417,13 @@ def main():
     ap.add_argument("--nsd", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config leg (\"configs\")")
-    ap.add_argument("--async-sums", action="store_true",
-                    help="form the loss on a side stream under the next step's launch (PoissonPlan(async_sums=True)) instead of inside the launch "
-                         "(default: its last workgroup adds up the per-workgroup partial sums, a ~3 us serial tail).  Measured SLOWER: the event "
-                         "record / wait between the launches costs more than the tail (60.5 against 56.0 us per step, profiles/r3_async_sums.txt)")
+    ap.add_argument("--sums", default="fold", choices=["fold", "kernel", "async"],
+                    help="where the loss of a step is formed from the launch's per-workgroup partial sums.  fold (default, round 4): by the first "
+                         "workgroup of the NEXT step's launch (dn_poisson_args.fold_prev; the last step of a timed region by one small kernel inside "
+                         "the region) -- the ~3 us serial tail at the end of every launch leaves the critical path, no event, no side stream: 56.3 -> "
+                         "53.7 us per step (profiles/r4_fold_sums.txt).  kernel: inside the launch (its last workgroup adds the partials up: rounds "
+                         "1-3).  async: one-workgroup kernel on a side stream under the next launch (measured slower: 60.5 us, profiles/r3_async_sums.txt)")
+    ap.add_argument("--async-sums", action="store_true", help="same as --sums async")
     ap.add_argument("--bc", default="auto", choices=["auto", "bits", "u8", "f32", "box"],
                     help="how the Dirichlet condition is held (auto: one bit per node for 2-D, uint8 image for 3-D: general mask arrays)")
     ap.add_argument("--slab", action="store_true",
@@ -432,7 +435,9 @@ def main():
     ap.add_argument("--slab-batch", type=int, default=1, help="samples of the slab leg's mesh (BASELINE configs[3] is parametric: the reference trains it with batch 8)")
     ap.add_argument("--slab-timeout", type=float, default=180.0, help="watchdog of the slab leg, seconds")
     args = ap.parse_args()
-    args.sync_sums = not args.async_sums
+    if args.async_sums:
+        args.sums = "async"
+    args.sync_sums = args.sums != "async"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                                      # does not return
@@ -484,15 +489,21 @@ def main():
     forms = {"u8": lambda bc: [(bc, 0.0)], "f32": lambda bc: [(bc.float(), 0.0)], "bits": lambda bc: [(PackedMask.pack(bc), 0.0)],
              "box": lambda bc: [(BoxFaces("all"), 0.0)]}
 
-    def make_plans(form, async_sums=None):
+    def make_plans(form, mode=None):
         # the prepared form of m.energy_loss_and_grad(u, nu, f, dirichlet, c) (diffnet_amd.ops.PoissonPlan: argument structs, outputs and
-        # workspace set up once, one ctypes call per launch).  async_sums (--async-sums, not the default: measured slower): the launch writes
-        # the gradient and its per-workgroup partial sums; the loss is formed from them by a one-workgroup kernel on a side stream, i.e.
-        # under the NEXT step's launch
-        return [_ops.PoissonPlan(m.geom, u, nu, f, None, forms[form](bc), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale0,
-                                 want_out=True, want_sums=True, loss_scale=scale0, async_sums=(not args.sync_sums) if async_sums is None else async_sums,
-                                 loss_out=loss_buf[k:k + 1] if (loss_buf is not None and form == bc_form and async_sums is None) else None)
-                for k, (u, nu, f, bc) in enumerate(sets)]
+        # workspace set up once, one ctypes call per launch).  mode (--sums): "fold" = every launch leaves its per-workgroup partial sums and
+        # forms the scalars of the launch BEFORE it in the rotation (its first workgroup, before its own march); "kernel" = in-kernel final
+        # reduction; "async" = one-workgroup kernel on a side stream
+        main = mode is None
+        mode = args.sums if mode is None else mode
+        pls = [_ops.PoissonPlan(m.geom, u, nu, f, None, forms[form](bc), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale0,
+                                want_out=True, want_sums=True, loss_scale=scale0, async_sums=mode == "async", pipelined_sums=mode == "fold",
+                                loss_out=loss_buf[k:k + 1] if (loss_buf is not None and form == bc_form and main) else None)
+               for k, (u, nu, f, bc) in enumerate(sets)]
+        if mode == "fold":
+            for k in range(len(pls)):
+                pls[k].fold(pls[k - 1])
+        return pls
 
     rot = make_plans(bc_form)
     turn = [0]

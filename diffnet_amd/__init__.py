@@ -7,5 +7,5 @@ __version__ = "0.1.0"
 
 from .base import PDE  # noqa: E402,F401
 from .fem import DiffNet2DFEM, DiffNet3DFEM, DiffNetFEM, FemGeometry, gauss_pt_eval  # noqa: E402,F401
-from .ops import Dirichlet, PackedMask, BoxFaces  # noqa: E402,F401
+from .ops import Dirichlet, PackedMask, BoxFaces, LoadVector  # noqa: E402,F401
 from . import torch_ops  # noqa: E402,F401  (registers the diffnet_mi:: operators with torch.library)

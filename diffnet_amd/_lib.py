@@ -39,7 +39,8 @@ class DnPoissonArgs(C.Structure):
                 ("out_scale", C.c_float),
                 ("out", C.c_void_p), ("energy", C.c_void_p), ("sumsq", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("energy_f32", C.c_void_p), ("energy_scale", C.c_double), ("strip_select", C.c_int32), ("accumulate_sums", C.c_int32), ("defer_sums", C.c_int32)]
+                ("energy_f32", C.c_void_p), ("energy_scale", C.c_double), ("strip_select", C.c_int32), ("accumulate_sums", C.c_int32), ("defer_sums", C.c_int32),
+                ("fold_prev", C.c_void_p), ("f_is_load", C.c_int32)]
 
 
 class DnFsdtArgs(C.Structure):

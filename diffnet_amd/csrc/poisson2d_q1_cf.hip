@@ -143,10 +143,24 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
     // Workgroup -> (chunk, strip, sample) so that NEIGHBOURING strips run on the same XCD (one L2) at the same time: the dispatcher
     // hands consecutive workgroups (x fastest, then y, z) to consecutive XCDs; XCD k takes the k-th contiguous range of strips.
     unsigned lid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#if defined(DN_CF_REV_PAIRS)          // (round 4 experiment) only the two strips of a PAIR share an XCD, dispatched 8 workgroups apart; consecutive pairs go round the
+    {                                 // XCDs in dispatch order as in the default launch (no contiguous range of samples per XCD)
+        const unsigned nwg = gridDim.x * gridDim.y * gridDim.z;
+        if ((nwg & 15u) == 0u) {
+            const unsigned xcd = lid & 7u, member = (lid >> 3) & 1u, q = lid >> 4;
+#if DN_CF_REV_PAIRS == 2              // pairs (2 k + 1, 2 k + 2): the strips that read their shared rows at their START (all workgroups start together: the second read
+            lid = (2u * (8u * q + xcd) + member + nwg - 1u) % nwg;     // meets the first in the L2; at the ends the two marches are microseconds apart)
+#else
+            lid = 2u * (8u * q + xcd) + member;
+#endif
+        }
+    }
+#elif !defined(DN_CF_REV_NOXCD)       // (round 4 experiment NOXCD: opposite marches in plain dispatch order -- the second read of a shared row then meets the first in the Infinity Cache, not in an L2)
     {
         const unsigned nwg = gridDim.x * gridDim.y * gridDim.z, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
         lid = xcd * base + min(xcd, rem) + idx;
     }
+#endif
     const int chunk = (int)(lid % gridDim.x), strip = (int)((lid / gridDim.x) % gridDim.y), b = (int)(lid / (gridDim.x * gridDim.y));
 #else
     const int chunk = blockIdx.x, strip = W > 1 ? (int)blockIdx.y * W + sub : selected_strip(p, (int)blockIdx.y), b = blockIdx.z;      // (chained launches cover every strip)
@@ -200,6 +214,8 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
         if (threadIdx.x < 4u * (W - 1)) (&cf_sflag[0][0][0])[threadIdx.x] = 0u;
         __syncthreads();
     }
+    // dn_poisson_args.fold_prev: the launch's first workgroup closes the evaluation before it (1-2 us once per launch, off every critical path)
+    if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0u) fold_prev_sums(p, (int)threadIdx.x, (int)blockDim.x, red);
     float spin_poison = 0.f;                                              // NaN once a poll has run into its bound (wave-uniform)
     auto spin_until = [&](const unsigned* flag, unsigned want) {          // wave-uniform poll of an LDS word
         const unsigned fa = lds_addr(flag);
@@ -768,7 +784,7 @@ __global__ void __launch_bounds__(W > 1 ? CF_TS * W : 256, W > 1 ? 4 : DN_Q1_2D_
 
 template <int E, bool VEC, int FL>
 static void cf_launch_one(const PoissonParams& pp, const Geom2D& g, int batch, hipStream_t s) {
-    if constexpr (E == 4 && VEC && DN_CF_W > 1 && (FL & CF_UA) == 0) {
+    if constexpr (E == 4 && VEC && DN_CF_W > 1 && (FL & CF_UA) == 0 && !DN_CF_REV && !DN_CF_PF) {
         if (g.W == DN_CF_W) {         // chained sub-strips (plan2d): W strips per workgroup
             hipLaunchKernelGGL((poisson2d_q1_cf_kernel<E, VEC, FL, DN_CF_W>), dim3(g.chunks, (g.strips + DN_CF_W - 1) / DN_CF_W, batch),
                                dim3(CF_TS * DN_CF_W), 0, s, pp);
@@ -810,8 +826,12 @@ int launch_poisson2d_q1_cf(const PoissonParams& pp, const Geom2D& g, int batch, 
     if (g.W > 1 && !(g.W == poisson2d_q1_cf_chain() && g.E == 4 && vec && g.T == CF_TS && g.R + 3 <= CF_NSLOT)) return DN_E_BADARG;
     if (g.ua) {                   // rows of 4 k + 1 nodes (plan2d): the vector kernel on 4-byte aligned rows, last node column in the last thread column
         if (g.E != 4 || g.W != 1 || (pp.nx & 3) != 1 || pp.nx < 9) return DN_E_BADARG;
+#if DN_CF_REV || DN_CF_PF || DN_CF_DPPX
+        return DN_E_UNSUPPORTED;  // (experiment builds: no 4 k + 1 form)
+#else
         cf_launch_flags<4, true, CF_UA>(pp, g, batch, s);
         return 0;
+#endif
     }
     if (g.E == 4 && vec) { cf_launch_flags<4, true>(pp, g, batch, s); return 0; }
     if (g.E == 2 && vec) { cf_launch_flags<2, true>(pp, g, batch, s); return 0; }

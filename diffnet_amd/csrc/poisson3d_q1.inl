@@ -13,7 +13,7 @@
 
 namespace dn {
 
-enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8, FL3_BC_U8C = 16, FL3_BC_ONE = 32, FL3_E1G = 64, FL3_BC_F32 = 128 };   // FL3_BC_F32 (node-owner form, with FL3_BC_U8C): the constant-value masks are fp32 images (> 0.5), the reference's format   // FL3_BC_U8C: uint8 masks with constant values only; FL3_BC_ONE (node-owner form): exactly one of them
+enum : int { FL3_NU = 1, FL3_F = 2, FL3_FGP = 4, FL3_BC = 8, FL3_BC_U8C = 16, FL3_BC_ONE = 32, FL3_E1G = 64, FL3_BC_F32 = 128, FL3_LOAD = 256, FL3_BOX = 512 };   // FL3_BOX (two-element node-owner form): at least one condition is given as faces of the domain box (DN_MASK_BOX): no array, no load   // FL3_LOAD (with FL3_F, two-element node-owner form): `f` holds the ASSEMBLED load vector b_a = sum_e sum_g W_g N_a f_g (dn_poisson_args.f_is_load) -- one FMA per node instead of the element's forcing arithmetic   // FL3_BC_F32 (node-owner form, with FL3_BC_U8C): the constant-value masks are fp32 images (> 0.5), the reference's format   // FL3_BC_U8C: uint8 masks with constant values only; FL3_BC_ONE (node-owner form): exactly one of them
 
 template <int NGP, int E>
 struct PlaneState3D {
@@ -908,11 +908,17 @@ __global__ void __launch_bounds__(256, NGP == 2 ? DN_Q1N_WAVES : (NGP == 3 ? 3 :
 #ifndef DN_Q1N2_WAVES
 #define DN_Q1N2_WAVES 3
 #endif
+#ifndef DN_Q1N2_LOAD_WAVES
+#define DN_Q1N2_LOAD_WAVES 3      // waves per SIMD asked of the load-vector instantiations (no staged forcing planes: 141-151 VGPRs with nu)
+#endif
 template <int FL>
-__global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
+__global__ void __launch_bounds__(256, (FL & FL3_LOAD) ? DN_Q1N2_LOAD_WAVES : DN_Q1N2_WAVES) poisson3d_q1n2_kernel(const PoissonParams p, const int chunks_x, const int tiles_y, const int strips_z) {
     constexpr int NGP = 2;
     constexpr bool UW = true;
-    constexpr bool HAS_NU = (FL & FL3_NU) != 0, HAS_F = (FL & FL3_F) != 0, BC_U8C = (FL & FL3_BC_U8C) != 0;
+    // LOADV: the forcing arrives as the assembled load vector (one value per node, used by the node's owner only: no staging, no element
+    // arithmetic); F_ARR: the third array is read at all (it travels in the records' .z either way); HAS_F: nodal forcing, staged per element
+    constexpr bool HAS_NU = (FL & FL3_NU) != 0, F_ARR = (FL & FL3_F) != 0, LOADV = F_ARR && (FL & FL3_LOAD) != 0, HAS_F = F_ARR && !LOADV;
+    constexpr bool BC_U8C = (FL & FL3_BC_U8C) != 0, BOX = (FL & FL3_BOX) != 0;
     constexpr int NMASK = !BC_U8C ? 0 : ((FL & FL3_BC_ONE) ? 1 : 2);
     constexpr bool MASK_F32 = (FL & FL3_BC_F32) != 0;
     constexpr bool E1G = (FL & FL3_E1G) != 0;
@@ -952,6 +958,7 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     __shared__ float2 xch[2][256];
     __shared__ double red[2 * (256 / 64)];
     __shared__ int last_flag;
+    if (blockIdx.x == 0u) fold_prev_sums(p, tid, 256, red);       // dn_poisson_args.fold_prev: close the evaluation before this one
 
     // own pair (clamped into the mesh: nx is even, so a pair is inside or outside as a whole) and the halo node this thread fetches
     const unsigned own_off = (unsigned)min(ey, p.ny - 1) * (unsigned)p.nx + (unsigned)min(x0, p.nx - 2);
@@ -963,7 +970,7 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     const int hidx = min(wave * 13 + hsub, 48);
     const int hrow = hidx < 33 ? 16 : hidx - 33, hcol = hidx < 33 ? hidx : 32;
     const unsigned halo_off = (unsigned)min(ny0 + hrow, p.ny - 1) * (unsigned)p.nx + (unsigned)min(nx0 + hcol, p.nx - 1);
-    const bool halo_lane = lane < 39 && wave * 13 + hsub < 49 && (hgrp == 0 || (hgrp == 1 ? HAS_NU : HAS_F));
+    const bool halo_lane = lane < 39 && wave * 13 + hsub < 49 && (hgrp == 0 || (hgrp == 1 ? HAS_NU : HAS_F));       // (the load vector is needed at owned nodes only: no halo)
     float* const halo_rec0 = reinterpret_cast<float*>((hcol & 1) ? &recO[0][hrow][hcol >> 1] : &recE[0][hrow][hcol >> 1]) + hgrp;      // component .x / .y / .z
     const unsigned halo_par_stride = 4u * ((hcol & 1) ? 17u * 16u : 17u * 17u);                                                        // floats
     const float* const halo_src = (hgrp == 1 && HAS_NU) ? sb.nu : ((hgrp == 2 && HAS_F) ? sb.f : sb.u);                               // per lane
@@ -973,7 +980,15 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
     mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);
     mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);
     const float* mask32[2] = {reinterpret_cast<const float*>(mask8[0]), reinterpret_cast<const float*>(mask8[1])};
-    const float bcval[2] = {NMASK == 1 ? (has_mask[0] ? p.bc[0].value : p.bc[1].value) : p.bc[0].value, p.bc[1].value};
+    // BOX: per condition the faces of the domain box it fixes (0: not a box condition).  In-plane part per node (this thread's pair, its halo
+    // node), constant over the march; the two faces across the marched axis per plane (wave-uniform)
+    const int bfaces[2] = {BOX && p.bc[0].kind == DN_MASK_BOX ? p.bc[0].box_faces : 0, BOX && p.bc[1].kind == DN_MASK_BOX ? p.bc[1].box_faces : 0};
+    auto box_xy = [&](int k, int x, int y) {
+        return ((bfaces[k] & DN_FACE_XLO) && x == 0) || ((bfaces[k] & DN_FACE_XHI) && x == p.nx - 1) || ((bfaces[k] & DN_FACE_YLO) && y == 0) ||
+               ((bfaces[k] & DN_FACE_YHI) && y == p.ny - 1);
+    };
+    const bool bxy0[2] = {box_xy(0, x0, ey), box_xy(1, x0, ey)}, bxy1[2] = {box_xy(0, x0 + 1, ey), box_xy(1, x0 + 1, ey)};
+    const bool bxyh[2] = {box_xy(0, nx0 + hcol, ny0 + hrow), box_xy(1, nx0 + hcol, ny0 + hrow)};
 
     struct RawNodes2 {
         float2 u, n, f;               // own pair
@@ -988,7 +1003,7 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         const unsigned oo = zoff + own_off, oh = zoff + halo_off;
         W.u = ld_at<float2>(sb.u, oo);
         if constexpr (HAS_NU) W.n = ld_at<float2>(sb.nu, oo);
-        if constexpr (HAS_F) W.f = ld_at<float2>(sb.f, oo);
+        if constexpr (F_ARR) W.f = ld_at<float2>(sb.f, oo);
         W.h = halo_src[oh];
         if constexpr (BC_U8C) {
 #pragma unroll
@@ -998,17 +1013,22 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
             }
         }
     };
-    auto record = [&](float uu, float nn, float ff, const bool (&set)[2]) {
+    // img[j]: the node is set in the j-th LOADED mask image (NMASK == 1: the one image is whichever condition has it); box[k]: by condition k's faces.
+    // The conditions are applied in their order (the reference's torch.where lines, e.g. IBN_3D.py:119-122)
+    auto record = [&](float uu, float nn, float ff, const bool (&img)[2], const bool (&box)[2]) {
         float keep = 1.f;
-        if constexpr (BC_U8C) {
+        if constexpr (BC_U8C || BOX) {
 #pragma unroll
-            for (int k = 0; k < NMASK; ++k) {
-                const bool s = (NMASK == 1 || has_mask[k]) && set[k];
-                uu = s ? bcval[k] : uu;
+            for (int k = 0; k < 2; ++k) {
+                bool s = false;
+                if constexpr (NMASK == 2) s = has_mask[k] && img[k];
+                if constexpr (NMASK == 1) s = has_mask[k] && img[0];
+                if constexpr (BOX) s = s || box[k];
+                uu = s ? p.bc[k].value : uu;
                 keep = s ? 0.f : keep;
             }
         }
-        return make_float4(uu, HAS_NU ? nn : 1.f, HAS_F ? ff : 0.f, keep);
+        return make_float4(uu, HAS_NU ? nn : 1.f, F_ARR ? ff : 0.f, keep);
     };
     auto plane_publish = [&](const RawNodes2& W, int zpl) {
         bool s0[2] = {false, false}, s1[2] = {false, false}, sh[2] = {false, false};
@@ -1020,15 +1040,21 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
             }
         }
         const int par = zpl & 1;
-        recE[par][ty][tx] = record(W.u.x, W.n.x, W.f.x, s0);
-        recO[par][ty][tx] = record(W.u.y, W.n.y, W.f.y, s1);
+        bool b0[2] = {false, false}, b1[2] = {false, false}, bh[2] = {false, false};
+        if constexpr (BOX) {
+            const int zc = min(zpl, p.nz - 1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bool zf = ((bfaces[k] & DN_FACE_ZLO) && zc == 0) || ((bfaces[k] & DN_FACE_ZHI) && zc == p.nz - 1);
+                b0[k] = bxy0[k] || zf; b1[k] = bxy1[k] || zf; bh[k] = bxyh[k] || zf;
+            }
+        }
+        recE[par][ty][tx] = record(W.u.x, W.n.x, W.f.x, s0, b0);
+        recO[par][ty][tx] = record(W.u.y, W.n.y, W.f.y, s1, b1);
         if (halo_lane) {
             float hv = W.h;
-            if constexpr (BC_U8C) {
-                if (hgrp == 0) {
-#pragma unroll
-                    for (int k = 0; k < NMASK; ++k) hv = ((NMASK == 1 || has_mask[k]) && sh[k]) ? bcval[k] : hv;
-                }
+            if constexpr (BC_U8C || BOX) {
+                if (hgrp == 0) hv = record(hv, 0.f, 0.f, sh, bh).x;
             }
             halo_rec0[par * halo_par_stride] = hv;       // (the .w of a halo record is never read; absent nu / f keep the 1 / 0 of the prologue)
         }
@@ -1103,6 +1129,7 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
         // records of the same parity (a wave's LDS accesses execute in order) and land under the barrier.
         const float4 own0 = recE[z & 1][ty][tx], own1 = recO[z & 1][ty][tx];
         const v2f keep = {own0.w, own1.w}, uown = {own0.x, own1.x};
+        const v2f bown = {own0.z, own1.z};            // LOADV: the load vector at the own node pair
         const float left0 = lane_from_left(o[0][1].y, from_left, nfirst);
         xch[par][tid] = make_float2(o[1][0].x + lane_from_left(o[1][1].y, from_left, nfirst), o[1][1].x + o[1][0].y);
         if (W != nullptr) plane_publish(*W, zpub);
@@ -1114,6 +1141,13 @@ __global__ void __launch_bounds__(256, DN_Q1N2_WAVES) poisson3d_q1n2_kernel(cons
             t += v2f{up.x, up.y};
         }
         const bool st = owned_plane && owner && noderow_ok;
+        if constexpr (LOADV) {
+            // out_a -= beta * wscale * b_a,  sum W f u = sum_a u_a b_a (u after the Dirichlet conditions): one FMA each per owned node.
+            // Threads beyond the mesh hold a clamped duplicate of a valid pair: excluded.
+            const bool inmesh = st && x0 < p.nx;
+            t = inmesh ? vfma(TV.nbw, bown, t) : t;
+            e2_acc2 = inmesh ? vfma(uown, bown, e2_acc2) : e2_acc2;
+        }
         if constexpr (E1G) ut_acc = st ? vfma(t, uown, ut_acc) : ut_acc;      // before the Dirichlet rows are zeroed
         t *= keep;
         sq_acc2 = st ? vfma(t, t, sq_acc2) : sq_acc2;
@@ -1336,6 +1370,12 @@ static void launch3_n2_bc(const PoissonParams& pp, const dim3& grid, const Geom3
         if (pp.bc[k].mask && !pp.bc[k].mask_is_u8) f32 = true;
     const dim3 block(16, 16);
 #define DN_N2(FLAGS) hipLaunchKernelGGL((poisson3d_q1n2_kernel<(FLAGS)>), grid, block, 0, s, pp, g.chunks, g.tiles, g.strips)
+    if (pp.bc[0].kind == DN_MASK_BOX || pp.bc[1].kind == DN_MASK_BOX) {       // box faces (no array), alone or beside ONE mask image
+        if (!any) DN_N2(FLB | FL3_BOX);
+        else if (!f32) DN_N2(FLB | FL3_BOX | FL3_BC_U8C | FL3_BC_ONE);
+        else DN_N2(FLB | FL3_BOX | FL3_BC_U8C | FL3_BC_F32 | FL3_BC_ONE);
+        return;
+    }
     if (!any) DN_N2(FLB);
     else if (!f32 && one) DN_N2(FLB | FL3_BC_U8C | FL3_BC_ONE);
     else if (!f32) DN_N2(FLB | FL3_BC_U8C);
@@ -1349,6 +1389,15 @@ static int launch3_n2(const PoissonParams& pp, const Geom3D& g, int batch, hipSt
     // energy from the nodal values (FL3_E1G) whenever the launch has a stiffness part and sums are wanted
     const bool e1g = pp.T.alpha != 0.f && pp.want_sums && config(CFG_Q1_3D_E1SUM) == nullptr;
     const int sel = (pp.nu ? 1 : 0) | (pp.f ? 2 : 0) | (e1g ? 4 : 0);
+    if (pp.f && pp.f_is_load) {                    // the forcing as the assembled load vector (dn_poisson_args.f_is_load)
+        switch (sel) {
+            case 2: launch3_n2_bc<FL3_F | FL3_LOAD>(pp, grid, g, s); break;
+            case 3: launch3_n2_bc<FL3_NU | FL3_F | FL3_LOAD>(pp, grid, g, s); break;
+            case 6: launch3_n2_bc<FL3_F | FL3_LOAD | FL3_E1G>(pp, grid, g, s); break;
+            default: launch3_n2_bc<FL3_NU | FL3_F | FL3_LOAD | FL3_E1G>(pp, grid, g, s); break;
+        }
+        return 0;
+    }
     switch (sel) {
         case 0: launch3_n2_bc<0>(pp, grid, g, s); break;
         case 1: launch3_n2_bc<FL3_NU>(pp, grid, g, s); break;
@@ -1366,6 +1415,7 @@ static int launch3_n2(const PoissonParams& pp, const Geom3D& g, int batch, hipSt
 #define DN_CAT2(a, b) a##b
 #define DN_CAT(a, b) DN_CAT2(a, b)
 int DN_CAT(launch_poisson3d_q1_g, DN_NGP)(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s) {
+    if (pp.f && pp.f_is_load && !(DN_NGP == 2 && g.E == 2 && g.TX == 16 && g.TY == 16)) return DN_E_UNSUPPORTED;      // load vectors: two-element node-owner form only
     if (g.E == 1) { launch3_flags<DN_NGP, 1, false>(pp, g, batch, s); return 0; }
 #if DN_NGP == 2
     if (g.E == 2 && g.TX == 16 && g.TY == 16) return launch3_n2(pp, g, batch, s);       // node-owner form, two elements per thread (dn_poisson_apply checked its preconditions)

@@ -23,6 +23,7 @@ struct PoissonParams {
     const float* f;
     const float* fgp;
     int nu_batched, f_batched;
+    int f_is_load;         // `f` is the assembled load vector (dn_poisson_args.f_is_load)
     DirichletDev bc[2];
     float out_scale;
     float* out;
@@ -41,6 +42,14 @@ struct PoissonParams {
     int acc_sums;          // the final scalars are ADDED to what energy / sumsq hold (the second launch of a split evaluation)
     int defer_sums;        // the launch only writes its per-workgroup partial sums; dn_poisson_finish_sums adds them up (on any stream ordered after it)
     int want_sums;
+    // dn_poisson_args.fold_prev: the partial sums an earlier launch left (defer_sums) are added up by this launch's first workgroup
+    const double* fold_pe;
+    const double* fold_ps;
+    double* fold_energy;
+    double* fold_sumsq;
+    float* fold_energy_f32;
+    double fold_scale;
+    int fold_n, fold_acc;
     int spin_limit;        // bound of the chained strips' LDS hand-over polls (0: the kernels' default; "HANDOVER_SPIN_LIMIT": test hook for the error path)
 };
 
@@ -204,6 +213,38 @@ __device__ __forceinline__ void finish_sums(const PoissonParams& p, float e1, fl
             if (p.energy_f32) *p.energy_f32 = (float)(e * p.energy_scale);
             __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+// dn_poisson_args.fold_prev: the final reduction of an EARLIER launch, done by the first workgroup of this one before its march (same
+// arithmetic as poisson_finish_sums_kernel: each thread adds its partials in index order, fixed-order block sum -> bitwise reproducible).
+// Sixteen partials of each sum are requested before the first addition (one memory round trip per 16).  `red`: >= 2 * waves doubles.
+__device__ __forceinline__ void fold_prev_sums(const PoissonParams& p, int tid, int nthreads, double* red) {
+    if (p.fold_n <= 0) return;                    // (wave-uniform)
+    double e = 0.0, s = 0.0;
+    constexpr int NB_ = 16;
+    for (int i0 = tid; i0 < p.fold_n; i0 += nthreads * NB_) {
+        double ve[NB_], vs[NB_];
+#pragma unroll
+        for (int k = 0; k < NB_; ++k) {
+            const int i = i0 + k * nthreads;
+            const int ic = i < p.fold_n ? i : 0;
+            ve[k] = p.fold_pe[ic];
+            vs[k] = p.fold_ps[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < NB_; ++k) {
+            const bool ok = i0 + k * nthreads < p.fold_n;
+            e += ok ? ve[k] : 0.0;
+            s += ok ? vs[k] : 0.0;
+        }
+    }
+    block_sum2(e, s, red, tid, nthreads);
+    if (tid == 0) {
+        if (p.fold_acc) { e += *p.fold_energy; s += *p.fold_sumsq; }
+        if (p.fold_energy) *p.fold_energy = e;
+        if (p.fold_sumsq) *p.fold_sumsq = s;
+        if (p.fold_energy_f32) *p.fold_energy_f32 = (float)(e * p.fold_scale);
     }
 }
 

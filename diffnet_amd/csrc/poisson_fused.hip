@@ -464,6 +464,8 @@ extern "C" int64_t dn_poisson_workspace_bytes(const dn_mesh* mesh) {
     return DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * n;
 }
 
+static long long launched_workgroups(const dn_mesh* m, const dn_poisson_args* a);
+
 // Vector loads / stores of NW nodes are legal when every row segment of every array of the call starts NW-element aligned.  ONE definition:
 // dn_poisson_apply picks the launch geometry with it, dn_poisson_finish_sums / launched_workgroups must arrive at the same geometry (the
 // stride between the two partial-sum arrays is the launch's workgroup count).
@@ -497,7 +499,12 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
             if (d.mask_kind == DN_MASK_BITS && d.row_words < (m->nx + 31) / 32) return DN_E_BADARG;
         }
     }
-    if (packed_bc) {
+    if (packed_bc && m->nsd == 3) {
+        // 3-D (round 4): box faces -- no bit arrays -- are taken by the two-element node-owner kernel, alone or beside mask images
+        for (int k = 0; k < 2; ++k)
+            if (a->bc[k].mask_kind == DN_MASK_BITS) return DN_E_UNSUPPORTED;
+        if (gen3d || !q1n2_ok(m, a)) return DN_E_UNSUPPORTED;
+    } else if (packed_bc) {
         if (m->nsd != 2 || P != 1 || a->f_gp || config(CFG_Q1_RULE_KERNEL) != nullptr) return DN_E_UNSUPPORTED;
         for (int k = 0; k < 2; ++k) {         // the compact form does not mix with per-node mask images
             const dn_dirichlet& d = a->bc[k];
@@ -556,6 +563,8 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.T.alpha = a->alpha; pp.T.beta = a->beta; pp.T.c = a->c;
     pp.u = a->u; pp.nu = a->nu; pp.f = a->f; pp.fgp = a->f_gp;
     pp.nu_batched = a->nu_batched; pp.f_batched = a->f_batched;
+    pp.f_is_load = (a->f_is_load && a->f) ? 1 : 0;
+    if (pp.f_is_load && !(m->nsd == 3 && !gen3d && q1n2_ok(m, a))) return DN_E_UNSUPPORTED;      // load vectors: the 3-D two-element kernel only (so far)
     for (int k = 0; k < 2; ++k) {
         const dn_dirichlet& d = a->bc[k];
         const bool present = d.mask_kind == DN_MASK_BOX ? d.box_faces != 0 : d.mask != nullptr;
@@ -576,6 +585,24 @@ extern "C" int dn_poisson_apply(const dn_mesh* m, const dn_poisson_args* a, void
     pp.want_sums = want_red ? 1 : 0;
     pp.spin_limit = config(CFG_HANDOVER_SPIN_LIMIT) ? std::atoi(config(CFG_HANDOVER_SPIN_LIMIT)) : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // fold_prev: this launch's first workgroup closes an earlier evaluation (its partial sums, left with defer_sums, lie in ITS workspace)
+    pp.fold_n = 0;
+    if (a->fold_prev) {
+        const dn_poisson_args* q = a->fold_prev;
+        if (gen3d || !q->defer_sums || !q->workspace || !(q->energy || q->sumsq || q->energy_f32)) return DN_E_BADARG;
+        if (q->accumulate_sums && !(q->energy && q->sumsq)) return DN_E_BADARG;
+        if (q->workspace == a->workspace && want_red) return DN_E_BADARG;        // this launch would overwrite the partials while they are read
+        const long long qn = launched_workgroups(m, q), qstride = num_workgroups(m, poisson_vec_ok(m, q, 4));
+        if (q->workspace_bytes < DN_WS_HEADER + (int64_t)(2 * sizeof(double)) * qstride || qn > qstride) return DN_E_WORKSPACE;
+        const bool cf2d = m->nsd == 2 && P == 1 && a->f_gp == nullptr && config(CFG_Q1_RULE_KERNEL) == nullptr;
+        if (!cf2d && !(m->nsd == 3 && q1n2_ok(m, a))) return DN_E_UNSUPPORTED;
+        pp.fold_pe = reinterpret_cast<const double*>(reinterpret_cast<const char*>(q->workspace) + DN_WS_HEADER);
+        pp.fold_ps = pp.fold_pe + qstride;
+        pp.fold_n = (int)qn;
+        pp.fold_energy = q->energy; pp.fold_sumsq = q->sumsq; pp.fold_energy_f32 = q->energy_f32;
+        pp.fold_scale = q->energy_scale;
+        pp.fold_acc = q->accumulate_sums ? 1 : 0;
+    }
 
     // split evaluation (dn_poisson_args.strip_select): a launch over the first and the last strip of the marched axis, or over the rest
     if (a->strip_select < 0 || a->strip_select > 2) return DN_E_BADARG;

@@ -206,6 +206,34 @@ class PackedMask:
         return self._u8
 
 
+class LoadVector:
+    """The forcing of a sample as its ASSEMBLED load vector b_a = sum_e sum_g w_g N_a(g) f_g instead of nodal values f (include/diffnet_hip.h:
+    dn_poisson_args.f_is_load).  The reference interpolates the nodal forcing to the Gauss points in every loss evaluation
+    (IBN/poisson-2d/parametric/IBN_2D.py:128-130); the forcing of a sample does not change between training steps, so -- like
+    `PackedMask.pack` for the Dirichlet masks -- it can be assembled ONCE when the dataset is placed on the device:
+    `LoadVector.assemble(geom, f)`.  Passed as the `f` argument of energy_loss / energy_loss_and_grad / residual* / PoissonPlan; the
+    kernel then spends one FMA per node on the forcing instead of the element arithmetic (3-D Q1 256^3: 114 -> 92 us).  Results equal
+    the nodal-forcing call to rounding.  Taken by the 3-D Q1 two-element kernel only (even nx, 2-point rule, constant-value uint8 /
+    float32 mask images); anything else raises DiffNetHipError (DN_E_UNSUPPORTED)."""
+
+    def __init__(self, tensor):
+        if not (isinstance(tensor, torch.Tensor) and tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous()):
+            raise DiffNetHipError("LoadVector needs a contiguous float32 CUDA tensor (B|1, 1, *N)")
+        self.tensor = tensor
+        self.shape = tensor.shape
+
+    @staticmethod
+    def assemble(geom, f):
+        """b = (rule weights, no Jacobian factor) mass-type assembly of the nodal forcing f (B|1, 1, *N): one launch of the fused operator
+        itself with u = 0 (out = -beta * b)."""
+        if not (isinstance(f, torch.Tensor) and f.is_cuda):
+            raise DiffNetHipError("LoadVector.assemble needs a CUDA tensor")
+        f = f.detach().to(torch.float32).contiguous()
+        zero = torch.zeros_like(f)
+        out, _ = poisson_apply(geom, zero, None, f, None, (), alpha=0.0, beta=-1.0, c=0.0, wscale=1.0, out_scale=1.0, want_out=True, want_sums=False)
+        return LoadVector(out)
+
+
 class BoxFaces:
     """Dirichlet condition on faces of the domain box, derived from the geometry (C ABI: DN_MASK_BOX): no mask array is read at
     all.  The reference builds these masks as images (`IBN/poisson-2d/parametric/IBN_2D.py:69-73`, `rectangles.py:16,232-233`).
@@ -323,7 +351,9 @@ def _tkey(t):
 
 
 def _call_key(geom, u, nu, f, f_gp, dl, scal, want_out, want_sums, out):
-    parts = [geom.key, u.device.index, _raw_stream(u.device), scal, want_out, want_sums]
+    parts = [geom.key, u.device.index, _raw_stream(u.device), scal, want_out, want_sums, isinstance(f, LoadVector)]
+    if isinstance(f, LoadVector):
+        f = f.tensor
     for t in (u, nu, f, f_gp, out):
         k = _tkey(t)
         if k is None or (k != 0 and k[1] != torch.float32):
@@ -425,8 +455,14 @@ class PoissonPlan:
 
     def __init__(self, geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, beta=1.0, c=1.0, wscale=1.0,
                  out_scale=1.0, want_out=True, want_sums=True, loss_scale=None, out=None, strict=True, strip_select=0, continues=None,
-                 async_sums=False, loss_out=None):
-        """async_sums: the launch leaves per-workgroup partial sums; the final scalars are formed by a one-workgroup kernel on a SIDE stream
+                 async_sums=False, loss_out=None, pipelined_sums=False):
+        """pipelined_sums (round 4): the launch leaves per-workgroup partial sums in a workspace of its own and does NOT form its scalars; the
+        NEXT launch in the loop does, at its start (`nxt.fold(this)`: dn_poisson_args.fold_prev -- the first workgroup of that launch adds the
+        partials up before its own march), and `finish_sums()` closes the last evaluation of a loop with the one-workgroup kernel.  The
+        final reduction (a ~3 us serial tail of a ~56 us launch: every workgroup has finished, the last arriver adds 2048 partials) leaves the
+        critical path without a side stream or an event; the price: the loss of step k is ready when launch k + 1 has run (a training loop
+        only logs it).  The gradient is final when its own launch ends, as always.
+        async_sums: the launch leaves per-workgroup partial sums; the final scalars are formed by a one-workgroup kernel on a SIDE stream
         (dn_poisson_finish_sums), i.e. under whatever the launch stream runs next -- the in-kernel final reduction is a ~3 us serial tail
         of every launch.  The gradient is ready in launch-stream order as always; the sums / the loss are ready on the side stream: call
         `wait_sums()` (makes the current stream wait for them) before consuming them there, or consume them under `sums_stream`.  Such a
@@ -454,6 +490,13 @@ class PoissonPlan:
         self.args.strip_select = int(strip_select)
         self.args.accumulate_sums = int(continues is not None)
         self.async_sums = bool(async_sums) and self.args.workspace is not None and self.args.workspace != 0
+        self.pipelined_sums = bool(pipelined_sums) and not self.async_sums and self.args.workspace is not None and self.args.workspace != 0
+        self._folds = None
+        if self.pipelined_sums:
+            self.args.defer_sums = 1
+            ws = torch.zeros(int(self.args.workspace_bytes), dtype=torch.uint8, device=u.device)      # its own: the partials wait for the next launch
+            self.keep.append(ws)
+            self.args.workspace = ws.data_ptr()
         if self.async_sums:
             self.args.defer_sums = 1
             ws = torch.zeros(int(self.args.workspace_bytes), dtype=torch.uint8, device=u.device)      # its own: the partials wait for the side stream
@@ -518,6 +561,29 @@ class PoissonPlan:
             _lib.check(rc, "dn_poisson_apply")
         return self.result
 
+    def fold(self, prev):
+        """This launch closes the evaluation of `prev` (a pipelined_sums plan on the same mesh whose launch precedes this one on the stream):
+        its first workgroup adds up prev's partial sums and writes prev's scalars.  fold(None) clears."""
+        if prev is None:
+            self.args.fold_prev = None
+            self._folds = None
+            return self
+        if not getattr(prev, "pipelined_sums", False):
+            raise DiffNetHipError("PoissonPlan.fold: the other plan must be prepared with pipelined_sums=True")
+        self._folds = prev                                    # keeps its argument struct and workspace alive
+        self.args.fold_prev = C.addressof(prev.args)
+        return self
+
+    def finish_sums(self):
+        """pipelined_sums: form this plan's scalars from the partial sums of its last launch now (one small kernel on the current stream)
+        -- for the last evaluation of a loop, which no further launch folds."""
+        if not self.pipelined_sums:
+            return self.result
+        rc = _lib.lib().dn_poisson_finish_sums(self._mesh_ref, self._args_ref, C.c_void_p(_raw_stream(self.device)))
+        if rc:
+            _lib.check(rc, "dn_poisson_finish_sums")
+        return self.result
+
     def wait_sums(self):
         """async_sums: make the current stream wait for the sums / the loss of the last launch (no-op otherwise)."""
         if self.async_sums and self._launched:
@@ -550,6 +616,9 @@ def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, ou
         args.nu, args.nu_batched = nu.data_ptr(), nb_
     if f is not None and f_gp is not None:
         raise ValueError("give either nodal f or f_gp, not both")
+    if isinstance(f, LoadVector):
+        args.f_is_load = 1
+        f = f.tensor
     if f is not None:
         f, fb = field(f, "f")
         if tuple(f.shape[1:]) != (1, *node_shape):
@@ -565,8 +634,25 @@ def _prepare_poisson(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, ou
     # condition of the call is one of them with a constant value; otherwise they are expanded to their (cached) uint8 images
     compact = (nsd == 2 and geom.deg == 1 and f_gp is None and len(dl) > 0 and _lib.lib().dn_config_get(b"Q1_RULE_KERNEL") in (None, b"") and
                all(isinstance(d.mask, (PackedMask, BoxFaces)) and not isinstance(d.value, torch.Tensor) for d in dl))
+    # 3-D (round 4): BoxFaces are taken as they are (no image, no load) by the two-element Q1 kernel -- exact 2-point rule, even nx, nodal /
+    # absent forcing, 8-byte aligned fields, constant values, at most one mask image beside them; anything else gets the expanded image
+    box3d = False
+    if nsd == 3 and geom.deg == 1 and f_gp is None and any(isinstance(d.mask, BoxFaces) for d in dl):
+        mesh0 = geom.mesh_struct(B)
+        imgs = [d.mask for d in dl if not isinstance(d.mask, BoxFaces)]
+        cfg = _lib.lib().dn_config_get
+        box3d = (mesh0.ngp == 2 and mesh0.nx % 2 == 0 and len(imgs) <= 1 and cfg(b"Q1_3D_T16") in (None, b"") and cfg(b"Q1_3D_E1") in (None, b"") and
+                 all(not isinstance(d.value, torch.Tensor) for d in dl) and
+                 all(isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.dtype in (torch.uint8, torch.float32) and
+                     t.data_ptr() % 8 == 0 for t in imgs) and
+                 all(t is None or t.data_ptr() % 8 == 0 for t in (u, nu, f, out)))
     for k, d in enumerate(dl):
         m = d.mask
+        if box3d and isinstance(m, BoxFaces):
+            bc = args.bc[k]
+            bc.value = float(d.value)
+            bc.mask_kind, bc.box_faces = _lib.MASK_BOX, m.bits
+            continue
         if compact:
             bc = args.bc[k]
             bc.value = float(d.value)
@@ -777,6 +863,8 @@ def _fused(geom, u, nu, f, f_gp, dirichlet, alpha, beta, c, wscale, out_scale, l
     plain autograd.Function, or directly when nothing requires a gradient."""
     if torch.compiler.is_compiling():
         from . import torch_ops
+        if isinstance(f, LoadVector):
+            raise DiffNetHipError("LoadVector forcing is an eager-mode argument (the registered operator takes tensors); pass nodal f under torch.compile")
         compact = (geom.nsd == 2 and geom.deg == 1 and f_gp is None and not _lib.CONFIG_MIRROR.get("Q1_RULE_KERNEL") and
                    all(not isinstance(d.value, torch.Tensor) for d in dirichlet))
         return torch_ops.poisson_apply(u, nu, f, f_gp, *torch_ops.dirichlet_args(dirichlet, u, compact), *torch_ops.geometry_args(geom),

@@ -149,6 +149,23 @@ typedef struct dn_poisson_args {
      * (its last workgroup waits for every other one), the deferred one overlaps the next evaluation.  The workspace must not be handed
      * to another launch before the finish kernel has run (one workspace per evaluation in flight). */
     int32_t defer_sums;
+    /* fold_prev != NULL (round 4): the arguments of an EARLIER dn_poisson_apply call on the same mesh that ran with defer_sums (its
+     * partial sums still lie in ITS workspace).  This launch's first workgroup adds them up and writes that call's energy / sumsq /
+     * energy_f32 -- what dn_poisson_finish_sums would do -- before it starts its own strip: the final reduction of evaluation k leaves
+     * the critical path (no tail at the end of launch k, no extra kernel, no event) and rides at the start of launch k + 1, where one
+     * of ~2000 workgroups doing 1-2 us of extra work delays nothing.  A loop therefore gets the loss of step k when launch k + 1 has
+     * run (a training loop only logs it); the last evaluation is closed with dn_poisson_finish_sums.  Kernels without the path (anything
+     * but the 2-D closed-form Q1 kernel and the 3-D Q1 two-element node-owner kernel) return DN_E_UNSUPPORTED.  Read at call time only. */
+    const struct dn_poisson_args *fold_prev;
+    /* f_is_load != 0 (round 4): `f` does not hold nodal forcing values but the ASSEMBLED load vector b_a = sum_e sum_g w_g N_a(g) f_g
+     * (the rule's own weights, no wscale / beta: what this operator returns as -out for u = 0, alpha = 0, beta = 1, wscale = 1, no
+     * conditions).  The forcing of a sample does not change from one training step to the next (the reference re-interpolates it to
+     * the Gauss points every step, e.g. IBN/poisson-2d/parametric/IBN_2D.py:128-130), so it can be assembled once when the dataset is
+     * placed on the device; the operator then spends one FMA per node on it instead of the element's forcing arithmetic (a fifth of
+     * the 3-D Q1 kernel's time): out_a -= beta wscale b_a,  sum W f u = sum_a u_a b_a -- equal to the nodal-forcing result to rounding.
+     * Only the 3-D Q1 two-element node-owner kernel (even nx, 2-point rule, constant-value uint8 / fp32 masks) takes it so far; every
+     * other launch returns DN_E_UNSUPPORTED. */
+    int32_t f_is_load;
 } dn_poisson_args;
 
 int dn_abi_version(void);

@@ -280,3 +280,122 @@ def test_chained_strip_handover_timeout_is_loud():
     v2, g2 = m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=1.0)
     assert torch.equal(v2, v0) and torch.equal(g2, g0)
     ops.workspace_status()
+
+
+# ---------------------------------------------------------------------------------------------
+# 4. Round-4 additions to the fused operator: the forcing as an assembled load vector, the final reduction folded into the next launch
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kw,B", [(dict(domain_sizes=(70, 21, 9), domain_lengths=(2.0, 1.0, 0.5), domain_size=70, domain_length=2.0, nsd=3), 2),
+                                  (dict(domain_size=34, nsd=3), 1)])
+def test_load_vector_forcing_3d_vs_oracle_and_nodal_forcing(kw, B):
+    """ops.LoadVector (dn_poisson_args.f_is_load): the forcing assembled once, b_a = sum_e sum_g w_g N_a f_g, instead of nodal values that
+    every evaluation interpolates to the Gauss points (IBN_3D.py:128-130 / solve_in_object_3d.py:93-96).  Loss and gradient against the
+    oracle's reference formulation on the NODAL forcing, and against the same launch with the nodal forcing; one and two conditions,
+    uint8 and fp32 masks, with and without nu; the energy_loss autograd route included."""
+    from diffnet_amd import LoadVector
+    from oracle.fem_oracle import Oracle
+    m, o = module(kw), Oracle(**kw)
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = seeded(shape, 101), seeded(shape, 102, 0.5), seeded(shape, 103)
+    box = boundary_mask(shape)
+    obj = _blob(shape, 104, 0.05) * (1 - box)
+    ud, nud, fd = u.to(dev()), nu.to(dev()), f.to(dev())
+    lv = LoadVector.assemble(m.geom, fd)
+    assert tuple(lv.shape) == shape
+    for variant, (nu_h, conds, c, jac) in enumerate([(nu, [(box, 0.0)], 0.5, 1.0), (None, [(obj, 1.0), (box, 0.0)], 1.0, 0.125), (nu, [], 1.0, 1.0)]):
+        ur = u.clone().requires_grad_(True)
+        ref = o.energy(ur, nu_h, f, dirichlet=conds, c=c, jac=jac)
+        (gref,) = torch.autograd.grad(ref, ur)
+        for fmt in (torch.uint8, torch.float32):
+            dc = [(mk.to(dev()).to(fmt), val) for mk, val in conds]
+            nd = None if nu_h is None else nud
+            v, g = m.energy_loss_and_grad(ud, nd, lv, dirichlet=dc, c=c, jac=jac)
+            np.testing.assert_allclose(float(v), float(ref), rtol=1e-5, err_msg=f"variant {variant}")
+            close(g, gref.numpy(), rtol=1e-4, arel=1e-4, msg=f"variant {variant}")
+            v2, g2 = m.energy_loss_and_grad(ud, nd, fd, dirichlet=dc, c=c, jac=jac)
+            np.testing.assert_allclose(float(v), float(v2), rtol=2e-6)
+            close(g, g2.cpu().numpy(), rtol=2e-6, arel=2e-6)
+    ug = ud.clone().requires_grad_(True)
+    loss = m.energy_loss(ug, nud, lv, dirichlet=[(box.to(dev()).to(torch.uint8), 0.0)], c=0.5)
+    (ga,) = torch.autograd.grad(loss, ug)
+    v, g = m.energy_loss_and_grad(ud, nud, lv, dirichlet=[(box.to(dev()).to(torch.uint8), 0.0)], c=0.5)
+    assert torch.equal(ga, g) and torch.equal(loss.detach(), v)
+
+
+def test_load_vector_is_refused_where_no_kernel_takes_it():
+    """2-D meshes and 3-D meshes outside the two-element kernel's preconditions (odd nx here) answer DN_E_UNSUPPORTED, never a wrong number."""
+    from diffnet_amd import LoadVector
+    from diffnet_amd._lib import DiffNetHipError
+    for kw in (dict(domain_size=64), dict(domain_size=33, nsd=3)):
+        m = module(kw)
+        shape = (1, 1, *m.geom.node_shape)
+        u, f = seeded(shape, 1).to(dev()), seeded(shape, 2).to(dev())
+        lv = LoadVector.assemble(m.geom, f)
+        with pytest.raises(DiffNetHipError, match="DN_E_UNSUPPORTED"):
+            m.energy_loss_and_grad(u, None, lv, dirichlet=[], c=1.0)
+
+
+@pytest.mark.parametrize("kw,B", [(dict(domain_size=64, ngp_1d=3), 3), (dict(domain_size=512, ngp_1d=3), 2), (dict(domain_size=34, nsd=3), 2)])
+def test_pipelined_sums_equal_in_kernel_sums(kw, B):
+    """PoissonPlan(pipelined_sums=True) + fold(): launch k + 1 forms the scalars of evaluation k from its per-workgroup partial sums
+    (dn_poisson_args.fold_prev), finish_sums() closes the last one.  Loss, energy, sum of squares and gradient of every evaluation of a
+    chain of three equal the in-kernel reduction's; nothing is written before the folding launch has run."""
+    from diffnet_amd import ops
+    m = module(kw)
+    shape = (B, 1, *m.geom.node_shape)
+    bc = boundary_mask((1,) + shape[1:]).to(torch.uint8).to(dev())
+    scale = 1.0 / (B * m.geom.nelem_total)
+    kwargs = dict(alpha=2.0, beta=1.0, c=1.0, wscale=1.0, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
+    sets = [(seeded(shape, 200 + 3 * k).to(dev()), (seeded(shape, 201 + 3 * k) + 0.5).to(dev()), seeded(shape, 202 + 3 * k).to(dev())) for k in range(3)]
+    refs = [[t.clone() for t in ops.PoissonPlan(m.geom, *s, None, [(bc, 0.0)], **kwargs).launch()] for s in sets]
+    plans = [ops.PoissonPlan(m.geom, *s, None, [(bc, 0.0)], pipelined_sums=True, **kwargs) for s in sets]
+    for k in (1, 2):
+        plans[k].fold(plans[k - 1])
+    for p in plans:
+        p.result[1].fill_(-1.0)
+        p.result[2].fill_(-1.0)
+    plans[0].launch()
+    torch.cuda.synchronize()
+    assert float(plans[0].result[2]) == -1.0 and torch.equal(plans[0].result[0], refs[0][0])      # gradient final, scalars not yet formed
+    plans[1].launch()
+    plans[2].launch()
+    torch.cuda.synchronize()
+    assert float(plans[2].result[2]) == -1.0
+    plans[2].finish_sums()
+    for k in range(3):
+        out, sums, loss = plans[k].result
+        assert torch.equal(out, refs[k][0])
+        np.testing.assert_allclose(sums.cpu().numpy(), refs[k][1].cpu().numpy(), rtol=1e-13)
+        np.testing.assert_allclose(float(loss), float(refs[k][2]), rtol=1e-7)
+
+
+@pytest.mark.parametrize("kw,B", [(dict(domain_size=34, nsd=3), 2), (dict(domain_sizes=(70, 21, 9), domain_lengths=(2.0, 1.0, 0.5), domain_size=70, domain_length=2.0, nsd=3), 1)])
+def test_box_faces_in_the_3d_two_element_kernel_equal_mask_images_bitwise(kw, B):
+    """BoxFaces in 3-D (round 4: DN_MASK_BOX read by poisson3d_q1n2_kernel -- no mask array, no load) against the same condition as a uint8
+    image: bitwise equal results, alone, beside an object mask image (uint8 and fp32, both orders of the two conditions), for a subset of
+    faces with a non-zero value, and with the load-vector forcing."""
+    from diffnet_amd import BoxFaces, LoadVector
+    m = module(kw)
+    shape = (B, 1, *m.geom.node_shape)
+    u, nu, f = seeded(shape, 111).to(dev()), seeded(shape, 112, 0.5).to(dev()), seeded(shape, 113).to(dev())
+    box = boundary_mask(shape).to(torch.uint8).to(dev())
+    obj = ((_blob(shape, 114, 0.05).to(dev()) > 0.5) & (box == 0)).to(torch.uint8)
+
+    def same(d_img, d_box, **kwargs):
+        a = m.energy_loss_and_grad(u, nu, kwargs.pop("f", f), dirichlet=d_img, **kwargs)
+        b = m.energy_loss_and_grad(u, nu, kwargs.pop("f2", f), dirichlet=d_box, **kwargs)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+    same([(box, 0.0)], [(BoxFaces("all"), 0.0)], c=0.5)
+    same([(obj, 1.0), (box, 0.0)], [(obj, 1.0), (BoxFaces("all"), 0.0)], c=1.0)
+    same([(box, 0.0), (obj, 1.0)], [(BoxFaces("all"), 0.0), (obj, 1.0)], c=1.0)
+    same([(obj.float(), 1.0), (box.float(), 0.0)], [(obj.float(), 1.0), (BoxFaces("all"), 0.0)], c=1.0)
+    part = torch.zeros(shape, dtype=torch.uint8, device=dev())
+    part[..., 0] = 1
+    part[:, :, -1] = 1
+    part[:, :, :, 0] = 1
+    same([(part, 0.25)], [(BoxFaces(["xlo", "zhi", "ylo"]), 0.25)], c=1.0, jac=0.5)
+    lv = LoadVector.assemble(m.geom, f)
+    a = m.energy_loss_and_grad(u, nu, lv, dirichlet=[(box, 0.0)], c=1.0)
+    b = m.energy_loss_and_grad(u, nu, lv, dirichlet=[(BoxFaces("all"), 0.0)], c=1.0)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
