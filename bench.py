@@ -3,8 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--settle S]
 
-The W warm-up + K timed steps are run twice: from an idle GPU (`cold_start` in the line) and again after S = 400 untimed steps (`value`,
-`ms_per_step`): for 1.3-10 ms after load onset the part runs every kernel 10-25 % slower, and W = 5, K = 20 is 1.4 ms of load.
+`value` / `ms_per_step`: W untimed warm-up steps, then exactly K timed steps.  The same W + K steps are run a second time after S = 400
+further untimed steps and reported as `steady_state` (for 1.3-10 ms after load onset the part runs every kernel 10-25 % slower, and
+W = 5, K = 20 is 1.4 ms of load: a job of more than a few hundred steps is in the second regime, and so are the roofline launches).
 
 N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the driver's form:
 RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or run plainly -- then this process, which has not touched the GPU
@@ -241,7 +242,8 @@ def device_us(fn, n=40, warm=3, settle_s=0.04):
     """Device time per call of `fn` in steady state.  40 ms of load first (between 1.3 and 10 ms after the GPU leaves idle every kernel
     runs 10-25 % slower, tools/ramp2d.py); then n calls enqueued behind a blocker kernel that outlasts the host's enqueue work, between
     one pair of events -- or, for calls whose host side is slower than the device (several launches + torch ops per call), the n calls
-    captured into ONE HIP graph whose replay is timed.  Returns (device_us, host_us)."""
+    captured into ONE HIP graph whose replay is timed.  Returns (device_us, host_us, method): every row says which of the three regimes it
+    was timed in ("back-to-back" / "hip-graph" / "behind-blocker")."""
     if _SLEEP_CYC_PER_US[0] is None:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda._sleep(1000); torch.cuda.synchronize()
@@ -271,7 +273,7 @@ def device_us(fn, n=40, warm=3, settle_s=0.04):
     torch.cuda.synchronize()
     direct_us = a.elapsed_time(b) / n * 1e3
     if direct_us > 3.0 * host_us:
-        return direct_us, host_us
+        return direct_us, host_us, "back-to-back"
     if host_us > 60.0:
         try:
             graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
@@ -288,7 +290,7 @@ def device_us(fn, n=40, warm=3, settle_s=0.04):
             graph.replay()
             b.record()
             torch.cuda.synchronize()
-            return a.elapsed_time(b) / n * 1e3, host_us
+            return a.elapsed_time(b) / n * 1e3, host_us, "hip-graph"
         except Exception:                      # not capturable: fall through to the blocker
             torch.cuda.synchronize()
     torch.cuda._sleep(int(_SLEEP_CYC_PER_US[0] * host_us * n * 3.0) + 1000)
@@ -297,10 +299,10 @@ def device_us(fn, n=40, warm=3, settle_s=0.04):
         fn()
     b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) / n * 1e3, host_us
+    return a.elapsed_time(b) / n * 1e3, host_us, "behind-blocker"
 
 
-def config_rows(dev, budget_s=90.0):
+def config_rows(dev, budget_s=150.0):
     """One row per BASELINE.json config (and the batch sizes SURVEY 8(d) names): us per evaluation of the loss + gradient in steady
     state, fraction of the HBM peak on the config's algorithmic bytes, work units per second.  Inputs larger
     than 64 MB rotate over several sets of arrays (no Infinity-Cache help).  Public API calls (the cached prepared launches of
@@ -309,32 +311,52 @@ def config_rows(dev, budget_s=90.0):
     t_start = time.perf_counter()
     rows = []
 
-    def add(name, us, host, alg_bytes, units, note=None):
+    def add(name, us, host, alg_bytes, units, note=None, method="wall-clock"):
         r = {"name": name, "us_per_eval": round(us, 2), "host_us_per_call": round(host, 1), "frac": round(alg_bytes / us / 1e3 / HBM_PEAK_GBS, 4),
-             "units_per_s": units / us * 1e6}
+             "units_per_s": units / us * 1e6, "timing": method}
         if note:
             r["note"] = note
         rows.append(r)
 
-    def poisson(name, nsd, n, ngp, B, c, nsets=1):
+    def poisson(name, nsd, n, ngp, B, c, nsets=1, load=False, box=False, fold=False):
+        """load: the forcing of every sample as its assembled load vector (diffnet_amd.LoadVector, assembled once outside the timed calls);
+        box: the Dirichlet condition as faces of the domain box (BoxFaces: no array); fold: prepared launches whose final reduction is done by
+        the next launch of the rotation (PoissonPlan(pipelined_sums=True)).  Without them: the public one-shot call on the reference's inputs."""
         if time.perf_counter() - t_start > budget_s:
             return
+        from diffnet_amd import BoxFaces, LoadVector
+        from diffnet_amd import ops as _ops
         cls = DiffNet3DFEM if nsd == 3 else DiffNet2DFEM
         m = cls(None, domain_size=n, ngp_1d=ngp, nsd=nsd).to(dev)
         shape = (B, 1, *m.geom.node_shape)
         sets = [make_inputs(shape, dev, 7 + k) for k in range(nsets)]
+        if load:
+            sets = [(u, nu, LoadVector.assemble(m.geom, f), bc) for (u, nu, f, bc) in sets]
         outs = [torch.empty(shape, device=dev) for _ in range(nsets)]
         turn = [0]
+        cond = (lambda bc: [(BoxFaces("all"), 0.0)]) if box else (lambda bc: [(bc, 0.0)])
+        if fold:
+            scale = 1.0 / (B * m.geom.nelem_total)
+            plans = [_ops.PoissonPlan(m.geom, u, nu, f, None, cond(bc), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale, want_out=True,
+                                      want_sums=True, loss_scale=scale, out=outs[k], pipelined_sums=True) for k, (u, nu, f, bc) in enumerate(sets)]
+            for k in range(nsets):
+                plans[k].fold(plans[k - 1])
 
-        def fn():
-            k = turn[0]
-            turn[0] = (k + 1) % nsets
-            u, nu, f, bc = sets[k]
-            return m.energy_loss_and_grad(u, nu, f, dirichlet=[(bc, 0.0)], c=c, out=outs[k])
+            def fn():
+                k = turn[0]
+                turn[0] = (k + 1) % nsets
+                return plans[k].launch()
+        else:
+            def fn():
+                k = turn[0]
+                turn[0] = (k + 1) % nsets
+                u, nu, f, bc = sets[k]
+                return m.energy_loss_and_grad(u, nu, f, dirichlet=cond(bc), c=c, out=outs[k])
 
-        us, host = device_us(fn)
-        add(name, us, host, ALG_BYTES_PER_NODE * B * m.geom.nnode_total, B * m.geom.nelem_total * m.geom.ngp_total,
-            f"{nsets} sets of arrays in rotation" if nsets > 1 else None)
+        us, host, how = device_us(fn)
+        notes = ([f"{nsets} sets of arrays in rotation"] if nsets > 1 else []) + (["forcing as assembled load vector"] if load else []) + \
+                (["Dirichlet condition as box faces (no array)"] if box else []) + (["prepared launches, final reduction folded into the next launch"] if fold else [])
+        add(name, us, host, ALG_BYTES_PER_NODE * B * m.geom.nnode_total, B * m.geom.nelem_total * m.geom.ngp_total, "; ".join(notes) or None, how)
 
     def fsdt(name, n, B):
         if time.perf_counter() - t_start > budget_s:
@@ -350,15 +372,48 @@ def config_rows(dev, budget_s=90.0):
         def fn():
             return fsdt_loss_and_grad(m, *fields, bc)
 
-        us, host = device_us(fn)
-        add(name, us, host, 68 * B * n * n, B * m.geom.nelem_total * m.geom.ngp_total, "fsdt_loss_and_grad: residual norms + gradient, two launches, no autograd graph")
+        us, host, how = device_us(fn)
+        add(name, us, host, 68 * B * n * n, B * m.geom.nelem_total * m.geom.ngp_total, "fsdt_loss_and_grad: residual norms + gradient, two launches, no autograd graph", how)
 
         def fn_autograd():
             torch.autograd.grad(fsdt_total_loss(m, *fields, bc), fields)
 
-        us, host = device_us(fn_autograd)
+        us, host, how = device_us(fn_autograd)
         add(name + " [autograd: fsdt_total_loss + backward]", us, host, 68 * B * n * n, B * m.geom.nelem_total * m.geom.ngp_total,
-            "the same two launches behind torch.autograd (one Function node): host_us_per_call is the eager wall time per step")
+            "the same two launches behind torch.autograd (one Function node): host_us_per_call is the eager wall time per step", how)
+
+    def dropin_ibn2d(name, n, B):
+        """The loss() body of IBN/poisson-2d/parametric/IBN_2D.py:116-134 as the reference wrote it (two torch.where lines, five
+        gauss_pt_evaluation* calls, the broadcast multiply / sum / mean), running on the drop-in operators (examples/ibn_2d_parametric.py,
+        Poisson(dropin=True)), forward + backward wrt u: what an UNMODIFIED caller pays.  The fused spelling of the same loss is the
+        `cfg2 ... B=16` row above."""
+        if time.perf_counter() - t_start > budget_s:
+            return
+        from examples.ibn_2d_parametric import Poisson
+        mod = Poisson(None, dropin=True, domain_size=n, ngp_1d=3).to(dev)
+        g = torch.Generator().manual_seed(5)
+        u = torch.rand((B, 1, n, n), generator=g).to(dev).requires_grad_(True)
+        f = torch.rand((B, 1, n, n), generator=g).to(dev)
+        sink = torch.zeros((B, 1, n, n), device=dev)
+        sink[..., 0] = 1; sink[..., -1] = 1; sink[..., 0, :] = 1; sink[..., -1, :] = 1
+        src = ((torch.rand((B, 1, n, n), generator=g) < 0.05).float().to(dev)) * (1 - sink)
+
+        def fn():
+            (gu,) = torch.autograd.grad(mod.loss(u, src, f, sink), u)
+            return gu
+
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = 10
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / k * 1e6
+        add(name, us, us, ALG_BYTES_PER_NODE * B * n * n, B * mod.geom.nelem_total * mod.geom.ngp_total,
+            "5 dn_gauss_pt_eval_fwd + 3 adjoint launches + the caller's own torch elementwise ops on (B, 9, 511, 511) tensors; wall clock per loss + backward; "
+            "frac counts the fused path's 16 B/node")
 
     def unet(name, n, B):
         if time.perf_counter() - t_start > budget_s:
@@ -394,7 +449,11 @@ def config_rows(dev, budget_s=90.0):
     poisson("cfg2 2-D 512^2 Q1 3x3 B=16", 2, 512, 3, 16, 1.0, nsets=4)
     poisson("cfg2 2-D 512^2 Q1 3x3 B=64 (uint8 mask images, public API)", 2, 512, 3, 64, 1.0, nsets=4)
     poisson("cfg3 3-D 128^3 Q1 2x2x2 B=1 energy c=1/2", 3, 128, 2, 1, 0.5)
+    poisson("cfg3 3-D 128^3 B=1, load vector + box faces, folded sums", 3, 128, 2, 1, 0.5, nsets=4, load=True, box=True, fold=True)
     poisson("cfg4 3-D 256^3 Q1 2x2x2 B=1 (whole mesh on one GPU)", 3, 256, 2, 1, 1.0, nsets=4)
+    poisson("cfg4 3-D 256^3 B=1, forcing as assembled load vector (uint8 mask image)", 3, 256, 2, 1, 1.0, nsets=4, load=True)
+    poisson("cfg4 3-D 256^3 B=1, load vector + box faces, folded sums", 3, 256, 2, 1, 1.0, nsets=4, load=True, box=True, fold=True)
+    dropin_ibn2d("cfg2 UNCHANGED CALLER: the loss() body of IBN_2D.py:116-134 on the drop-in operators + backward, 512^2 B=16", 512, 16)
     fsdt("cfg5 FSDT plate 1025^2 nodes (512^2 Q2 elements) 3x3 B=1", 1025, 1)
     fsdt("cfg5 FSDT plate 1025^2 Q2 3x3 B=8", 1025, 8)
     unet("cfg2 UNet(2->1) + FEM loss training step, 512^2 B=16", 512, 16)
@@ -407,9 +466,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps directly before the timed ones")
     ap.add_argument("--settle", type=int, default=400,
-                    help="untimed steps BEFORE the warm-up + timed steps whose rate is reported as `value` (about 22 ms of load: between about 1.3 and "
+                    help="untimed steps before the SECOND run of the warm-up + timed steps, reported as `steady_state` (about 22 ms of load: between about 1.3 and "
                          "10 ms after the GPU leaves idle the launch runs 10-25 %% slower -- power-management transient, tools/ramp2d.py, "
-                         "profiles/r2_ramp2d.txt).  The same warm-up + timed steps are also run from idle first and reported as `cold_start`; "
+                         "profiles/r2_ramp2d.txt).  `value` is the W + K steps run first, from idle; this second run is reported as `steady_state`; "
                          "--settle 0 makes the two the same thing")
     ap.add_argument("--batch", type=int, default=64, help="samples per GPU")
     ap.add_argument("--size", type=int, default=512)
@@ -434,6 +493,7 @@ def main():
     ap.add_argument("--slab-warmup", type=int, default=300, help="untimed steps of the slab leg (past the load-onset transient: profiles/r2_ramp3d.txt)")
     ap.add_argument("--slab-batch", type=int, default=1, help="samples of the slab leg's mesh (BASELINE configs[3] is parametric: the reference trains it with batch 8)")
     ap.add_argument("--slab-timeout", type=float, default=180.0, help="watchdog of the slab leg, seconds")
+    ap.add_argument("--no-slab-b8", action="store_true", help="skip the batch-8 repetition of the slab leg (`slab_3d_b8`)")
     args = ap.parse_args()
     if args.async_sums:
         args.sums = "async"
@@ -517,8 +577,17 @@ def main():
         return rot[k].launch()
 
     first_unreduced = [0]          # grouped: the first slot of the current group whose loss no collective has taken yet
+    fold = args.sums == "fold"     # the loss of evaluation k is formed by launch k + 1 (slot k of loss_buf is written one launch late)
+
+    def close_last():
+        """fold: the scalars of the last launched evaluation are still per-workgroup partial sums -- one small kernel forms them (called
+        inside every timed region, so that every step's loss is formed inside it)"""
+        if fold and last[0] is not None:
+            last[0].finish_sums()
 
     def reduce_slots(a, b):
+        if b <= a:                                         # [a, NROT): the range ends at the wrap of the rotation
+            b = NROT
         view = loss_buf[a:b]
         if backend == "nccl":                              # mean over ranks inside the collective: no extra launch
             work = dist.all_reduce(view, op=dist.ReduceOp.AVG, async_op=True)
@@ -530,11 +599,17 @@ def main():
     def step():
         if grouped:
             k = turn[0]
-            if k % PIPE == 0:
-                while len(pending) > 1:                    # the collective that read this group's slots last (issued PIPE steps ago) is done
+            # the collective that read this group's slots last must be done before the first of them is written again: by this launch
+            # (in-kernel sums: launch k writes slot k) or by the next one (fold: launch k writes slot k - 1)
+            if k % PIPE == (1 if fold else 0):
+                while len(pending) > 1:
                     pending.pop(0)[0].wait()
             grad, _, loss = launch_rot()
-            if (k + 1) % PIPE == 0:
+            if fold:
+                if k % PIPE == 0 and first_unreduced[0] != k:      # this launch has just formed the last loss of the group before it
+                    reduce_slots(first_unreduced[0], k)
+                    first_unreduced[0] = k
+            elif (k + 1) % PIPE == 0:
                 reduce_slots(first_unreduced[0], k + 1)
                 first_unreduced[0] = (k + 1) % NROT
             return loss, grad
@@ -566,6 +641,7 @@ def main():
         return loss, grad
 
     def drain():
+        close_last()
         if grouped and first_unreduced[0] != turn[0]:      # a group that is not full yet: its losses so far
             reduce_slots(first_unreduced[0], turn[0])
             first_unreduced[0] = turn[0]
@@ -586,6 +662,7 @@ def main():
         region[0].record()
         for _ in range(args.steps):
             step()
+        close_last()                                       # (fold: the last step's loss; a no-op otherwise)
         region[1].record()
         drain()
         if dist is not None:
@@ -599,13 +676,15 @@ def main():
 
     # The GPU leaves idle when the first launch arrives, and between 1.3 and 10 ms after that every kernel runs 10-25 % slower (power-management
     # ramp, tools/ramp2d.py): the driver's W = 5, K = 20 is 1.4 ms of load, i.e. entirely inside that transient.  The W + K steps are therefore
-    # run twice: once from idle (reported as `cold_start`), then again after --settle untimed steps (default 400: 22 ms of the same load) -- the
-    # steady state a job of more than a few hundred steps is in, and the regime of the roofline launches below.  `value` is the second run.
-    cold_dt, cold_region_ms = timed_steps()
+    # run twice.  `value` / `ms_per_step` are the FIRST run -- exactly the contract: W untimed warm-up steps, then K timed steps, nothing before
+    # them (round 4; rounds 2-3 reported the second run as `value` and this one as `cold_start`).  The second run, after --settle untimed steps
+    # (default 400: 22 ms of the same load), is the steady state a job of more than a few hundred steps is in and the regime of the roofline
+    # launches below: reported as `steady_state`.
+    dt, region_ms = timed_steps()
     for _ in range(args.settle):
         step()
     drain()
-    dt, region_ms = timed_steps()
+    steady_dt, steady_timed_ms = timed_steps()
 
     # dominant-kernel time: timing-only HIP events on the launch stream around each dn_poisson_apply (ONE kernel: the fused Poisson
     # kernel, whose last workgroup also does the fixed-order final reduction), K launches over the rotation, each between its own pair
@@ -627,8 +706,8 @@ def main():
     steady_region_ms = rot_region[0].elapsed_time(rot_region[1]) / (2 * K)
     # side field: the same rotation with the loss formed inside the launch (in-kernel final reduction)
     sync_ms = None
-    if not args.sync_sums and rank == 0:
-        pls = make_plans(bc_form, async_sums=False)
+    if args.sums != "kernel" and rank == 0:
+        pls = make_plans(bc_form, "kernel")
         t = [0]
 
         def go_sync():
@@ -647,7 +726,7 @@ def main():
     bc_forms_us = {}
     if args.nsd == 2 and rank == 0:
         for name in forms:
-            pls = rot if name == bc_form else make_plans(name)
+            pls = rot if name == bc_form else make_plans(name, args.sums)
             t = [0]
 
             def go():
@@ -697,7 +776,11 @@ def main():
         all_sets = sets + extra
         mk = lambda st: _ops.PoissonPlan(m.geom, st[0], st[1], st[2], None, forms[bc_form](st[3]), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0,
                                          out_scale=scale0, want_out=True, want_sums=True, loss_scale=scale0, async_sums=False)
-        pl16 = rot + [mk(st) for st in extra]
+        pl16 = [_ops.PoissonPlan(m.geom, st[0], st[1], st[2], None, forms[bc_form](st[3]), alpha=2.0 * c, beta=1.0, c=c, wscale=1.0, out_scale=scale0,
+                                 want_out=True, want_sums=True, loss_scale=scale0, pipelined_sums=fold) for st in all_sets]
+        if fold:
+            for k in range(16):
+                pl16[k].fold(pl16[k - 1])
         t = [0]
 
         def go16():
@@ -774,10 +857,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "poisson fused kernel (one launch per dn_poisson_apply)", "kernel_avg_ms": kern_avg_ms,
-                         "sums": ("the loss of a step is formed from the launch's per-workgroup partial sums by a one-workgroup kernel on a side stream, "
-                                  "under the next step's launch (dn_poisson_finish_sums); kernel_avg_ms is the fused kernel, value / ms_per_step include "
-                                  "every step's reduction (all of them run inside the timed region)") if not args.sync_sums else
-                                 "the loss is formed inside the launch (its last workgroup adds up the partial sums)",
+                         "sums_mode": args.sums,
+                         "sums": {"fold": "the loss of step k is formed from launch k's per-workgroup partial sums by the FIRST workgroup of launch k + 1, before its "
+                                          "own march (dn_poisson_args.fold_prev): the ~3 us serial final reduction leaves the end of every launch; the last step of "
+                                          "a timed region is closed by dn_poisson_finish_sums inside the region.  kernel_avg_ms is this launch (it includes the "
+                                          "folding of the launch before it); kernel_avg_ms_with_in_kernel_sums is the round-1..3 form",
+                                  "async": "the loss of a step is formed from the launch's per-workgroup partial sums by a one-workgroup kernel on a side stream, "
+                                           "under the next step's launch (dn_poisson_finish_sums); value / ms_per_step include every step's reduction",
+                                  "kernel": "the loss is formed inside the launch (its last workgroup adds up the partial sums)"}[args.sums],
                          "kernel_avg_ms_with_in_kernel_sums": None if sync_ms is None else sum(sync_ms) / len(sync_ms),
                          "frac_with_in_kernel_sums": None if sync_ms is None else alg_bytes / (sum(sync_ms) / len(sync_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_median_ms": kern_med_ms, "kernel_min_ms": kern_ms[0], "kernel_max_ms": kern_ms[-1],
@@ -798,11 +885,12 @@ def main():
                          "timed_region_ms_per_launch": region_ms,
                          "frac_over_timed_region": alg_bytes / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "rotation_kernel_median_us_by_mask_format": bc_forms_us, "deeper_rotation": deeper},
-            "cold_start": {"value": units_per_step * world * args.steps / cold_dt, "ms_per_step": cold_dt / args.steps * 1e3,
-                           "timed_region_ms_per_launch": cold_region_ms,
-                           "note": "the same W warm-up + K timed steps started from an idle GPU (no settle steps before them): with the driver's W = 5, K = 20 "
-                                   "all of it falls into the 1.3-10 ms power-management transient after load onset; `value` is the same measurement "
-                                   "repeated after `settle` untimed steps"},
+            "steady_state": {"value": units_per_step * world * args.steps / steady_dt, "ms_per_step": steady_dt / args.steps * 1e3,
+                             "timed_region_ms_per_launch": steady_timed_ms, "untimed_steps_before": 2 * args.warmup + args.steps + args.settle,
+                             "note": "the same W warm-up + K timed steps repeated after `settle` further untimed steps: `value` (W + K steps from an idle GPU: with "
+                                     "the driver's W = 5, K = 20 all of it falls into the 1.3-10 ms power-management transient after load onset, tools/ramp2d.py) "
+                                     "says what a 25-step job sees, this what a job of more than a few hundred steps sees.  Rounds 2-3 reported this one as "
+                                     "`value` and the other as `cold_start`"},
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, c)
@@ -818,8 +906,9 @@ def main():
     # strong-scaling leg of BASELINE configs[3] in the same run (all ranks take part): one 256^3 mesh cut into z-slabs.  The headline
     # measurement above is complete at this point; the leg runs under a watchdog so that a failure or a hang in its point-to-point
     # exchange (first exercised over RCCL on the driver's multi-GPU node) still leaves the ONE JSON line, with the reason in
-    # "slab_3d.error" -- which is what a reader must check: the process then ends with status 0 because the headline is complete
-    # (status 1 only if the line could not be printed).  `emitted` makes sure exactly one line is printed, whoever gets there first.
+    # "slab_3d.error".  Exit status (round 4): with ONE rank the headline is complete and the status stays 0; with WORLD_SIZE > 1 a failed or hung
+    # slab leg ends the process with status 3 AFTER the line has been printed -- under torchrun a dead RCCL point-to-point exchange must not read as
+    # success (status 1: the line could not be printed).  `emitted` makes sure exactly one line is printed, whoever gets there first.
     if args.slab_size and args.nsd == 2 and args.size == 512:
         import threading
         emit_lock, emitted = threading.Lock(), [False]
@@ -836,10 +925,12 @@ def main():
                 except Exception:
                     return False
 
+        fail_status = 3 if world > 1 else 0
+
         def give_up():
             if rank == 0:
                 out["slab_3d"] = {"error": f"slab leg did not finish within {args.slab_timeout} s (n_gpus={world})"}
-            os._exit(0 if emit() else 1)
+            os._exit(fail_status if emit() else 1)
 
         dog = threading.Timer(args.slab_timeout, give_up)
         dog.daemon = True
@@ -848,11 +939,18 @@ def main():
             slab = slab_leg(args, rank, world, dev, dist, args.slab_size, args.slab_batch, 2, args.slab_steps, args.slab_warmup)
             if rank == 0:
                 out["slab_3d"] = slab
+            # the same mesh with the batch the reference trains IBN_3D with (IBN_3D.py:167-179): per-rank kernels grow with B, the exchange does not
+            if args.slab_batch != 8 and not args.no_slab_b8:
+                slab8 = slab_leg(args, rank, world, dev, dist, args.slab_size, 8, 2, max(10, args.slab_steps // 4), max(20, args.slab_warmup // 4))
+                if rank == 0:
+                    out["slab_3d_b8"] = slab8
         except Exception as e:                       # noqa: BLE001 -- reported, not hidden: the line says what failed
             dog.cancel()
             if rank == 0:
-                out["slab_3d"] = {"error": f"{type(e).__name__}: {e}"[:500]}
-            os._exit(0 if emit() else 1)             # peers may be stuck in a collective: no orderly teardown (their watchdogs end them)
+                out.setdefault("slab_3d", {"error": f"{type(e).__name__}: {e}"[:500]})
+                if "error" not in out["slab_3d"]:
+                    out["slab_3d_b8"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            os._exit(fail_status if emit() else 1)   # peers may be stuck in a collective: no orderly teardown (their watchdogs end them)
         dog.cancel()
         emit()
     elif rank == 0:

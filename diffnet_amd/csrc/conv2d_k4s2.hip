@@ -24,6 +24,16 @@
 
 namespace dn {
 
+// round 4: raw-row-tile forms (conv2d_k4s2_v2.hip); false = preconditions not met (or "CONV2D_V1" set): run the kernels above
+bool conv2d_down_v2(const float* fine, const float* w, float* coarse, int64_t B, int64_t C, int64_t M, int64_t H, int64_t W, hipStream_t s);
+bool conv2d_up_v2(const float* coarse, const float* w, float* fine, int64_t B, int64_t C, int64_t M, int64_t H, int64_t W, hipStream_t s);
+bool conv2d_wrw_v2_ok(const float* fine, const float* coarse, int64_t C, int64_t H, int64_t W);
+bool conv2d_wrw_v2_shape_ok(int64_t C, int64_t H, int64_t W);
+int conv2d_wrw_v2_ncw(int64_t C);
+bool conv2d_wrw_v2(const float* fine, const float* coarse, float* part, int64_t B, int64_t C, int64_t M, int64_t H, int64_t W, int nz, int tiles_per_wg,
+                   hipStream_t s);
+
+
 typedef float c2_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int C2_TN = 64;          // positions per tile
@@ -433,13 +443,30 @@ __global__ void __launch_bounds__(256) conv2d_k4s2_wsum_kernel(const float* __re
     gw[k] = (float)s;
 }
 
+// the same sum with one WAVE per output (lane l adds slices l, l + 64, ... in order, then the fixed-order wave sum): for launches with many
+// K-slices and few outputs -- the U-Net's first layer has 1024 outputs: one thread per output left the whole reduction to four workgroups
+__global__ void __launch_bounds__(256) conv2d_k4s2_wsum_wave_kernel(const float* __restrict__ part, float* __restrict__ gw, int nz, long n) {
+    const long k = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int z = lane; z < nz; z += 64) s += (double)part[(size_t)z * n + k];
+    s = wave_sum(s);
+    if (lane == 0) gw[k] = (float)s;
+}
+
 static void c2_wrw_plan(int64_t B, int64_t C, int64_t M, int64_t H, int64_t W, int& nz, int& tiles_per_wg) {
     const int64_t tiles = (B * H * W + C2_TN - 1) / C2_TN;
-    const int64_t groups = ((C + 3) / 4) * ((M + 63) / 64);
-    int64_t want = (2048 + groups - 1) / groups;          // ~8 workgroups per CU in total
+    const int64_t ncw = conv2d_wrw_v2_shape_ok(C, H, W) ? conv2d_wrw_v2_ncw(C) : 4;       // fine channels per workgroup of the kernel that will run
+    const int64_t groups = ((C + ncw - 1) / ncw) * ((M + 63) / 64);
+    const char* tw = config(CFG_CONV_WRW_WGS);             // (tuning switch: workgroups a weight-gradient launch aims at)
+    const int64_t total = tw ? std::max(256, std::atoi(tw)) : 1024;      // round 4: 2048 -> 1024 with the v2 kernels (3-4 resident per CU): fewer, longer K-slices and
+                                                                         // half the partial arrays to sum -- U-Net step 7.28 -> 7.12 ms (2048 / 1280 / 1024 / 768: 7.28 / 7.26 / 7.12 / 7.19)
+    int64_t want = (total + groups - 1) / groups;
     if (want < 1) want = 1;
     if (want > tiles) want = tiles;
-    if (want > 256) want = 256;
+    if (want > 1024) want = 1024;                         // (round 4: 256 -> 1024 for layers with ONE (channel group, row group) pair -- the U-Net's first, 2 -> 32,
+                                                          // was a launch of 256 workgroups of 64 dependent chunks each; their partials are summed a wave per output)
     tiles_per_wg = (int)((tiles + want - 1) / want);
     nz = (int)((tiles + tiles_per_wg - 1) / tiles_per_wg);
 }
@@ -459,6 +486,10 @@ extern "C" int dn_conv2d_k4s2_down(const float* fine, const float* w, float* coa
     if (int rc = c2_check(B, C, M, H, W)) return rc;
     if (!fine || !w || !coarse) return DN_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (conv2d_down_v2(fine, w, coarse, B, C, M, H, W, s)) {
+        DN_LAUNCH_CHECK();
+        return 0;
+    }
     const int64_t tiles = B * ((H * W + C2_TN - 1) / C2_TN);
     if (tiles >= (1ll << 31)) return DN_E_UNSUPPORTED;
     if (M <= 32) {
@@ -477,6 +508,10 @@ extern "C" int dn_conv2d_k4s2_up(const float* coarse, const float* w, float* fin
     if (int rc = c2_check(B, C, M, H, W)) return rc;
     if (!fine || !w || !coarse) return DN_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (conv2d_up_v2(coarse, w, fine, B, C, M, H, W, s)) {
+        DN_LAUNCH_CHECK();
+        return 0;
+    }
     const int64_t tiles = B * ((H * W + C2_TN - 1) / C2_TN);
     if (tiles >= (1ll << 31)) return DN_E_UNSUPPORTED;
     if (C <= 32) {
@@ -506,11 +541,16 @@ extern "C" int dn_conv2d_k4s2_wrw(const float* fine, const float* coarse, float*
     if (nz > 1 && (!workspace || workspace_bytes < dn_conv2d_k4s2_wrw_workspace_bytes(B, C, M, H, W))) return DN_E_WORKSPACE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* part = nz == 1 ? grad_weight : static_cast<float*>(workspace);
-    hipLaunchKernelGGL(conv2d_k4s2_wrw_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)((M + 63) / 64), (unsigned)nz), dim3(256), 0, s, fine, coarse,
-                       part, (int)B, (int)C, (int)M, (int)H, (int)W, tpw);
+    // (the K-split plan counts tiles of 64 flattened positions; the v2 kernel's tiles are 64 positions too: TR x TW blocks of one sample)
+    if (!(conv2d_wrw_v2_ok(fine, coarse, C, H, W) && conv2d_wrw_v2(fine, coarse, part, B, C, M, H, W, nz, tpw, s)))
+        hipLaunchKernelGGL(conv2d_k4s2_wrw_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)((M + 63) / 64), (unsigned)nz), dim3(256), 0, s, fine, coarse,
+                           part, (int)B, (int)C, (int)M, (int)H, (int)W, tpw);
     if (nz > 1) {
         const long nout = (long)M * C * 16;
-        hipLaunchKernelGGL(conv2d_k4s2_wsum_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, part, grad_weight, nz, nout);
+        if (nz >= 128 && nout <= 16384)
+            hipLaunchKernelGGL(conv2d_k4s2_wsum_wave_kernel, dim3((unsigned)((nout + 3) / 4)), dim3(256), 0, s, part, grad_weight, nz, nout);
+        else
+            hipLaunchKernelGGL(conv2d_k4s2_wsum_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, s, part, grad_weight, nz, nout);
     }
     DN_LAUNCH_CHECK();
     return 0;

@@ -183,9 +183,17 @@ class SlabPoisson:
     the fused kernel on the slab, nothing computed twice: first the strips next to the two faces across the decomposed axis (C ABI:
     dn_poisson_args.strip_select = 1) -- after it this rank's parts of its interface layers are final, and their exchange with the
     neighbouring ranks starts on a side stream --, then all the other strips (strip_select = 2, sums added to the first launch's),
-    which the exchange overlaps; the 4-byte loss all-reduce (asynchronous); one small add per face."""
+    which the exchange overlaps; the 4-byte loss all-reduce (asynchronous); one small add per face.
 
-    def __init__(self, nsd, sizes_xyz, lengths_xyz, rank, world, ngp_1d=2, group=None, device=None, overlap=True):
+    overlap: True = always the two-launch form, False = one launch over the slab, then the exchange; "auto" (default, round 4) = the launch
+    plan decides per call: a slab whose kernel is shorter than the collectives' latency is not worth splitting -- two launches over half the
+    strips each take nearly as long as one over all of them when a launch is the latency chain of ~10 layers (rank 3 of 8 of 256^3, B = 1:
+    18.1 + 18.3 us against 24.7 us in one launch, profiles/r3_slab_timeline.txt) -- so the split is used from SPLIT_MIN_NODES slab nodes x
+    batch on (256^3 over 8 ranks: B >= 4)."""
+
+    SPLIT_MIN_NODES = 8_000_000
+
+    def __init__(self, nsd, sizes_xyz, lengths_xyz, rank, world, ngp_1d=2, group=None, device=None, overlap="auto"):
         from . import DiffNet2DFEM, DiffNet3DFEM
         self.dec = SlabDecomposition(nsd, sizes_xyz, lengths_xyz, rank, world)
         cls = DiffNet3DFEM if nsd == 3 else DiffNet2DFEM
@@ -193,7 +201,7 @@ class SlabPoisson:
         if device is not None:
             self.fem = self.fem.to(device)
         self.group = group
-        self.overlap = overlap and world > 1
+        self.overlap = overlap if world > 1 else False
         self.exchange = InterfaceExchange(self.dec, group)
 
     def _local_conditions(self, dirichlet, like):
@@ -236,8 +244,9 @@ class SlabPoisson:
             dec = self.dec
             local = self._local_conditions(dl, u_local)
             kw = dict(alpha=2.0 * c, beta=1.0, c=c, wscale=jac, out_scale=scale, want_out=True, want_sums=True, loss_scale=scale)
-            first = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, local, strip_select=1 if self.overlap else 0, **kw)
-            rest = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, local, strip_select=2, continues=first, **kw) if self.overlap else None
+            split = (u_local.numel() >= self.SPLIT_MIN_NODES) if self.overlap == "auto" else bool(self.overlap)
+            first = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, local, strip_select=1 if split else 0, **kw)
+            rest = ops.PoissonPlan(self.fem.geom, u_local, nu, f, None, local, strip_select=2, continues=first, **kw) if split else None
             self._plan_key, self._plan = key, (first, rest, local)
         return self._plan
 

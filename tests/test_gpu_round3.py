@@ -85,7 +85,7 @@ def test_slab_path_takes_packed_masks_and_box_faces(nsd, sizes, world, B):
     lref, gref = m.energy_loss_and_grad(u, nu, f, dirichlet=[(src, 1.0), (box, 0.0)], c=0.7)
     total, gsum = 0.0, torch.zeros_like(u)
     for r in range(world):
-        sp = SlabPoisson(nsd, sizes, lengths, r, world, ngp_1d=2, device=dev())
+        sp = SlabPoisson(nsd, sizes, lengths, r, world, ngp_1d=2, device=dev(), overlap=True)
         dec = sp.dec
         ul, nul, fl = dec.take(u), dec.take(nu), dec.take(f)
         cond = [(PackedMask.pack(dec.take(src)), 1.0), (box, 0.0)]
@@ -100,6 +100,13 @@ def test_slab_path_takes_packed_masks_and_box_faces(nsd, sizes, world, B):
         assert torch.equal(grad[:, :, 0], face_lo) and torch.equal(grad[:, :, -1], face_hi)
         total += float(loss)
         gsum[:, :, dec.n0:dec.n1 + 1] += grad
+        # overlap="auto" (the default, round 4): a slab this small is evaluated by ONE launch -- same numbers
+        sp1 = SlabPoisson(nsd, sizes, lengths, r, world, ngp_1d=2, device=dev())
+        one, none, _ = sp1._plans(ul, nul, fl, cond, 0.7, 1.0, scale)
+        assert none is None and sp1.overlap == "auto"
+        g1, _, l1 = one.launch()
+        assert torch.equal(g1, grad)
+        np.testing.assert_allclose(float(l1), float(loss), rtol=1e-6)
         with pytest.raises(Exception, match="contiguous"):
             sp._plans(ul[..., ::2], nul, fl, cond, 0.7, 1.0, scale)
     np.testing.assert_allclose(total, float(lref), rtol=2e-6)
