@@ -105,14 +105,48 @@ __global__ void __launch_bounds__(256) upconv3d_fwd_kernel(const float* __restri
         }
 }
 
-__device__ __forceinline__ float gz3_at(const float* __restrict__ g, const float* __restrict__ y, int Z, int Y, int X, int D, int H, int W,
-                                        int act) {
-    if (Z < 0 || Z >= D || Y < 0 || Y >= H || X < 0 || X >= W) return 0.f;
-    const size_t o = ((size_t)Z * H + Y) * W + X;
-    const float gv = g[o];
-    if (!act) return gv;
-    const float yv = y[o];
-    return gv * yv * (1.f - yv);
+// gz = gout * y (1 - y) (sigmoid) or gout over the 4 x 4 x 4 patch around the high-resolution voxel (2 i - 1, 2 j - 1, 2 k - 1), zero outside
+// the volume.  Round 4: branch-free (see gz_patch in upconv_out.hip: a bounds branch and an `act` branch around each of the 64 loads made
+// every load wait for the one before it) -- loads of clamped addresses, an opaque bit mask afterwards, ONE uniform branch for the sigmoid factor.
+__device__ __forceinline__ void gz3_patch(const float* __restrict__ g, const float* __restrict__ y, int i, int j, int k, int D, int H, int W, int act,
+                                          bool live, float (&G)[64]) {
+    unsigned zoff[4], yoff[4], xoff[4];
+    bool zok[4], yok[4], xok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int Z = 2 * i - 1 + t, Y = 2 * j - 1 + t, X = 2 * k - 1 + t;
+        zok[t] = Z >= 0 && Z < D; yok[t] = Y >= 0 && Y < H; xok[t] = X >= 0 && X < W;
+        zoff[t] = (unsigned)min(max(Z, 0), D - 1) * (unsigned)(H * W);
+        yoff[t] = (unsigned)min(max(Y, 0), H - 1) * (unsigned)W;
+        xoff[t] = (unsigned)min(max(X, 0), W - 1);
+    }
+#pragma unroll
+    for (int dz = 0; dz < 4; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) G[dz * 16 + dy * 4 + dx] = g[zoff[dz] + yoff[dy] + xoff[dx]];
+    if (act) {
+#pragma unroll
+        for (int dz = 0; dz < 4; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    const float yv = y[zoff[dz] + yoff[dy] + xoff[dx]];
+                    G[dz * 16 + dy * 4 + dx] *= yv * (1.f - yv);
+                }
+    }
+#pragma unroll
+    for (int dz = 0; dz < 4; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                unsigned m = (live && zok[dz] && yok[dy] && xok[dx]) ? 0xffffffffu : 0u;
+                asm volatile("" : "+v"(m));               // opaque: no branch around the load
+                G[dz * 16 + dy * 4 + dx] = __uint_as_float(__float_as_uint(G[dz * 16 + dy * 4 + dx]) & m);
+            }
 }
 
 // grad wrt the low-resolution input: 4 x 4 x 4 gradient patch in registers, loop over channels.
@@ -126,12 +160,7 @@ __global__ void __launch_bounds__(256) upconv3d_bwd_data_kernel(const float* __r
     const float* gb = gout + (size_t)b * D2 * H2 * W2;
     const float* yb = y ? y + (size_t)b * D2 * H2 * W2 : nullptr;
     float G[64];
-#pragma unroll
-    for (int dz = 0; dz < 4; ++dz)
-#pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) G[dz * 16 + dy * 4 + dx] = gz3_at(gb, yb, 2 * i - 1 + dz, 2 * j - 1 + dy, 2 * k - 1 + dx, D2, H2, W2, act);
+    gz3_patch(gb, yb, i, j, k, D2, H2, W2, act, true, G);
     const size_t vol = (size_t)d * h * w;
     float* ob = gin + (size_t)b * C * vol + ((size_t)i * h + j) * w + k;
     for (int c = 0; c < C; ++c) {
@@ -183,15 +212,9 @@ __global__ void __launch_bounds__(256) upconv3d_bwd_weight_kernel(const float* _
             __syncthreads();
             if (half == 0) {
                 const float* gb = gout + (size_t)b * D2 * H2 * W2;
-                const float* yb = y ? y + (size_t)b * D2 * H2 * W2 : nullptr;
+                const float* yb = y ? y + (size_t)b * D2 * H2 * W2 : gb;
                 float G[64];
-#pragma unroll
-                for (int dz = 0; dz < 4; ++dz)
-#pragma unroll
-                    for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 4; ++dx)
-                            G[dz * 16 + dy * 4 + dx] = ok ? gz3_at(gb, yb, 2 * i - 1 + dz, 2 * j - 1 + dy, 2 * k - 1 + dx, D2, H2, W2, act) : 0.f;
+                gz3_patch(gb, yb, i, j, k, D2, H2, W2, act, ok, G);
                 // pair sums along x, then y, then z: X[dz][dy][q] = G[..][q] + G[..][q+1], q = 0..2, and so on
                 float Xs[4][4][3];
 #pragma unroll
@@ -220,7 +243,11 @@ __global__ void __launch_bounds__(256) upconv3d_bwd_weight_kernel(const float* _
             }
             const float* ib = in + (size_t)b * C * vol + ((size_t)i * h + j) * w + k;
 #pragma unroll 8
-            for (int c = half; c < U3_CCH; c += 2) V[c][pp] = (ok && c0 + c < C) ? ib[(size_t)(c0 + c) * vol] : 0.f;
+            for (int c = half; c < U3_CCH; c += 2) {      // (unconditional loads of clamped channels + opaque mask: see gz3_patch)
+                unsigned mk = (ok && c0 + c < C) ? 0xffffffffu : 0u;
+                asm volatile("" : "+v"(mk));
+                V[c][pp] = __uint_as_float(__float_as_uint(ib[(size_t)min(c0 + c, C - 1) * vol]) & mk);
+            }
             __syncthreads();
 #pragma unroll 8
             for (int q0 = 0; q0 < U3_TP; q0 += 4)

@@ -274,6 +274,59 @@ def _mask_image(m, like):
     return m
 
 
+# ---- mask images packed on first use (round 4) ------------------------------------------------------------------------------------
+# The reference keeps Dirichlet masks as fp32 images and hands them to loss() every step (IBN_2D.py:69-73, 119-121); read as they are they
+# cost the fused 2-D kernel 4 B per node and launch (72 against 54-56 us at 512^2 x 64), as uint8 images 1 B.  A one-shot call
+# (energy_loss / energy_loss_and_grad / residual*) therefore packs a mask image to one bit per node the FIRST time it sees it and finds the
+# bits again on later calls: the cache is keyed on the mask's storage (address, offset, shape, strides, dtype) AND its version counter -- an
+# in-place write to the mask (or to any view of its storage) changes the version and the image is packed again -- and an entry holds the
+# mask tensor itself, so that the address cannot be handed to another tensor while the entry lives.  Small LRU; `AUTO_PACK_MASKS = False`
+# turns it off.  Prepared launches (PoissonPlan) take what they are given: pack explicitly with PackedMask.pack there.
+AUTO_PACK_MASKS = True
+_PACK_CACHE = __import__("collections").OrderedDict()
+_PACK_CACHE_MAX = 8
+_PACK_STATS = {"hit": 0, "pack": 0}
+
+
+def _packed_on_first_use(m):
+    key = (m.untyped_storage().data_ptr(), m.storage_offset(), tuple(m.shape), tuple(m.stride()), m.dtype)
+    with _WS_LOCK:
+        ent = _PACK_CACHE.get(key)
+        if ent is not None and ent[1] == m._version:
+            _PACK_CACHE.move_to_end(key)
+            _PACK_STATS["hit"] += 1
+            return ent[2]
+    pm = PackedMask.pack(m)
+    _PACK_STATS["pack"] += 1
+    with _WS_LOCK:
+        _PACK_CACHE[key] = (m, m._version, pm)
+        _PACK_CACHE.move_to_end(key)
+        while len(_PACK_CACHE) > _PACK_CACHE_MAX:
+            _PACK_CACHE.popitem(last=False)
+    return pm
+
+
+def _auto_pack(geom, u, f_gp, dl):
+    """The conditions of a one-shot 2-D Q1 call with their mask IMAGES replaced by (cached) bit-packed masks, where the compact kernels
+    take the whole call: every condition a constant value on a PackedMask / BoxFaces / contiguous float32, uint8 or bool CUDA image."""
+    if not (AUTO_PACK_MASKS and geom.nsd == 2 and geom.deg == 1 and f_gp is None and len(dl) > 0 and isinstance(u, torch.Tensor) and u.is_cuda):
+        return dl
+    if _lib.CONFIG_MIRROR.get("Q1_RULE_KERNEL"):
+        return dl
+    want = (1, *geom.node_shape)
+    for d in dl:
+        m = d.mask
+        if isinstance(d.value, torch.Tensor):
+            return dl
+        if isinstance(m, (PackedMask, BoxFaces)):
+            continue
+        if not (isinstance(m, torch.Tensor) and m.is_cuda and m.device == u.device and m.is_contiguous() and not m.requires_grad and
+                m.dtype in (torch.float32, torch.uint8, torch.bool) and m.dim() == u.dim() and tuple(m.shape[1:]) == want and
+                m.shape[0] in (1, u.shape[0])):
+            return dl
+    return [d if isinstance(d.mask, (PackedMask, BoxFaces)) else Dirichlet(_packed_on_first_use(d.mask), d.value) for d in dl]
+
+
 def _norm_dirichlet(dirichlet):
     out = []
     for d in dirichlet or ():
@@ -384,7 +437,7 @@ def poisson_apply(geom, u, nu=None, f=None, f_gp=None, dirichlet=(), alpha=1.0, 
     """One launch of dn_poisson_apply.  Returns (out | None, sums | None) where sums is a float64 device
     tensor [energy, sum(out_unscaled^2)].  With `loss_scale` a third value is returned: the 0-dim float32 tensor
     energy * loss_scale written by the same launch.  See include/diffnet_hip.h for the operator definition."""
-    dl = _norm_dirichlet(dirichlet)
+    dl = _auto_pack(geom, u, f_gp, _norm_dirichlet(dirichlet))
     key = None
     if isinstance(u, torch.Tensor) and u.is_cuda:
         key = _call_key(geom, u, nu, f, f_gp, dl, (float(alpha), float(beta), float(c), float(wscale), float(out_scale),
@@ -443,6 +496,7 @@ def call_cache_clear():
     with _WS_LOCK:
         _CALL_CACHE.clear()
         _FSDT_CACHE.clear()
+        _PACK_CACHE.clear()
     _POISSON_WS_BYTES.clear()
     _FSDT_WS_BYTES.clear()
 

@@ -400,3 +400,44 @@ def test_box_faces_in_the_3d_two_element_kernel_equal_mask_images_bitwise(kw, B)
     a = m.energy_loss_and_grad(u, nu, lv, dirichlet=[(box, 0.0)], c=1.0)
     b = m.energy_loss_and_grad(u, nu, lv, dirichlet=[(BoxFaces("all"), 0.0)], c=1.0)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_mask_images_are_packed_on_first_use_and_repacked_after_an_in_place_write():
+    """One-shot 2-D Q1 calls pack fp32 / uint8 mask IMAGES (the reference's format: IBN_2D.py:69-73, 119-121) to one bit per node the first time
+    they see them (ops._packed_on_first_use): later calls find the bits (keyed on storage, layout and the tensor's version counter), an
+    in-place write to the mask is seen (new version -> packed again -> new result), a view of the same storage shares the entry's version
+    logic, and the numbers equal the image path's (AUTO_PACK_MASKS = False) to rounding."""
+    from diffnet_amd import ops
+    m = module(dict(domain_size=128, ngp_1d=3))
+    shape = (3, 1, 128, 128)
+    u, nu, f = seeded(shape, 301).to(dev()), seeded(shape, 302, 0.5).to(dev()), seeded(shape, 303).to(dev())
+    box = boundary_mask(shape).to(dev())                       # fp32 image, as the reference keeps it
+    src = (_blob(shape, 304, 0.05).to(dev()) * (1 - box)).contiguous()
+    ops.call_cache_clear()
+    ops._PACK_STATS.update(hit=0, pack=0)
+    cond = [(src, 1.0), (box, 0.0)]
+    v1, g1 = m.energy_loss_and_grad(u, nu, f, dirichlet=cond, c=1.0)
+    assert ops._PACK_STATS == {"hit": 0, "pack": 2}
+    v2, g2 = m.energy_loss_and_grad(u, nu, f, dirichlet=cond, c=1.0)
+    assert ops._PACK_STATS == {"hit": 2, "pack": 2} and torch.equal(g1, g2) and torch.equal(v1, v2)
+    ops.AUTO_PACK_MASKS = False
+    try:
+        v0, g0 = m.energy_loss_and_grad(u, nu, f, dirichlet=cond, c=1.0)
+    finally:
+        ops.AUTO_PACK_MASKS = True
+    np.testing.assert_allclose(float(v1), float(v0), rtol=2e-6)
+    close(g1, g0.cpu().numpy(), rtol=2e-6, arel=2e-6)
+    # an in-place write (through a view of the same storage) bumps the version: the next call packs again and sees the new mask
+    src[0, 0, 40:60, 40:60] = 1.0
+    v3, g3 = m.energy_loss_and_grad(u, nu, f, dirichlet=cond, c=1.0)
+    assert ops._PACK_STATS["pack"] == 3 and float(g3[0, 0, 50, 50]) == 0.0 and float(g1[0, 0, 50, 50]) != 0.0
+    ops.AUTO_PACK_MASKS = False
+    try:
+        v4, g4 = m.energy_loss_and_grad(u, nu, f, dirichlet=cond, c=1.0)
+    finally:
+        ops.AUTO_PACK_MASKS = True
+    np.testing.assert_allclose(float(v3), float(v4), rtol=2e-6)
+    close(g3, g4.cpu().numpy(), rtol=2e-6, arel=2e-6)
+    # value fields, f_gp or a non-contiguous image leave the call on the image path
+    v5, _ = m.energy_loss_and_grad(u, nu, f, dirichlet=[(box, torch.zeros_like(u))], c=1.0)
+    assert ops._PACK_STATS["pack"] == 3
