@@ -1418,7 +1418,11 @@ int DN_CAT(launch_poisson3d_q1_g, DN_NGP)(const PoissonParams& pp, const Geom3D&
     if (pp.f && pp.f_is_load && !(DN_NGP == 2 && g.E == 2 && g.TX == 16 && g.TY == 16)) return DN_E_UNSUPPORTED;      // load vectors: two-element node-owner form only
     if (g.E == 1) { launch3_flags<DN_NGP, 1, false>(pp, g, batch, s); return 0; }
 #if DN_NGP == 2
-    if (g.E == 2 && g.TX == 16 && g.TY == 16) return launch3_n2(pp, g, batch, s);       // node-owner form, two elements per thread (dn_poisson_apply checked its preconditions)
+    if (g.E == 2 && g.TX == 16 && g.TY == 16) {
+        // round 4: the closed-form-in-z kernel (poisson3d_q1_cf.hip) wherever the launch has a stiffness part; dn_config_set("Q1_3D_N2") keeps the round-3 kernel
+        if (poisson3d_q1_cf_ok(pp) && (!pp.want_sums || pp.T.alpha != 0.f)) return launch_poisson3d_q1_cf(pp, g, batch, s);
+        return launch3_n2(pp, g, batch, s);
+    }       // node-owner form, two elements per thread (dn_poisson_apply checked its preconditions)
 #endif
     return DN_E_UNSUPPORTED;
 }

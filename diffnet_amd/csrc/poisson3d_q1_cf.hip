@@ -1,0 +1,629 @@
+// 3-D Q1 fused Poisson kernel, CLOSED FORM ALONG THE MARCHED AXIS (round 4).  Default for the exact 2-point rule on
+// meshes with an even number of nodes per row, nodal / absent / pre-assembled forcing and constant-value Dirichlet conditions held as
+// uint8 or fp32 images or as faces of the domain box -- configs[2] and configs[3] of BASELINE.json and the slab decomposition.
+//
+// What it evaluates, per sample:   out_a = wscale ( alpha sum_e sum_g nu_g gradN_a . grad u_g  -  beta sum_e sum_g N_a f_g ),   rows of fixed
+// nodes zeroed, the two energy sums and sum out^2 -- the loss bodies IBN_3D.py:114-136 and solve_in_object_3d.py:75-102 (5-6 x 8 single-channel
+// Conv3d + cat + elementwise + backward in the reference, DiffNetFEM.py:7-18) in one pass over the nodal fields.
+//
+// The memory side is the node-owner form of poisson3d_q1n2_kernel (poisson3d_q1.inl): a 16 x 16 workgroup marches a tile of 32 x 16 elements
+// over R element layers; a thread owns two nodes of a node row (one 8-byte load per field and plane, one 8-byte store) and the two elements to
+// their right; every node is requested once per workgroup and plane and published as a 16-byte record {u', nu', f', keep} in LDS, one LDS-only
+// barrier per layer, contributions to nodes of neighbouring threads handed over through ds_bpermute (x) and an LDS slot (y).  The
+// ARITHMETIC is new.  The round-3 kernel was bound by its instruction count (~260 VALU instructions per thread and layer on packed fp32,
+// VALU busy 73 % of the launch, profiles/r3_stamp3d_n2.txt); this form needs ~150:
+//   * in-plane stages in MONOMIAL form: with u(x, y) = u00 + dx0 x + dy0 y + xy x y on an element face, the x-derivative at the y-Gauss points,
+//     the y-derivative at the x-Gauss points and the value at the four in-plane points cost 14 instructions, their adjoint 22 (was 15 + 33);
+//   * the x- and y-flux terms are integrated along z IN CLOSED FORM: for nu and du/dx both linear in z the sum over the two z-Gauss points of
+//     (1 - t) nu u_x and t nu u_x is tau [ (A + B)(a + b) + kappa A a ] and tau [ (A + B)(a + b) + kappa B b ]  (A, B / a, b: the values on the
+//     lower / upper plane, tau = sum_k t_k^2 (1 - t_k), kappa = sum_k t_k^3 / tau - 1 -- moments of the reference's own rule, exact, no new
+//     quadrature); the plane-local products A a are shared by the two layers of a plane: 6 instructions per term instead of 15;
+//   * the forcing term is the mass matrix M_x (x) M_y (x) M_z applied to the nodal f (f trilinear per element, rule exact): the node owner
+//     applies the 3-point stencil of M_z to the plane it publishes (f is requested one plane ahead), the elements stage that plane like nu
+//     (12 instructions) and add it to the cotangent of the staged u (4) -- and sum_g f_g u_g is the sum over the in-plane points of the same
+//     products (5);
+//   * the stiffness part of the energy comes from the finished nodal values (sum_a u_a out_a), as in round 3.
+// Results differ from the per-Gauss-point kernels by fp32 rounding only (tools/q1cf3d_proto.py: the same formulas in float64 against the CPU
+// oracle; tests/test_gpu_q1cf3d.py: this kernel against the oracle and against the round-3 kernels).
+#include <cmath>
+
+#include "poisson_common.h"
+
+namespace dn {
+
+enum : int { CF3_NU = 1, CF3_F = 2, CF3_LOAD = 4, CF3_IMG = 8, CF3_ONE = 16, CF3_F32 = 32, CF3_BOX = 64 };
+// CF3_LOAD (with CF3_F): `f` holds the assembled load vector (dn_poisson_args.f_is_load); CF3_IMG: mask images, uint8 or (CF3_F32) fp32, two or
+// (CF3_ONE) one of them; CF3_BOX: at least one condition is given as faces of the domain box
+
+struct Cf3Consts {
+    float t0, t1;                      // lerp weights of the two Gauss points
+    float snu;                         // scale of the nu records: kap_x * tau
+    float ry, rz;                      // kap_y / kap_x, kap_z / (kap_x tau)
+    float rzt0, rzt1, ryt0, ryt1;      // rz t_k, ry t_k
+    float kappa, kappa2;               // sigma / tau - 1 and twice that
+    float nbz;                         // -beta wscale / rz: forcing into the cotangent of the staged u
+    float nbw;                         // -beta wscale
+    float c00, c01, c11;               // 1-D element mass matrix of the rule
+    float czd[4];                      // middle coefficient of the z mass stencil: interior plane, bottom plane, top plane, both (a mesh of one layer)
+    float inv_esc, beta, inv_alpha;
+};
+
+#ifndef DN_Q1CF_WAVES
+#define DN_Q1CF_WAVES 3               // waves per SIMD asked of the compiler (<= 168 VGPRs)
+#endif
+
+#if defined(DN_STAMP3D)
+// Diagnostic build only (tools/stamp3d.py): per-wave cycle budget of the loop, accumulated in scalar registers with s_memtime and written once
+// at the end of the kernel by wave 0 of every workgroup.  Phases per layer: A = request the next plane + deferred store, B = gather the upper
+// plane from LDS + stage it, C = layer arithmetic + adjoint, D = hand-over + publish + barrier, E = hand-over read + finish the node values.
+__device__ unsigned long long dn_stamp_buf[8192 * 8];
+extern "C" int dn_debug_stamps(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dn_stamp_buf), bytes); }
+#define DN_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); var += t__ - stamp_last; stamp_last = t__; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DN_STAMP(var) do { } while (0)
+#endif
+
+// lane l <- lane l - 1 of the wave, 0 for the first lane of a row of 16.  ds_bpermute, not DPP: on gfx950 a DPP move costs a shared SIMD ~33
+// cycles, a ds_bpermute ~3 (tools/micro/valu_mem.hip, profiles/r2_valu_mem.txt).
+__device__ __forceinline__ float cf3_from_left(float v, int from, float nf) {
+    return nf * __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(from, __builtin_bit_cast(int, v)));
+}
+
+// wave-uniform float select on the scalar unit: (a < b) ? x : y for wave-uniform integers a, b.  Inline asm: written in C++ (with floats or with
+// their bit patterns) the compiler moves both values into vector registers, selects there and reads the result back (4 VALU instructions)
+__device__ __forceinline__ float cf3_usel_lt(int a, int b, float x, float y) {
+    int r;
+    asm("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, %3, %4"
+        : "=s"(r)
+        : "s"(__builtin_amdgcn_readfirstlane(a)), "s"(__builtin_amdgcn_readfirstlane(b)), "s"(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))),
+          "s"(__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y)))
+        : "scc");
+    return __builtin_bit_cast(float, r);
+}
+
+template <int FL>
+__global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(const PoissonParams p, const Cf3Consts k, const int chunks_x, const int tiles_y, const int strips_z) {
+    constexpr bool HAS_NU = (FL & CF3_NU) != 0, F_ARR = (FL & CF3_F) != 0, LOADV = F_ARR && (FL & CF3_LOAD) != 0, HAS_F = F_ARR && !LOADV;
+    constexpr bool IMG = (FL & CF3_IMG) != 0, BOX = (FL & CF3_BOX) != 0;
+    constexpr int NMASK = !IMG ? 0 : ((FL & CF3_ONE) ? 1 : 2);
+    constexpr bool MASK_F32 = (FL & CF3_F32) != 0;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int tid = ty * 16 + tx;
+    // 1-D grid with an XCD-aware decode: workgroups are dealt round-robin to the 8 XCDs, each with its own L2; every XCD gets a contiguous range of
+    // the logical order (chunk fastest, then tile, strip, sample), so a tile's halo is read from HBM once instead of once per XCD
+    unsigned lid = blockIdx.x;
+    {
+        const unsigned nwg = gridDim.x, xcd = lid & 7u, idx = lid >> 3, base = nwg >> 3, rem = nwg & 7u;
+        lid = xcd * base + min(xcd, rem) + idx;
+    }
+    const int chunk = (int)(lid % (unsigned)chunks_x);
+    lid /= (unsigned)chunks_x;
+    const int tile = (int)(lid % (unsigned)tiles_y);
+    lid /= (unsigned)tiles_y;
+    const int strip = selected_strip(p, (int)(lid % (unsigned)strips_z)), b = (int)(lid / (unsigned)strips_z);
+    const int nx0 = chunk * 30, ny0 = tile * 15;               // first node of the tile (chunks overlap by one thread column = two elements)
+    const int x0 = nx0 + 2 * tx, ey = ny0 + ty;                // the thread's first node == lower-left node of its first element
+    const bool owner = !(chunk > 0 && tx == 0) && !(tile > 0 && ty == 0);
+    const unsigned npl = (unsigned)(p.nx * p.ny);
+    const int64_t nps = (int64_t)npl * p.nz;
+    const SampleBases sb = sample_bases(p, b, nps);
+    const int R = p.rows_per_strip;
+    const int ez_own = strip * R;
+    const int ez_begin = ez_own > 0 ? ez_own - 1 : 0;
+    const int ez_end = min(ez_own + R, p.nelz);
+    const bool noderow_ok = ey < p.ny;
+    // elements beyond the mesh (ragged last chunk / tile) are computed on clamped, finite node values and their results multiplied by 0
+    const v2f zero2 = {0.f, 0.f};
+
+    const v2f okv = {(ey < p.nely && x0 < p.nelx) ? 1.f : 0.f, (ey < p.nely && x0 + 1 < p.nelx) ? 1.f : 0.f};
+    const v2f okown = owner ? okv : zero2;         // elements this workgroup counts in the element sums
+#if defined(DN_STAMP3D)
+    unsigned long long stamp_A = 0, stamp_B = 0, stamp_C = 0, stamp_D = 0, stamp_E = 0, stamp_n = 0, stamp_last = 0;
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // the node planes in LDS, one array per field (structure of arrays): [plane parity][node row][node column], rows of 33 nodes padded to 36
+    // floats.  A thread reads the node pairs (x0, x0 + 1) and (x0 + 1, x0 + 2) of its two node rows as ds_read_b64 / ds_read2_b32: the values land in
+    // the register pairs the packed instructions take (the 16-byte records of round 3 cost 24 v_mov per layer to form those pairs).
+    constexpr int LP = 36;
+    __shared__ float Lu[2][17][LP];               // u after the Dirichlet conditions
+    __shared__ float Ln[2][17][LP];               // nu * snu
+    __shared__ float Lf[2][17][LP];               // f' (z mass stencil applied) or the load vector
+    __shared__ float2 Lk[2][16][16];              // keep (0 on fixed nodes) of the own node pairs
+    __shared__ float2 xch[2][256];
+    __shared__ double red[2 * (256 / 64)];
+    __shared__ int last_flag;
+    if (blockIdx.x == 0u) fold_prev_sums(p, tid, 256, red);       // dn_poisson_args.fold_prev: close the evaluation before this one
+
+    // own pair (clamped into the mesh: nx is even, so a pair is inside or outside as a whole) and the halo node this thread fetches
+    const unsigned own_off = (unsigned)min(ey, p.ny - 1) * (unsigned)p.nx + (unsigned)min(x0, p.nx - 2);
+    const int lane = tid & 63, wave = tid >> 6;
+    // 49 halo nodes (node row 16: 33 nodes, node column 32: 16 nodes), 13 per wave, ONE load instruction for their u, nu and f: lanes 0..12 fetch
+    // u, 13..25 nu, 26..38 f of the wave's 13 nodes through per-lane 64-bit addresses; the other lanes repeat lane 38
+    const int hgrp = min(lane / 13, 2), hsub = min(lane - 13 * hgrp, 12);
+    const int hidx = min(wave * 13 + hsub, 48);
+    const int hrow = hidx < 33 ? 16 : hidx - 33, hcol = hidx < 33 ? hidx : 32;
+    const unsigned halo_off = (unsigned)min(ny0 + hrow, p.ny - 1) * (unsigned)p.nx + (unsigned)min(nx0 + hcol, p.nx - 1);
+    const bool halo_lane = lane < 39 && wave * 13 + hsub < 49 && (hgrp == 0 || (hgrp == 1 ? HAS_NU : HAS_F));       // (a load vector is needed at owned nodes only)
+    float* const halo_rec0 = (hgrp == 0 ? &Lu[0][0][0] : (hgrp == 1 ? &Ln[0][0][0] : &Lf[0][0][0])) + hrow * LP + hcol;              // the lane's field array
+    constexpr unsigned halo_par_stride = 17u * LP;                                                                                      // floats
+    const float* const halo_src = (hgrp == 1 && HAS_NU) ? sb.nu : ((hgrp == 2 && HAS_F) ? sb.f : sb.u);                               // per lane
+    const bool halo_is_f = HAS_F && hgrp == 2;
+    const unsigned halo_fmask = halo_is_f ? 0xffffffffu : 0u;
+    const float halo_mul = (HAS_NU && hgrp == 1) ? k.snu : 1.f;
+
+    const bool has_mask[2] = {sb.mask[0] != nullptr, sb.mask[1] != nullptr};
+    const uint8_t* mask8[2];
+    mask8[0] = reinterpret_cast<const uint8_t*>(has_mask[0] ? sb.mask[0] : sb.mask[1]);      // an absent condition re-reads the other one and is
+    mask8[1] = reinterpret_cast<const uint8_t*>(has_mask[1] ? sb.mask[1] : sb.mask[0]);      // ignored: no load inside a wave-uniform branch
+    const float* mask32[2] = {reinterpret_cast<const float*>(mask8[0]), reinterpret_cast<const float*>(mask8[1])};
+    // BOX: per condition the faces of the domain box it fixes (0: not a box condition); in-plane part per node, constant over the march
+    const int bfaces[2] = {BOX && p.bc[0].kind == DN_MASK_BOX ? p.bc[0].box_faces : 0, BOX && p.bc[1].kind == DN_MASK_BOX ? p.bc[1].box_faces : 0};
+    auto box_xy = [&](int kk, int x, int y) {
+        return ((bfaces[kk] & DN_FACE_XLO) && x == 0) || ((bfaces[kk] & DN_FACE_XHI) && x == p.nx - 1) || ((bfaces[kk] & DN_FACE_YLO) && y == 0) ||
+               ((bfaces[kk] & DN_FACE_YHI) && y == p.ny - 1);
+    };
+    const bool bxy0[2] = {box_xy(0, x0, ey), box_xy(1, x0, ey)}, bxy1[2] = {box_xy(0, x0 + 1, ey), box_xy(1, x0 + 1, ey)};
+    const bool bxyh[2] = {box_xy(0, nx0 + hcol, ny0 + hrow), box_xy(1, nx0 + hcol, ny0 + hrow)};
+
+    struct RawNodes {
+        v2f u, n, f;                  // own pair (f: one plane AHEAD of u and nu when it is nodal forcing)
+        float h;                      // halo node: u, nu or f by lane group
+        uint16_t m[2];                // uint8 masks of the own pair (two bytes), per condition
+        v2f mf[2];                    // fp32 masks of the own pair
+        uint8_t hm[2];
+        float hmf[2];
+    };
+    auto ld_pair = [&](const float* base, unsigned off) {
+        const float2 t = ld_at<float2>(base, off);
+        return v2f{t.x, t.y};
+    };
+    // z-offsets (nodes) of plane z and, for nodal forcing, of the plane after it -- clamped into the mesh
+    auto plane_request = [&](int zreq, RawNodes& W) {
+        const unsigned zoff = (unsigned)min(zreq, p.nz - 1) * npl;
+        const unsigned zoff_f = HAS_F ? (unsigned)min(zreq + 1, p.nz - 1) * npl : zoff;
+        const unsigned oo = zoff + own_off, oh = zoff + halo_off + (halo_fmask & (zoff_f - zoff));
+        W.u = ld_pair(sb.u, oo);
+        if constexpr (HAS_NU) W.n = ld_pair(sb.nu, oo);
+        if constexpr (F_ARR) W.f = ld_pair(sb.f, zoff_f + own_off);
+        W.h = halo_src[oh];
+        if constexpr (IMG) {
+            const unsigned ohm = zoff + halo_off;
+#pragma unroll
+            for (int kk = 0; kk < NMASK; ++kk) {
+                if constexpr (MASK_F32) { W.mf[kk] = ld_pair(mask32[kk], oo); W.hmf[kk] = ld_at<float>(mask32[kk], ohm); }
+                else { W.m[kk] = ld_at<uint16_t>(mask8[kk], oo); W.hm[kk] = ld_at<uint8_t>(mask8[kk], ohm); }
+            }
+        }
+    };
+    // Dirichlet conditions of one node: set[k]: the node is fixed by condition k (its mask image and / or its box faces).  Applied in their order
+    // (the reference's torch.where lines, IBN_3D.py:119-122): uu <- value, keep <- 0
+    const float bcv1 = has_mask[0] ? p.bc[0].value : p.bc[1].value;      // NMASK == 1, no box faces: the value of the one condition
+    auto fix_node = [&](float& uu, float& keep, const bool (&img)[2], const bool (&box)[2]) {
+        keep = 1.f;
+        if constexpr (NMASK == 1 && !BOX) {
+            uu = img[0] ? bcv1 : uu;
+            keep = img[0] ? 0.f : 1.f;
+        } else if constexpr (IMG || BOX) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bool sset = false;
+                if constexpr (NMASK == 2) sset = has_mask[kk] && img[kk];
+                if constexpr (NMASK == 1) sset = has_mask[kk] && img[0];
+                if constexpr (BOX) sset = sset || box[kk];
+                uu = sset ? p.bc[kk].value : uu;
+                keep = sset ? 0.f : keep;
+            }
+        }
+    };
+    // nodal forcing: the owner keeps the two planes before the one in W (own pair, and its halo node in the f lanes) and publishes
+    //     f'(m) = czl f(m - 1) + czd f(m) + czu f(m + 1),      the 3-point stencil of the rule's 1-D mass matrix along z (boundary planes: one side)
+    v2f fh0 = 0.f, fh1 = 0.f;
+    float hh0 = 0.f, hh1 = 0.f;
+    auto plane_publish = [&](const RawNodes& W, int zpl) {
+        bool s0[2] = {false, false}, s1[2] = {false, false}, sh[2] = {false, false};
+        if constexpr (IMG) {
+#pragma unroll
+            for (int kk = 0; kk < NMASK; ++kk) {
+                if constexpr (MASK_F32) { s0[kk] = W.mf[kk].x > 0.5f; s1[kk] = W.mf[kk].y > 0.5f; sh[kk] = W.hmf[kk] > 0.5f; }
+                else { s0[kk] = (W.m[kk] & 0xffu) != 0; s1[kk] = (W.m[kk] >> 8) != 0; sh[kk] = W.hm[kk] != 0; }
+            }
+        }
+        const int par = zpl & 1;
+        bool b0[2] = {false, false}, b1[2] = {false, false}, bh[2] = {false, false};
+        const int zc = min(zpl, p.nz - 1);
+        if constexpr (BOX) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bool zf = ((bfaces[kk] & DN_FACE_ZLO) && zc == 0) || ((bfaces[kk] & DN_FACE_ZHI) && zc == p.nz - 1);
+                b0[kk] = bxy0[kk] || zf; b1[kk] = bxy1[kk] || zf; bh[kk] = bxyh[kk] || zf;
+            }
+        }
+        v2f fz = 0.f;
+        float hv = W.h * halo_mul;
+        if constexpr (HAS_F) {
+            // c01 (f(m-1) + f(m+1)) + czd f(m), czd by the plane's position (Cf3Consts::czd; wave-uniform)
+            const float czd = cf3_usel_lt(0, zc, cf3_usel_lt(zc, p.nz - 1, k.czd[0], k.czd[2]), cf3_usel_lt(zc, p.nz - 1, k.czd[1], k.czd[3]));
+            fz = vfma(czd, fh1, k.c01 * (fh0 + W.f));
+            fh0 = fh1; fh1 = W.f;
+            const float hz = fmaf(czd, hh1, k.c01 * (hh0 + W.h));
+            hh0 = hh1; hh1 = W.h;
+            hv = halo_is_f ? hz : hv;
+        } else if constexpr (LOADV) {
+            fz = W.f;
+        }
+        float u0 = W.u.x, u1 = W.u.y, k0, k1;
+        fix_node(u0, k0, s0, b0);
+        fix_node(u1, k1, s1, b1);
+        *reinterpret_cast<float2*>(&Lu[par][ty][2 * tx]) = make_float2(u0, u1);
+        if constexpr (HAS_NU) {
+            const v2f nr = k.snu * W.n;
+            *reinterpret_cast<float2*>(&Ln[par][ty][2 * tx]) = make_float2(nr.x, nr.y);
+        }
+        if constexpr (F_ARR) *reinterpret_cast<float2*>(&Lf[par][ty][2 * tx]) = make_float2(fz.x, fz.y);
+        if constexpr (IMG || BOX) Lk[par][ty][tx] = make_float2(k0, k1);
+        if (halo_lane) {
+            if constexpr (IMG || BOX) {
+                float kh;
+                float hu = hv;
+                fix_node(hu, kh, sh, bh);
+                hv = hgrp == 0 ? hu : hv;
+            }
+            halo_rec0[par * halo_par_stride] = hv;
+        }
+    };
+
+    // From here on a value of type v2f holds the same quantity of the thread's two elements (.x: element at node column x0, .y: at x0 + 1) or of its
+    // two nodes: the element arithmetic runs on packed fp32 instructions, one per pair.
+    // In-plane stage of one node plane, per element (t = lerp coordinate on the element face, Gauss points t0, t1):
+    //   BX[j] = du/dx at y = t_j (constant in x),  CY[i] = du/dy at x = t_i,  U[j][i] = u(t_i, t_j),  V[j][i] = nu'(t_i, t_j)
+    struct PlaneC { v2f BX[2], CY[2], U[2][2], V[2][2]; };
+    auto stage_vals = [&](const v2f v00, const v2f v10, const v2f v01, const v2f v11, v2f (&G)[2][2]) {
+        const v2f dx0 = v10 - v00, dx1 = v11 - v01, dy0 = v01 - v00, xy = dx1 - dx0;
+        const v2f A0 = vfma(k.t0, dy0, v00), A1 = vfma(k.t1, dy0, v00), B0 = vfma(k.t0, xy, dx0), B1 = vfma(k.t1, xy, dx0);
+        G[0][0] = vfma(k.t0, B0, A0); G[0][1] = vfma(k.t1, B0, A0);
+        G[1][0] = vfma(k.t0, B1, A1); G[1][1] = vfma(k.t1, B1, A1);
+    };
+    auto plane_gather = [&](int zpl, PlaneC& S, v2f (&F)[2][2]) {
+        const int par = zpl & 1;
+        // the four node pairs of the thread's two elements in one field plane: (x0, x0 + 1), (x0 + 1, x0 + 2) of node rows ty and ty + 1.  Inline asm:
+        // written in C++ the compiler takes x0 + 1 from the first pair and forms the second with v_mov (12 per layer); ds_read2_b32 delivers it as a
+        // register pair.  The reads of a plane are waited for together (cf3_lds_wait) -- the compiler does not count asm LDS accesses.
+        auto pairs = [&](const float (&A)[2][17][LP], v2f& v00, v2f& v10, v2f& v01, v2f& v11) {
+            const unsigned a = (unsigned)(uintptr_t)&A[par][ty][2 * tx];
+            asm volatile("ds_read_b64 %0, %4\n\tds_read2_b32 %1, %4 offset0:1 offset1:2\n\tds_read_b64 %2, %4 offset:%5\n\tds_read2_b32 %3, %4 offset0:%6 offset1:%7"
+                         : "=&v"(v00), "=&v"(v10), "=&v"(v01), "=&v"(v11)
+                         : "v"(a), "n"(4 * LP), "n"(LP + 1), "n"(LP + 2));
+        };
+        // wait until at most N of the LGKM operations issued so far are outstanding: LDS operations complete in order, so the first 12 - N of the
+        // plane's reads have landed whatever else (scalar loads, the compiler's own LDS accesses) is counted with them
+#define CF3_LDS_WAIT(N, q0, q1, q2, q3) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3))
+        constexpr int NF = 1 + (HAS_NU ? 1 : 0) + (HAS_F ? 1 : 0);
+        v2f u00, u10, u01, u11, n00, n10, n01, n11, f00, f10, f01, f11;
+        pairs(Lu, u00, u10, u01, u11);
+        if constexpr (HAS_NU) pairs(Ln, n00, n10, n01, n11);
+        if constexpr (HAS_F) pairs(Lf, f00, f10, f01, f11);
+        if constexpr (NF == 3) CF3_LDS_WAIT(8, u00, u10, u01, u11);
+        else if constexpr (NF == 2) CF3_LDS_WAIT(4, u00, u10, u01, u11);
+        else CF3_LDS_WAIT(0, u00, u10, u01, u11);
+        {
+            const v2f dx0 = u10 - u00, dx1 = u11 - u01, dy0 = u01 - u00, xy = dx1 - dx0;
+            S.BX[0] = vfma(k.t0, xy, dx0); S.BX[1] = vfma(k.t1, xy, dx0);
+            S.CY[0] = vfma(k.t0, xy, dy0); S.CY[1] = vfma(k.t1, xy, dy0);
+            const v2f A0 = vfma(k.t0, dy0, u00), A1 = vfma(k.t1, dy0, u00);
+            S.U[0][0] = vfma(k.t0, S.BX[0], A0); S.U[0][1] = vfma(k.t1, S.BX[0], A0);
+            S.U[1][0] = vfma(k.t0, S.BX[1], A1); S.U[1][1] = vfma(k.t1, S.BX[1], A1);
+        }
+        if constexpr (HAS_NU) {
+            if constexpr (HAS_F) CF3_LDS_WAIT(4, n00, n10, n01, n11);
+            else CF3_LDS_WAIT(0, n00, n10, n01, n11);
+            stage_vals(n00, n10, n01, n11, S.V);
+        }
+        if constexpr (HAS_F) {
+            CF3_LDS_WAIT(0, f00, f10, f01, f11);
+            stage_vals(f00, f10, f01, f11, F);
+        }
+#undef CF3_LDS_WAIT
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    PlaneC SA, SB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) SA.V[j][i] = SB.V[j][i] = k.snu;       // nu absent: the constant field 1
+
+    // carried cotangents of the plane between two layers, from the layer below: cX / cY of BX / CY (closed-form sums, with the plane's own
+    // product kappa * PX * BX counted twice -- once for each of its layers; a boundary plane takes one back), cU of U
+    v2f cX[2], cY[2], cU[2][2];
+    v2f e2_acc2 = 0.f, sq_acc2 = 0.f, ut_acc = 0.f;
+    int par = 0;
+
+    // adjoint of the in-plane stage: cotangents of BX, CY (up to the factors 1 and ry), U (up to rz) -> contributions to each element's 2 x 2 nodes
+    auto plane_adjoint = [&](const v2f (&GX)[2], const v2f (&GY)[2], const v2f (&GU)[2][2], v2f (&o)[2][2]) {
+        const v2f gA0 = k.rz * (GU[0][0] + GU[0][1]), gA1 = k.rz * (GU[1][0] + GU[1][1]);
+        const v2f gB0 = vfma(k.rzt1, GU[0][1], vfma(k.rzt0, GU[0][0], GX[0]));
+        const v2f gB1 = vfma(k.rzt1, GU[1][1], vfma(k.rzt0, GU[1][0], GX[1]));
+        const v2f g_u00 = gA0 + gA1;
+        const v2f g_dy0 = vfma(k.t1, gA1, vfma(k.t0, gA0, k.ry * (GY[0] + GY[1])));
+        const v2f g_dx0 = gB0 + gB1;
+        const v2f g_xy = vfma(k.ryt1, GY[1], vfma(k.ryt0, GY[0], vfma(k.t1, gB1, k.t0 * gB0)));
+        const v2f o10 = g_dx0 - g_xy, o01 = g_dy0 - g_xy;
+        o[0][1] = okv * o10; o[1][1] = okv * g_xy; o[1][0] = okv * o01; o[0][0] = okv * (g_u00 - o10 - g_dy0);
+    };
+
+    const unsigned out_row = (unsigned)ey * (unsigned)p.nx;
+    const int from_left = (int)(((unsigned)tid - 1u) & 63u) << 2;
+    const float nfirst = tx > 0 ? 1.f : 0.f;
+    float2 pend_v = make_float2(0.f, 0.f);
+    unsigned pend_off = 0u;
+    bool pend_st = false;
+    auto flush_store = [&]() {
+        if (pend_st) st_at<float2>(sb.out, pend_off, pend_v);
+        pend_st = false;
+    };
+    // o[node row][node column of the element]: contributions of the thread's two elements (.x, .y) to their 2 x 2 nodes in the plane being
+    // finished.  The thread's node columns: c0 = o[.][0].x (+ the left thread's o[.][1].y), c1 = o[.][1].x + o[.][0].y; o[.][1].y goes right.
+    auto emit_plane = [&](const v2f (&o)[2][2], int z, bool owned_plane, const RawNodes* W, int zpub) {
+        DN_STAMP(stamp_C);
+        // keep and the value of the own node pair in the plane being finished: re-read from the thread's own LDS entries (issued BEFORE this call's
+        // publish overwrites the entries of the same parity -- a wave's LDS accesses execute in order -- and landing under the barrier)
+        const float2 ou = *reinterpret_cast<const float2*>(&Lu[z & 1][ty][2 * tx]);
+        const v2f uown = {ou.x, ou.y};
+        v2f keep = {1.f, 1.f}, bown = {0.f, 0.f};
+        if constexpr (IMG || BOX) { const float2 t2 = Lk[z & 1][ty][tx]; keep = v2f{t2.x, t2.y}; }
+        if constexpr (LOADV) { const float2 t2 = *reinterpret_cast<const float2*>(&Lf[z & 1][ty][2 * tx]); bown = v2f{t2.x, t2.y}; }       // the load vector at the own node pair
+        const float left0 = cf3_from_left(o[0][1].y, from_left, nfirst);
+        xch[par][tid] = make_float2(o[1][0].x + cf3_from_left(o[1][1].y, from_left, nfirst), o[1][1].x + o[1][0].y);
+        if (W != nullptr) plane_publish(*W, zpub);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        DN_STAMP(stamp_D);
+        v2f t = {o[0][0].x + left0, o[0][1].x + o[0][0].y};
+        if (ty > 0) {
+            const float2 up = xch[par][tid - 16];
+            t += v2f{up.x, up.y};
+        }
+        const bool st = owned_plane && owner && noderow_ok;
+        // the sums take the owned nodes only: factor 1 / 0 (threads beyond the mesh in x hold clamped duplicates with contributions 0; the load
+        // vector's share needs the explicit test)
+        const float stf = st ? 1.f : 0.f;
+        if constexpr (LOADV) {
+            // out_a -= beta * wscale * b_a,  sum f u = sum_a u_a b_a (u after the Dirichlet conditions): one FMA each per owned node
+            const float inm = (st && x0 < p.nx) ? 1.f : 0.f;
+            const v2f bm = inm * bown;
+            t = vfma(k.nbw, bm, t);
+            e2_acc2 = vfma(uown, bm, e2_acc2);
+        }
+        t *= stf;
+        ut_acc = vfma(t, uown, ut_acc);        // sum_a u_a out_a, before the Dirichlet rows are zeroed
+        t *= keep;
+        sq_acc2 = vfma(t, t, sq_acc2);
+        pend_v = make_float2(t.x * p.out_scale, t.y * p.out_scale);
+        pend_off = (unsigned)z * npl + out_row + (unsigned)x0;
+        pend_st = st && sb.out != nullptr && x0 < p.nx;
+        par ^= 1;
+    };
+    // one element layer between the staged planes L (lower, plane ez) and Up (plane ez + 1, its forcing stage F): finishes plane ez
+    auto layer = [&](int ez, const PlaneC& L, const PlaneC& Up, const v2f (&F)[2][2], const RawNodes* W) {
+        const bool own_layer = ez >= ez_own;
+        v2f GX[2], GY[2], GU[2][2], Sz[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                Sz[j][i] = L.V[j][i] + Up.V[j][i];
+                const v2f q = Sz[j][i] * (Up.U[j][i] - L.U[j][i]);
+                GU[j][i] = cU[j][i] - q;
+                if constexpr (HAS_F) cU[j][i] = vfma(k.nbz, F[j][i], q);
+                else cU[j][i] = q;
+            }
+        if constexpr (HAS_F) {
+            // sum_g f_g u_g of the upper plane's share: counted where that plane is owned (the plane ez_end belongs to the next strip, the mesh's top
+            // plane to the last one)
+            const bool own_up_u = ez + 1 >= ez_own && (ez + 1 < ez_end || ez_end == p.nelz);
+            const v2f s = vfma(F[1][1], Up.U[1][1], vfma(F[1][0], Up.U[1][0], vfma(F[0][1], Up.U[0][1], F[0][0] * Up.U[0][0])));
+            const v2f cnt = cf3_usel_lt(0, own_up_u ? 1 : 0, 1.f, 0.f) * okown;
+            e2_acc2 = vfma(cnt, s, e2_acc2);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const v2f T = (Sz[j][0] + Sz[j][1]) * (L.BX[j] + Up.BX[j]);
+            GX[j] = cX[j] + T;
+            cX[j] = vfma(k.kappa2, (Up.V[j][0] + Up.V[j][1]) * Up.BX[j], T);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const v2f T = (Sz[0][i] + Sz[1][i]) * (L.CY[i] + Up.CY[i]);
+            GY[i] = cY[i] + T;
+            cY[i] = vfma(k.kappa2, (Up.V[0][i] + Up.V[1][i]) * Up.CY[i], T);
+        }
+        v2f o[2][2];
+        plane_adjoint(GX, GY, GU, o);
+        __builtin_amdgcn_sched_barrier(0);
+        emit_plane(o, ez, own_layer, W, ez + 2);
+    };
+
+    // prologue: planes ez_begin and ez_begin + 1 into LDS (requested together), the lower one staged
+    // constant planes (absent nu: the field 1, scaled; keep stays in registers when there is no condition) and the halo entries no lane group writes
+    for (int i = tid; i < 2 * 17 * LP; i += 256) {
+        if constexpr (!HAS_NU) (&Ln[0][0][0])[i] = k.snu;
+        if constexpr (!F_ARR || LOADV) (&Lf[0][0][0])[i] = 0.f;
+    }
+    __syncthreads();
+    RawNodes W;
+    {
+        RawNodes W0;
+        if constexpr (HAS_F) {         // the forcing of the two planes before the first published one's upper neighbour
+            const unsigned zm = (unsigned)max(ez_begin - 1, 0) * npl, z0 = (unsigned)ez_begin * npl;
+            fh0 = ld_pair(sb.f, zm + own_off); fh1 = ld_pair(sb.f, z0 + own_off);
+            hh0 = halo_src[zm + halo_off]; hh1 = halo_src[z0 + halo_off];
+        }
+        plane_request(ez_begin, W0);
+        plane_request(ez_begin + 1, W);
+        plane_publish(W0, ez_begin);
+        plane_publish(W, ez_begin + 1);
+    }
+    __syncthreads();
+    {
+        v2f F0[2][2];
+        plane_gather(ez_begin, SA, F0);
+        // the first plane's own terms (they matter for the mesh's bottom plane only: every other strip recomputes its first layer for the plane above)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cX[j] = k.kappa * ((SA.V[j][0] + SA.V[j][1]) * SA.BX[j]);
+            cY[j] = k.kappa * ((SA.V[0][j] + SA.V[1][j]) * SA.CY[j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (HAS_F) cU[j][i] = k.nbz * F0[j][i];
+                else cU[j][i] = zero2;
+            }
+        }
+        if constexpr (HAS_F) {
+            const v2f s = vfma(F0[1][1], SA.U[1][1], vfma(F0[1][0], SA.U[1][0], vfma(F0[0][1], SA.U[0][1], F0[0][0] * SA.U[0][0])));
+            const v2f cnt = cf3_usel_lt(ez_begin, ez_own, 0.f, 1.f) * okown;
+            e2_acc2 = vfma(cnt, s, e2_acc2);
+        }
+    }
+    __syncthreads();              // every thread has read plane ez_begin before the first layer publishes plane ez_begin + 2 into its slot
+    int ez = ez_begin;
+#if defined(DN_STAMP3D)
+    stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+    v2f FU[2][2];
+#pragma nounroll
+    for (; ez + 1 < ez_end; ez += 2) {
+        plane_request(ez + 2, W);                 // lands while this layer is computed; published before the layer's barrier
+        flush_store();
+        DN_STAMP(stamp_A);
+        plane_gather(ez + 1, SB, FU);
+        DN_STAMP(stamp_B);
+        layer(ez, SA, SB, FU, &W);
+        DN_STAMP(stamp_E);
+        plane_request(ez + 3, W);
+        flush_store();
+        DN_STAMP(stamp_A);
+        plane_gather(ez + 2, SA, FU);
+        DN_STAMP(stamp_B);
+        layer(ez + 1, SB, SA, FU, &W);
+        DN_STAMP(stamp_E);
+#if defined(DN_STAMP3D)
+        stamp_n += 2;
+#endif
+    }
+    // the last strip owns the top boundary plane: only the layer below contributes -- take back one of the plane's two products.  (Called on SA
+    // or SB by name: selecting between the two states through a reference would put both into scratch memory.)
+    auto top_plane = [&](const PlaneC& Tp) {
+        v2f GX[2], GY[2], o[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            GX[j] = vfma(-k.kappa, (Tp.V[j][0] + Tp.V[j][1]) * Tp.BX[j], cX[j]);
+            GY[j] = vfma(-k.kappa, (Tp.V[0][j] + Tp.V[1][j]) * Tp.CY[j], cY[j]);
+        }
+        plane_adjoint(GX, GY, cU, o);
+        emit_plane(o, p.nz - 1, true, nullptr, 0);
+        flush_store();
+    };
+    if (ez < ez_end) {
+        flush_store();
+        plane_gather(ez + 1, SB, FU);
+        layer(ez, SA, SB, FU, nullptr);
+        flush_store();
+        if (ez_end == p.nelz) top_plane(SB);
+    } else {
+        flush_store();
+        if (ez_end == p.nelz) top_plane(SA);
+    }
+#if defined(DN_STAMP3D)
+    if (tid == 0) {                               // wave 0 of every workgroup (tools/stamp3d.py)
+        const unsigned slot = blockIdx.x;
+        if (slot < 8192u) {
+            unsigned long long* d = dn_stamp_buf + slot * 8u;
+            const unsigned long long hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+            d[0] = stamp_A; d[1] = stamp_B; d[2] = stamp_C; d[3] = stamp_D;
+            d[4] = stamp_E | ((__builtin_amdgcn_s_memrealtime() - stamp_rt0) << 40);
+            d[5] = stamp_n | (hwid << 16) | ((xcc & 0xffull) << 48);
+            d[6] = stamp_t0; d[7] = __builtin_amdgcn_s_memtime();
+        }
+    }
+#endif
+    if (p.want_sums) {
+        const float e2_acc = e2_acc2.x + e2_acc2.y, sq_acc = sq_acc2.x + sq_acc2.y;
+        // sum_a u_a out_a = wscale ( alpha sum nu |grad u|^2 - beta sum f u ): this thread's share of the stiffness sum (the identity holds for the total)
+        const float e1_acc = ((ut_acc.x + ut_acc.y) * k.inv_esc + k.beta * e2_acc) * k.inv_alpha;
+        finish_sums(p, e1_acc, e2_acc, sq_acc, tid, 256, red, &last_flag, (double)p.T.esc);
+    }
+}
+
+// ---- dispatch ---------------------------------------------------------------------------------------------
+template <int FLB>
+static void launch_cf3_bc(const PoissonParams& pp, const Cf3Consts& kc, const dim3& grid, const Geom3D& g, hipStream_t s) {
+    const bool any = pp.bc[0].mask || pp.bc[1].mask;
+    const bool one = (pp.bc[0].mask != nullptr) != (pp.bc[1].mask != nullptr);
+    bool f32 = false;
+    for (int kk = 0; kk < 2; ++kk)
+        if (pp.bc[kk].mask && !pp.bc[kk].mask_is_u8) f32 = true;
+    const dim3 block(16, 16);
+#define DN_CF3(FLAGS) hipLaunchKernelGGL((poisson3d_q1_cf_kernel<(FLAGS)>), grid, block, 0, s, pp, kc, g.chunks, g.tiles, g.strips)
+    if (pp.bc[0].kind == DN_MASK_BOX || pp.bc[1].kind == DN_MASK_BOX) {       // box faces (no array), alone or beside ONE mask image
+        if (!any) DN_CF3(FLB | CF3_BOX);
+        else if (!f32) DN_CF3(FLB | CF3_BOX | CF3_IMG | CF3_ONE);
+        else DN_CF3(FLB | CF3_BOX | CF3_IMG | CF3_F32 | CF3_ONE);
+        return;
+    }
+    if (!any) DN_CF3(FLB);
+    else if (!f32 && one) DN_CF3(FLB | CF3_IMG | CF3_ONE);
+    else if (!f32) DN_CF3(FLB | CF3_IMG);
+    else if (one) DN_CF3(FLB | CF3_IMG | CF3_F32 | CF3_ONE);
+    else DN_CF3(FLB | CF3_IMG | CF3_F32);
+#undef DN_CF3
+}
+
+// May this launch run the closed-form kernel?  (dn_poisson_apply has checked q1n2_ok(): exact 2-point rule, even nx, aligned pairs, nodal /
+// absent / pre-assembled forcing, constant-value conditions as images of one kind or box faces.)  It needs a stiffness part (the scales of its
+// records divide by alpha) and takes the energy from the nodal values.
+bool poisson3d_q1_cf_ok(const PoissonParams& pp) {
+    if (config(CFG_Q1_3D_N2) != nullptr || config(CFG_Q1_3D_E1SUM) != nullptr) return false;
+    if (!(pp.T.alpha != 0.f) || !std::isfinite(pp.T.alpha)) return false;
+    if (!(pp.T.kap[0] != 0.f && pp.T.kap[1] != 0.f && pp.T.kap[2] != 0.f)) return false;
+    if (std::fabs(pp.T.b[0][1] + pp.T.b[1][1] - 1.0f) > 1e-6f) return false;        // the closed form assumes the symmetric rule
+    return true;
+}
+
+int launch_poisson3d_q1_cf(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s) {
+    if (!(g.E == 2 && g.TX == 16 && g.TY == 16)) return DN_E_UNSUPPORTED;
+    // constants of the closed form, in double from the rule's own table entries (unit weights)
+    const double t0 = pp.T.b[0][1], t1 = pp.T.b[1][1];
+    const double sig = 0.5 * (t0 * t0 * t0 + t1 * t1 * t1 + (1 - t0) * (1 - t0) * (1 - t0) + (1 - t1) * (1 - t1) * (1 - t1));
+    const double tau = 0.5 * (t0 * t0 * (1 - t0) + t1 * t1 * (1 - t1) + (1 - t0) * (1 - t0) * t0 + (1 - t1) * (1 - t1) * t1);
+    const double kx = pp.T.kap[0], ky = pp.T.kap[1], kz = pp.T.kap[2];
+    Cf3Consts kc;
+    kc.t0 = (float)t0; kc.t1 = (float)t1;
+    kc.snu = (float)(kx * tau);
+    const double ry = ky / kx, rz = kz / (kx * tau);
+    kc.ry = (float)ry; kc.rz = (float)rz;
+    kc.rzt0 = (float)(rz * t0); kc.rzt1 = (float)(rz * t1); kc.ryt0 = (float)(ry * t0); kc.ryt1 = (float)(ry * t1);
+    kc.kappa = (float)(sig / tau - 1.0); kc.kappa2 = (float)(2.0 * (sig / tau - 1.0));
+    kc.nbw = pp.T.nbw;
+    kc.nbz = (float)((double)pp.T.nbw / rz);
+    kc.c00 = pp.T.q1my[0]; kc.c01 = pp.T.q1my[1]; kc.c11 = pp.T.q1my[2];
+    // f'(m) = c01 (f(m-1) + f(m+1)) + czd f(m); on the mesh's bottom / top plane the clamped load of the missing neighbour returns f(m) itself: its c01
+    // and the missing element's diagonal share are taken off the middle coefficient
+    kc.czd[0] = kc.c00 + kc.c11; kc.czd[1] = kc.c00 - kc.c01; kc.czd[2] = kc.c11 - kc.c01; kc.czd[3] = -2.f * kc.c01;
+    kc.inv_esc = (float)(1.0 / (double)pp.T.esc); kc.beta = pp.T.beta; kc.inv_alpha = (float)(1.0 / (double)pp.T.alpha);
+    const dim3 grid((unsigned)((long long)g.chunks * g.tiles * g.strips * batch));
+    const int sel = (pp.nu ? 1 : 0) | (pp.f ? 2 : 0);
+    if (pp.f && pp.f_is_load) {                    // the forcing as the assembled load vector (dn_poisson_args.f_is_load)
+        if (sel == 2) launch_cf3_bc<CF3_F | CF3_LOAD>(pp, kc, grid, g, s);
+        else launch_cf3_bc<CF3_NU | CF3_F | CF3_LOAD>(pp, kc, grid, g, s);
+        return 0;
+    }
+    switch (sel) {
+        case 0: launch_cf3_bc<0>(pp, kc, grid, g, s); break;
+        case 1: launch_cf3_bc<CF3_NU>(pp, kc, grid, g, s); break;
+        case 2: launch_cf3_bc<CF3_F>(pp, kc, grid, g, s); break;
+        default: launch_cf3_bc<CF3_NU | CF3_F>(pp, kc, grid, g, s); break;
+    }
+    return 0;
+}
+
+}  // namespace dn

@@ -371,6 +371,10 @@ int launch_poisson3d_q1_g2(const PoissonParams& pp, const Geom3D& g, int batch, 
 int launch_poisson3d_q1_g3(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);
 int launch_poisson3d_q1_g4(const PoissonParams& pp, const Geom3D& g, int batch, bool vec, hipStream_t s);
 
+// closed-form-in-z 3-D Q1 kernel (poisson3d_q1_cf.hip): exact 2-point rule, two elements per thread, energy from the nodal values
+bool poisson3d_q1_cf_ok(const PoissonParams& pp);
+int launch_poisson3d_q1_cf(const PoissonParams& pp, const Geom3D& g, int batch, hipStream_t s);
+
 // 3-D Q2 / Q3 (poisson3d_gen.hip): element vectors + fixed-order gather assembly; its workspace lies behind the common header
 static constexpr int64_t DN_WS_HEADER = 64 * (1 + 64);   // top counter + DN_NSHARD shard counters, one 64-B line each
 static constexpr int DN_WS_ERRWORD = 8;                    // word 8 of the top counter's line: sticky error bits of the launches that used this workspace

@@ -2,7 +2,7 @@
 """Round-4 timing harness: one fused Poisson launch (2-D or 3-D Q1) over NSETS field sets in rotation, prepared launches back to back,
 steady state.  usage: r4_time.py <2|3> <n> <B> <bc: none|u8|f32|bits|box> [key=value ...]
 keys: sums=1|0|defer|fold (in-kernel final reduction / no sums / per-workgroup partials only / partials folded by the next launch), load=1 (forcing as LoadVector), nsets=4, plan=<PLAN2D|PLAN3D override>,
-      nu=1|0, f=1|0, reps=3, iters=400, tag=<label>.  DN_LIB_PATH selects a variant build."""
+      nu=1|0, f=1|0, reps=3, iters=400, tag=<label>, cfg=KEY:VALUE[,...] (dn_config_set).  DN_LIB_PATH selects a variant build."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffnet_amd import BoxFaces, DiffNet2DFEM, DiffNet3DFEM, LoadVector, PackedMask, _lib, ops
@@ -11,6 +11,8 @@ nsd, n, B, form = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv
 kv = dict(a.split("=", 1) for a in sys.argv[5:])
 dev = torch.device("cuda:0")
 m = (DiffNet3DFEM(None, domain_size=n, nsd=3) if nsd == 3 else DiffNet2DFEM(None, domain_size=n, ngp_1d=int(kv.get("ngp", 3)))).to(dev)
+for c in filter(None, kv.get("cfg", "").split(",")):          # cfg=KEY:VALUE[,KEY:VALUE]: dn_config_set switches (e.g. cfg=Q1_3D_N2:1)
+    _lib.config_set(*c.split(":", 1))
 if "plan" in kv:
     _lib.config_set("PLAN3D" if nsd == 3 else "PLAN2D", kv["plan"])
 shape = (B, 1) + (n,) * nsd
@@ -74,5 +76,5 @@ for _ in range(reps):
     ts.append(a.elapsed_time(b) * 1000.0 / iters)
 nodes = B * n ** nsd
 med = sorted(ts)[len(ts) // 2]
-print(f"{kv.get('tag', '')} lib={os.path.basename(os.environ.get('DN_LIB_PATH', 'default'))} {nsd}-D n={n} B={B} bc={form} sums={sums} plan={kv.get('plan', 'default')} "
+print(f"{kv.get('tag', '')} lib={os.path.basename(os.environ.get('DN_LIB_PATH', 'default'))} {nsd}-D n={n} B={B} bc={form} sums={sums} plan={kv.get('plan', 'default')} cfg={kv.get('cfg', '-')} "
       f"nu={kv.get('nu', '1')} f={kv.get('f', '1')} nsets={nsets}: {med:.2f} us per launch  ({16.0 * nodes / med * 1e-6:.3f} TB/s of 16 B/node)  {[round(t, 2) for t in ts]}", flush=True)
