@@ -122,15 +122,28 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    // the node planes in LDS, one array per field (structure of arrays): [plane parity][node row][node column], rows of 33 nodes padded to 36
-    // floats.  A thread reads the node pairs (x0, x0 + 1) and (x0 + 1, x0 + 2) of its two node rows as ds_read_b64 / ds_read2_b32: the values land in
-    // the register pairs the packed instructions take (the 16-byte records of round 3 cost 24 v_mov per layer to form those pairs).
-    constexpr int LP = 36;
-    __shared__ float Lu[2][17][LP];               // u after the Dirichlet conditions
-    __shared__ float Ln[2][17][LP];               // nu * snu
-    __shared__ float Lf[2][17][LP];               // f' (z mass stencil applied) or the load vector
-    __shared__ float2 Lk[2][16][16];              // keep (0 on fixed nodes) of the own node pairs
-    __shared__ float2 xch[2][256];
+    // The node planes in LDS: ONE block, two slots; per slot 17 node rows, per row the three fields one after the other, per field the EVEN node
+    // columns (17 floats, padded to 18) followed by the ODD ones (16, padded to 18).  A thread's element pair needs the node pairs (x0, x0 + 1)
+    // = (E[tx], O[tx]) and (x0 + 1, x0 + 2) = (O[tx], E[tx + 1]) of two node rows: each is ONE ds_read2_b32 whose two passes read consecutive floats
+    // in consecutive lanes (no bank conflicts) and whose result is the register pair the packed instructions take -- the 16-byte node records of
+    // round 3 cost 24 v_mov per layer to form those pairs, plain rows of nodes a two-way bank conflict on every second read.  Every access of a
+    // thread is one of two per-thread byte offsets (its node column in a row, its pair slot) plus a compile-time constant: the plane slots alternate
+    // with the layers of the two-layer loop body and are literals there; all of a gather's offsets lie within the reach of the read2 offset fields.
+    constexpr int HALF = 18, LP = 2 * HALF, ROW = 3 * LP + 4, PLANE = 17 * ROW;      // (rows of 112 floats: consecutive thread rows land on the other 16 banks)
+    constexpr int OFF_U = 0, OFF_N = LP, OFF_F = 2 * LP, OFF_K = 2 * PLANE, OFF_X = OFF_K + 2 * 512, LDS_FLOATS = OFF_X + 2 * 512;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];      // u' | nu * snu | f' or the load vector, per row;  keep of the own pairs;  hand-over slots
+    typedef __attribute__((address_space(3))) float* lds_fptr;
+    lds_fptr const lds_own = (lds_fptr)(lds + ty * ROW + tx);           // E[tx] of the thread's node row (field 0, slot 0); O[tx] is HALF floats on
+    char* const lds_pair = reinterpret_cast<char*>(lds) + tid * 8;      // the thread's float2 in the keep / hand-over arrays
+    // (per slot: the base of the gather's inline-asm reads)
+    lds_fptr const lds_own_b0 = lds_own, lds_own_b1 = lds_own + PLANE;
+    auto lds_rd2 = [&](lds_fptr base, int off_a, int off_b) { return v2f{base[off_a], base[off_b]}; };          // -> ds_read2_b32
+    auto lds_wr2 = [&](lds_fptr base, int off_a, int off_b, float a, float b) { base[off_a] = a; base[off_b] = b; };   // -> ds_write2_b32
+    auto lds_ld2 = [&](const char* base, int float_off) {
+        const float2 t = *reinterpret_cast<const float2*>(base + float_off * 4);
+        return v2f{t.x, t.y};
+    };
+    auto lds_st2 = [&](char* base, int float_off, float a, float b) { *reinterpret_cast<float2*>(base + float_off * 4) = make_float2(a, b); };
     __shared__ double red[2 * (256 / 64)];
     __shared__ int last_flag;
     if (blockIdx.x == 0u) fold_prev_sums(p, tid, 256, red);       // dn_poisson_args.fold_prev: close the evaluation before this one
@@ -145,8 +158,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     const int hrow = hidx < 33 ? 16 : hidx - 33, hcol = hidx < 33 ? hidx : 32;
     const unsigned halo_off = (unsigned)min(ny0 + hrow, p.ny - 1) * (unsigned)p.nx + (unsigned)min(nx0 + hcol, p.nx - 1);
     const bool halo_lane = lane < 39 && wave * 13 + hsub < 49 && (hgrp == 0 || (hgrp == 1 ? HAS_NU : HAS_F));       // (a load vector is needed at owned nodes only)
-    float* const halo_rec0 = (hgrp == 0 ? &Lu[0][0][0] : (hgrp == 1 ? &Ln[0][0][0] : &Lf[0][0][0])) + hrow * LP + hcol;              // the lane's field array
-    constexpr unsigned halo_par_stride = 17u * LP;                                                                                      // floats
+    float* const halo_lds = lds + (hgrp == 0 ? OFF_U : (hgrp == 1 ? OFF_N : OFF_F)) + hrow * ROW + (hcol & 1) * HALF + (hcol >> 1);    // the lane's field, slot 0
     const float* const halo_src = (hgrp == 1 && HAS_NU) ? sb.nu : ((hgrp == 2 && HAS_F) ? sb.f : sb.u);                               // per lane
     const bool halo_is_f = HAS_F && hgrp == 2;
     const unsigned halo_fmask = halo_is_f ? 0xffffffffu : 0u;
@@ -184,6 +196,12 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         const unsigned zoff_f = HAS_F ? (unsigned)min(zreq + 1, p.nz - 1) * npl : zoff;
         const unsigned oo = zoff + own_off, oh = zoff + halo_off + (halo_fmask & (zoff_f - zoff));
         W.u = ld_pair(sb.u, oo);
+#ifdef DN_CF3_ABL_REQ                      // timing experiment only (results are wrong): u is the one array requested, the other values are made up from it
+        W.n = W.u + 0.5f; W.f = W.u; W.h = W.u.x;
+        W.m[0] = W.m[1] = (uint16_t)(W.u.x == 123.456f); W.hm[0] = W.hm[1] = (uint8_t)W.m[0];
+        W.mf[0] = W.mf[1] = 0.f; W.hmf[0] = W.hmf[1] = 0.f;
+        return;
+#endif
         if constexpr (HAS_NU) W.n = ld_pair(sb.nu, oo);
         if constexpr (F_ARR) W.f = ld_pair(sb.f, zoff_f + own_off);
         W.h = halo_src[oh];
@@ -220,7 +238,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     //     f'(m) = czl f(m - 1) + czd f(m) + czu f(m + 1),      the 3-point stencil of the rule's 1-D mass matrix along z (boundary planes: one side)
     v2f fh0 = 0.f, fh1 = 0.f;
     float hh0 = 0.f, hh1 = 0.f;
-    auto plane_publish = [&](const RawNodes& W, int zpl) {
+    auto plane_publish = [&](const RawNodes& W, int zpl, int slot) {
         bool s0[2] = {false, false}, s1[2] = {false, false}, sh[2] = {false, false};
         if constexpr (IMG) {
 #pragma unroll
@@ -229,7 +247,6 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
                 else { s0[kk] = (W.m[kk] & 0xffu) != 0; s1[kk] = (W.m[kk] >> 8) != 0; sh[kk] = W.hm[kk] != 0; }
             }
         }
-        const int par = zpl & 1;
         bool b0[2] = {false, false}, b1[2] = {false, false}, bh[2] = {false, false};
         const int zc = min(zpl, p.nz - 1);
         if constexpr (BOX) {
@@ -255,13 +272,13 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         float u0 = W.u.x, u1 = W.u.y, k0, k1;
         fix_node(u0, k0, s0, b0);
         fix_node(u1, k1, s1, b1);
-        *reinterpret_cast<float2*>(&Lu[par][ty][2 * tx]) = make_float2(u0, u1);
+        lds_wr2(lds_own, slot * PLANE + OFF_U, slot * PLANE + OFF_U + HALF, u0, u1);
         if constexpr (HAS_NU) {
             const v2f nr = k.snu * W.n;
-            *reinterpret_cast<float2*>(&Ln[par][ty][2 * tx]) = make_float2(nr.x, nr.y);
+            lds_wr2(lds_own, slot * PLANE + OFF_N, slot * PLANE + OFF_N + HALF, nr.x, nr.y);
         }
-        if constexpr (F_ARR) *reinterpret_cast<float2*>(&Lf[par][ty][2 * tx]) = make_float2(fz.x, fz.y);
-        if constexpr (IMG || BOX) Lk[par][ty][tx] = make_float2(k0, k1);
+        if constexpr (F_ARR) lds_wr2(lds_own, slot * PLANE + OFF_F, slot * PLANE + OFF_F + HALF, fz.x, fz.y);
+        if constexpr (IMG || BOX) lds_st2(lds_pair, OFF_K + slot * 512, k0, k1);
         if (halo_lane) {
             if constexpr (IMG || BOX) {
                 float kh;
@@ -269,7 +286,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
                 fix_node(hu, kh, sh, bh);
                 hv = hgrp == 0 ? hu : hv;
             }
-            halo_rec0[par * halo_par_stride] = hv;
+            halo_lds[slot * PLANE] = hv;
         }
     };
 
@@ -284,25 +301,23 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         G[0][0] = vfma(k.t0, B0, A0); G[0][1] = vfma(k.t1, B0, A0);
         G[1][0] = vfma(k.t0, B1, A1); G[1][1] = vfma(k.t1, B1, A1);
     };
-    auto plane_gather = [&](int zpl, PlaneC& S, v2f (&F)[2][2]) {
-        const int par = zpl & 1;
-        // the four node pairs of the thread's two elements in one field plane: (x0, x0 + 1), (x0 + 1, x0 + 2) of node rows ty and ty + 1.  Inline asm:
-        // written in C++ the compiler takes x0 + 1 from the first pair and forms the second with v_mov (12 per layer); ds_read2_b32 delivers it as a
-        // register pair.  The reads of a plane are waited for together (cf3_lds_wait) -- the compiler does not count asm LDS accesses.
-        auto pairs = [&](const float (&A)[2][17][LP], v2f& v00, v2f& v10, v2f& v01, v2f& v11) {
-            const unsigned a = (unsigned)(uintptr_t)&A[par][ty][2 * tx];
-            asm volatile("ds_read_b64 %0, %4\n\tds_read2_b32 %1, %4 offset0:1 offset1:2\n\tds_read_b64 %2, %4 offset:%5\n\tds_read2_b32 %3, %4 offset0:%6 offset1:%7"
-                         : "=&v"(v00), "=&v"(v10), "=&v"(v01), "=&v"(v11)
-                         : "v"(a), "n"(4 * LP), "n"(LP + 1), "n"(LP + 2));
-        };
-        // wait until at most N of the LGKM operations issued so far are outstanding: LDS operations complete in order, so the first 12 - N of the
-        // plane's reads have landed whatever else (scalar loads, the compiler's own LDS accesses) is counted with them
+    auto plane_gather = [&](int slot, PlaneC& S, v2f (&F)[2][2]) {
+        // the four node pairs of the thread's two elements in one field plane: (x0, x0 + 1), (x0 + 1, x0 + 2) of node rows ty and ty + 1
+        // Inline asm: the compiler sorts the two offsets of a ds_read2_b32 it forms by address, which delivers (O[tx], E[tx + 1]) swapped and costs two
+        // v_mov per pair.  It does not count asm LDS accesses, so the waits are written here: "at most N LGKM operations outstanding" -- LDS accesses
+        // complete in order, so the first 12 - N reads of the plane have landed whatever else (scalar loads, the compiler's own LDS accesses) is counted
+        const unsigned bu = (unsigned)(uintptr_t)(slot ? lds_own_b1 : lds_own_b0);
+#define CF3_PAIRS(off, v00, v10, v01, v11)                                                                                                   \
+    asm volatile("ds_read2_b32 %0, %4 offset0:%5 offset1:%6\n\tds_read2_b32 %1, %4 offset0:%6 offset1:%7\n\t"                                   \
+                 "ds_read2_b32 %2, %4 offset0:%8 offset1:%9\n\tds_read2_b32 %3, %4 offset0:%9 offset1:%10"                                       \
+                 : "=&v"(v00), "=&v"(v10), "=&v"(v01), "=&v"(v11)                                                                                \
+                 : "v"(bu), "n"(off), "n"((off) + HALF), "n"((off) + 1), "n"((off) + ROW), "n"((off) + ROW + HALF), "n"((off) + ROW + 1))
 #define CF3_LDS_WAIT(N, q0, q1, q2, q3) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3))
         constexpr int NF = 1 + (HAS_NU ? 1 : 0) + (HAS_F ? 1 : 0);
         v2f u00, u10, u01, u11, n00, n10, n01, n11, f00, f10, f01, f11;
-        pairs(Lu, u00, u10, u01, u11);
-        if constexpr (HAS_NU) pairs(Ln, n00, n10, n01, n11);
-        if constexpr (HAS_F) pairs(Lf, f00, f10, f01, f11);
+        CF3_PAIRS(OFF_U, u00, u10, u01, u11);
+        if constexpr (HAS_NU) CF3_PAIRS(OFF_N, n00, n10, n01, n11);
+        if constexpr (HAS_F) CF3_PAIRS(OFF_F, f00, f10, f01, f11);
         if constexpr (NF == 3) CF3_LDS_WAIT(8, u00, u10, u01, u11);
         else if constexpr (NF == 2) CF3_LDS_WAIT(4, u00, u10, u01, u11);
         else CF3_LDS_WAIT(0, u00, u10, u01, u11);
@@ -324,6 +339,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
             stage_vals(f00, f10, f01, f11, F);
         }
 #undef CF3_LDS_WAIT
+#undef CF3_PAIRS
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -336,8 +352,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     // carried cotangents of the plane between two layers, from the layer below: cX / cY of BX / CY (closed-form sums, with the plane's own
     // product kappa * PX * BX counted twice -- once for each of its layers; a boundary plane takes one back), cU of U
     v2f cX[2], cY[2], cU[2][2];
-    v2f e2_acc2 = 0.f, sq_acc2 = 0.f, ut_acc = 0.f;
-    int par = 0;
+    float e2_acc = 0.f, sq_acc = 0.f, ut_acc = 0.f;      // per-thread sums over both elements / nodes (one register each: the kernel sits at its register cap)
 
     // adjoint of the in-plane stage: cotangents of BX, CY (up to the factors 1 and ry), U (up to rz) -> contributions to each element's 2 x 2 nodes
     auto plane_adjoint = [&](const v2f (&GX)[2], const v2f (&GY)[2], const v2f (&GU)[2][2], v2f (&o)[2][2]) {
@@ -364,25 +379,26 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     };
     // o[node row][node column of the element]: contributions of the thread's two elements (.x, .y) to their 2 x 2 nodes in the plane being
     // finished.  The thread's node columns: c0 = o[.][0].x (+ the left thread's o[.][1].y), c1 = o[.][1].x + o[.][0].y; o[.][1].y goes right.
-    auto emit_plane = [&](const v2f (&o)[2][2], int z, bool owned_plane, const RawNodes* W, int zpub) {
+    // zslot: the LDS slot of plane z (and of the plane published here, two planes on); xslot: the hand-over slot of this call (they alternate)
+    auto emit_plane = [&](const v2f (&o)[2][2], int z, int zslot, int xslot, bool owned_plane, const RawNodes* W, int zpub) {
         DN_STAMP(stamp_C);
         // keep and the value of the own node pair in the plane being finished: re-read from the thread's own LDS entries (issued BEFORE this call's
         // publish overwrites the entries of the same parity -- a wave's LDS accesses execute in order -- and landing under the barrier)
-        const float2 ou = *reinterpret_cast<const float2*>(&Lu[z & 1][ty][2 * tx]);
-        const v2f uown = {ou.x, ou.y};
+        const v2f uown = lds_rd2(lds_own, zslot * PLANE + OFF_U, zslot * PLANE + OFF_U + HALF);
         v2f keep = {1.f, 1.f}, bown = {0.f, 0.f};
-        if constexpr (IMG || BOX) { const float2 t2 = Lk[z & 1][ty][tx]; keep = v2f{t2.x, t2.y}; }
-        if constexpr (LOADV) { const float2 t2 = *reinterpret_cast<const float2*>(&Lf[z & 1][ty][2 * tx]); bown = v2f{t2.x, t2.y}; }       // the load vector at the own node pair
+        if constexpr (IMG || BOX) keep = lds_ld2(lds_pair, OFF_K + zslot * 512);
+        if constexpr (LOADV) bown = lds_rd2(lds_own, zslot * PLANE + OFF_F, zslot * PLANE + OFF_F + HALF);       // the load vector at the own node pair
         const float left0 = cf3_from_left(o[0][1].y, from_left, nfirst);
-        xch[par][tid] = make_float2(o[1][0].x + cf3_from_left(o[1][1].y, from_left, nfirst), o[1][1].x + o[1][0].y);
-        if (W != nullptr) plane_publish(*W, zpub);
+        lds_st2(lds_pair, OFF_X + xslot * 512, o[1][0].x + cf3_from_left(o[1][1].y, from_left, nfirst), o[1][1].x + o[1][0].y);
+        if (W != nullptr) plane_publish(*W, zpub, zslot);
+#ifdef DN_CF3_ABL_BAR                      // timing experiment only (results are wrong): no workgroup barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         DN_STAMP(stamp_D);
         v2f t = {o[0][0].x + left0, o[0][1].x + o[0][0].y};
-        if (ty > 0) {
-            const float2 up = xch[par][tid - 16];
-            t += v2f{up.x, up.y};
-        }
+        if (ty > 0) t += lds_ld2(lds_pair, OFF_X + xslot * 512 - 32);       // the hand-over of the thread one node row below (tid - 16)
         const bool st = owned_plane && owner && noderow_ok;
         // the sums take the owned nodes only: factor 1 / 0 (threads beyond the mesh in x hold clamped duplicates with contributions 0; the load
         // vector's share needs the explicit test)
@@ -392,19 +408,20 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
             const float inm = (st && x0 < p.nx) ? 1.f : 0.f;
             const v2f bm = inm * bown;
             t = vfma(k.nbw, bm, t);
-            e2_acc2 = vfma(uown, bm, e2_acc2);
+            const v2f ub = uown * bm;
+            e2_acc += ub.x + ub.y;
         }
         t *= stf;
-        ut_acc = vfma(t, uown, ut_acc);        // sum_a u_a out_a, before the Dirichlet rows are zeroed
+        const v2f tu = t * uown;               // sum_a u_a out_a, before the Dirichlet rows are zeroed
+        ut_acc += tu.x + tu.y;
         t *= keep;
-        sq_acc2 = vfma(t, t, sq_acc2);
+        sq_acc = fmaf(t.x, t.x, fmaf(t.y, t.y, sq_acc));
         pend_v = make_float2(t.x * p.out_scale, t.y * p.out_scale);
         pend_off = (unsigned)z * npl + out_row + (unsigned)x0;
         pend_st = st && sb.out != nullptr && x0 < p.nx;
-        par ^= 1;
     };
     // one element layer between the staged planes L (lower, plane ez) and Up (plane ez + 1, its forcing stage F): finishes plane ez
-    auto layer = [&](int ez, const PlaneC& L, const PlaneC& Up, const v2f (&F)[2][2], const RawNodes* W) {
+    auto layer = [&](int ez, int zslot, const PlaneC& L, const PlaneC& Up, const v2f (&F)[2][2], const RawNodes* W) {
         const bool own_layer = ez >= ez_own;
         v2f GX[2], GY[2], GU[2][2], Sz[2][2];
 #pragma unroll
@@ -422,8 +439,8 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
             // plane to the last one)
             const bool own_up_u = ez + 1 >= ez_own && (ez + 1 < ez_end || ez_end == p.nelz);
             const v2f s = vfma(F[1][1], Up.U[1][1], vfma(F[1][0], Up.U[1][0], vfma(F[0][1], Up.U[0][1], F[0][0] * Up.U[0][0])));
-            const v2f cnt = cf3_usel_lt(0, own_up_u ? 1 : 0, 1.f, 0.f) * okown;
-            e2_acc2 = vfma(cnt, s, e2_acc2);
+            const v2f cs = (cf3_usel_lt(0, own_up_u ? 1 : 0, 1.f, 0.f) * okown) * s;
+            e2_acc += cs.x + cs.y;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -439,20 +456,19 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         }
         v2f o[2][2];
         plane_adjoint(GX, GY, GU, o);
+#ifndef DN_CF3_NOSB
         __builtin_amdgcn_sched_barrier(0);
-        emit_plane(o, ez, own_layer, W, ez + 2);
+#endif
+        emit_plane(o, ez, zslot, zslot, own_layer, W, ez + 2);
     };
 
-    // prologue: planes ez_begin and ez_begin + 1 into LDS (requested together), the lower one staged
-    // constant planes (absent nu: the field 1, scaled; keep stays in registers when there is no condition) and the halo entries no lane group writes
-    for (int i = tid; i < 2 * 17 * LP; i += 256) {
-        if constexpr (!HAS_NU) (&Ln[0][0][0])[i] = k.snu;
-        if constexpr (!F_ARR || LOADV) (&Lf[0][0][0])[i] = 0.f;
-    }
-    __syncthreads();
-    RawNodes W;
+    // prologue: planes ez_begin (slot 0) and ez_begin + 1 (slot 1) into LDS (requested together), the lower one staged
+    // TWO planes are in flight per thread (round 4: with one, the launch held ~6 MB in flight over the whole chip -- by Little's law 2.9 TB/s at the
+    // ~2 us a loaded memory system takes, which is what it ran at: profiles/r4_stamp3d_cf.txt): WA carries the even, WB the odd planes after the first
+    RawNodes WA, WB;
     {
-        RawNodes W0;
+        RawNodes& W0 = WA;
+        RawNodes& W = WB;
         if constexpr (HAS_F) {         // the forcing of the two planes before the first published one's upper neighbour
             const unsigned zm = (unsigned)max(ez_begin - 1, 0) * npl, z0 = (unsigned)ez_begin * npl;
             fh0 = ld_pair(sb.f, zm + own_off); fh1 = ld_pair(sb.f, z0 + own_off);
@@ -460,13 +476,15 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         }
         plane_request(ez_begin, W0);
         plane_request(ez_begin + 1, W);
-        plane_publish(W0, ez_begin);
-        plane_publish(W, ez_begin + 1);
+        plane_publish(W0, ez_begin, 0);
+        plane_publish(W, ez_begin + 1, 1);
+        plane_request(ez_begin + 2, WA);
+        plane_request(ez_begin + 3, WB);
     }
     __syncthreads();
     {
         v2f F0[2][2];
-        plane_gather(ez_begin, SA, F0);
+        plane_gather(0, SA, F0);
         // the first plane's own terms (they matter for the mesh's bottom plane only: every other strip recomputes its first layer for the plane above)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -480,8 +498,8 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         }
         if constexpr (HAS_F) {
             const v2f s = vfma(F0[1][1], SA.U[1][1], vfma(F0[1][0], SA.U[1][0], vfma(F0[0][1], SA.U[0][1], F0[0][0] * SA.U[0][0])));
-            const v2f cnt = cf3_usel_lt(ez_begin, ez_own, 0.f, 1.f) * okown;
-            e2_acc2 = vfma(cnt, s, e2_acc2);
+            const v2f cs = (cf3_usel_lt(ez_begin, ez_own, 0.f, 1.f) * okown) * s;
+            e2_acc += cs.x + cs.y;
         }
     }
     __syncthreads();              // every thread has read plane ez_begin before the first layer publishes plane ez_begin + 2 into its slot
@@ -492,27 +510,27 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     v2f FU[2][2];
 #pragma nounroll
     for (; ez + 1 < ez_end; ez += 2) {
-        plane_request(ez + 2, W);                 // lands while this layer is computed; published before the layer's barrier
+        plane_gather(1, SB, FU);
+        DN_STAMP(stamp_B);
+        layer(ez, 0, SA, SB, FU, &WA);            // publishes plane ez + 2 (requested two layers ago) before its barrier
+        DN_STAMP(stamp_E);
+        plane_request(ez + 4, WA);
         flush_store();
         DN_STAMP(stamp_A);
-        plane_gather(ez + 1, SB, FU);
+        plane_gather(0, SA, FU);
         DN_STAMP(stamp_B);
-        layer(ez, SA, SB, FU, &W);
+        layer(ez + 1, 1, SB, SA, FU, &WB);
         DN_STAMP(stamp_E);
-        plane_request(ez + 3, W);
+        plane_request(ez + 5, WB);
         flush_store();
         DN_STAMP(stamp_A);
-        plane_gather(ez + 2, SA, FU);
-        DN_STAMP(stamp_B);
-        layer(ez + 1, SB, SA, FU, &W);
-        DN_STAMP(stamp_E);
 #if defined(DN_STAMP3D)
         stamp_n += 2;
 #endif
     }
     // the last strip owns the top boundary plane: only the layer below contributes -- take back one of the plane's two products.  (Called on SA
     // or SB by name: selecting between the two states through a reference would put both into scratch memory.)
-    auto top_plane = [&](const PlaneC& Tp) {
+    auto top_plane = [&](const PlaneC& Tp, int zslot) {
         v2f GX[2], GY[2], o[2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -520,18 +538,18 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
             GY[j] = vfma(-k.kappa, (Tp.V[0][j] + Tp.V[1][j]) * Tp.CY[j], cY[j]);
         }
         plane_adjoint(GX, GY, cU, o);
-        emit_plane(o, p.nz - 1, true, nullptr, 0);
+        emit_plane(o, p.nz - 1, zslot, zslot, true, nullptr, 0);
         flush_store();
     };
     if (ez < ez_end) {
         flush_store();
-        plane_gather(ez + 1, SB, FU);
-        layer(ez, SA, SB, FU, nullptr);
+        plane_gather(1, SB, FU);
+        layer(ez, 0, SA, SB, FU, nullptr);
         flush_store();
-        if (ez_end == p.nelz) top_plane(SB);
+        if (ez_end == p.nelz) top_plane(SB, 1);
     } else {
         flush_store();
-        if (ez_end == p.nelz) top_plane(SA);
+        if (ez_end == p.nelz) top_plane(SA, 0);
     }
 #if defined(DN_STAMP3D)
     if (tid == 0) {                               // wave 0 of every workgroup (tools/stamp3d.py)
@@ -547,9 +565,8 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     }
 #endif
     if (p.want_sums) {
-        const float e2_acc = e2_acc2.x + e2_acc2.y, sq_acc = sq_acc2.x + sq_acc2.y;
         // sum_a u_a out_a = wscale ( alpha sum nu |grad u|^2 - beta sum f u ): this thread's share of the stiffness sum (the identity holds for the total)
-        const float e1_acc = ((ut_acc.x + ut_acc.y) * k.inv_esc + k.beta * e2_acc) * k.inv_alpha;
+        const float e1_acc = (ut_acc * k.inv_esc + k.beta * e2_acc) * k.inv_alpha;
         finish_sums(p, e1_acc, e2_acc, sq_acc, tid, 256, red, &last_flag, (double)p.T.esc);
     }
 }
