@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     // thread is one of two per-thread byte offsets (its node column in a row, its pair slot) plus a compile-time constant: the plane slots alternate
     // with the layers of the two-layer loop body and are literals there; all of a gather's offsets lie within the reach of the read2 offset fields.
     constexpr int HALF = 18, LP = 2 * HALF, ROW = 3 * LP + 4, PLANE = 17 * ROW;      // (rows of 112 floats: consecutive thread rows land on the other 16 banks)
-    constexpr int OFF_U = 0, OFF_N = LP, OFF_F = 2 * LP, OFF_K = 2 * PLANE, OFF_X = OFF_K + 2 * 512, LDS_FLOATS = OFF_X + 2 * 512;
+    constexpr int OFF_U = 0, OFF_N = LP, OFF_F = 2 * LP, OFF_K = 2 * PLANE, OFF_X = OFF_K + 4 * 512, LDS_FLOATS = OFF_X + 2 * 512;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];      // u' | nu * snu | f' or the load vector, per row;  keep of the own pairs;  hand-over slots
     typedef __attribute__((address_space(3))) float* lds_fptr;
     lds_fptr const lds_own = (lds_fptr)(lds + ty * ROW + tx);           // E[tx] of the thread's node row (field 0, slot 0); O[tx] is HALF floats on
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
             lds_wr2(lds_own, slot * PLANE + OFF_N, slot * PLANE + OFF_N + HALF, nr.x, nr.y);
         }
         if constexpr (F_ARR) lds_wr2(lds_own, slot * PLANE + OFF_F, slot * PLANE + OFF_F + HALF, fz.x, fz.y);
-        if constexpr (IMG || BOX) lds_st2(lds_pair, OFF_K + slot * 512, k0, k1);
+        if constexpr (IMG || BOX) *reinterpret_cast<float2*>(lds_pair + (OFF_K + (zpl & 3) * 512) * 4) = make_float2(k0, k1);
         if (halo_lane) {
             if constexpr (IMG || BOX) {
                 float kh;
@@ -294,34 +294,42 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     // two nodes: the element arithmetic runs on packed fp32 instructions, one per pair.
     // In-plane stage of one node plane, per element (t = lerp coordinate on the element face, Gauss points t0, t1):
     //   BX[j] = du/dx at y = t_j (constant in x),  CY[i] = du/dy at x = t_i,  U[j][i] = u(t_i, t_j),  V[j][i] = nu'(t_i, t_j)
-    struct PlaneC { v2f BX[2], CY[2], U[2][2], V[2][2]; };
+    struct PlaneC { v2f BX[2], CY[2], U[2][2], V[2][2], own; };       // own: u' at the thread's own node pair (= the element pair's lower-left nodes)
     auto stage_vals = [&](const v2f v00, const v2f v10, const v2f v01, const v2f v11, v2f (&G)[2][2]) {
         const v2f dx0 = v10 - v00, dx1 = v11 - v01, dy0 = v01 - v00, xy = dx1 - dx0;
         const v2f A0 = vfma(k.t0, dy0, v00), A1 = vfma(k.t1, dy0, v00), B0 = vfma(k.t0, xy, dx0), B1 = vfma(k.t1, xy, dx0);
         G[0][0] = vfma(k.t0, B0, A0); G[0][1] = vfma(k.t1, B0, A0);
         G[1][0] = vfma(k.t0, B1, A1); G[1][1] = vfma(k.t1, B1, A1);
     };
-    auto plane_gather = [&](int slot, PlaneC& S, v2f (&F)[2][2]) {
-        // the four node pairs of the thread's two elements in one field plane: (x0, x0 + 1), (x0 + 1, x0 + 2) of node rows ty and ty + 1
-        // Inline asm: the compiler sorts the two offsets of a ds_read2_b32 it forms by address, which delivers (O[tx], E[tx + 1]) swapped and costs two
-        // v_mov per pair.  It does not count asm LDS accesses, so the waits are written here: "at most N LGKM operations outstanding" -- LDS accesses
-        // complete in order, so the first 12 - N reads of the plane have landed whatever else (scalar loads, the compiler's own LDS accesses) is counted
-        const unsigned bu = (unsigned)(uintptr_t)(slot ? lds_own_b1 : lds_own_b0);
+    // The four node pairs of the thread's two elements in one field plane: (x0, x0 + 1), (x0 + 1, x0 + 2) of node rows ty and ty + 1, three fields.
+    // gather_issue only ISSUES the reads (right after the barrier that published the plane, a whole finish + publish + request phase before they are
+    // needed); gather_stage waits for them field by field and stages.
+    // Inline asm: the compiler sorts the two offsets of a ds_read2_b32 it forms by address, which delivers (O[tx], E[tx + 1]) swapped and costs two
+    // v_mov per pair.  It does not count asm LDS accesses, so the waits are written here: "at most N LGKM operations outstanding".  LDS accesses
+    // complete in order, so once at most N are outstanding every LDS access but the last N issued has landed, whatever else (scalar loads) is
+    // counted with them: the waits below name how many of the gather's own reads were issued AFTER the ones they wait for.
+    struct RawPairs { v2f u00, u10, u01, u11, n00, n10, n01, n11, f00, f10, f01, f11; };
+    RawPairs RP;
 #define CF3_PAIRS(off, v00, v10, v01, v11)                                                                                                   \
     asm volatile("ds_read2_b32 %0, %4 offset0:%5 offset1:%6\n\tds_read2_b32 %1, %4 offset0:%6 offset1:%7\n\t"                                   \
                  "ds_read2_b32 %2, %4 offset0:%8 offset1:%9\n\tds_read2_b32 %3, %4 offset0:%9 offset1:%10"                                       \
                  : "=&v"(v00), "=&v"(v10), "=&v"(v01), "=&v"(v11)                                                                                \
                  : "v"(bu), "n"(off), "n"((off) + HALF), "n"((off) + 1), "n"((off) + ROW), "n"((off) + ROW + HALF), "n"((off) + ROW + 1))
-#define CF3_LDS_WAIT(N, q0, q1, q2, q3) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3))
+    auto gather_issue = [&](int slot) {
+        const unsigned bu = (unsigned)(uintptr_t)(slot ? lds_own_b1 : lds_own_b0);
+        CF3_PAIRS(OFF_U, RP.u00, RP.u10, RP.u01, RP.u11);
+        if constexpr (HAS_NU) CF3_PAIRS(OFF_N, RP.n00, RP.n10, RP.n01, RP.n11);
+        if constexpr (HAS_F) CF3_PAIRS(OFF_F, RP.f00, RP.f10, RP.f01, RP.f11);
+    };
+#undef CF3_PAIRS
+    auto gather_stage = [&](PlaneC& S, v2f (&F)[2][2]) {
+        constexpr int LATER = 0;       // (LDS accesses the wave issues after the gather's may or may not exist: none are assumed)
         constexpr int NF = 1 + (HAS_NU ? 1 : 0) + (HAS_F ? 1 : 0);
-        v2f u00, u10, u01, u11, n00, n10, n01, n11, f00, f10, f01, f11;
-        CF3_PAIRS(OFF_U, u00, u10, u01, u11);
-        if constexpr (HAS_NU) CF3_PAIRS(OFF_N, n00, n10, n01, n11);
-        if constexpr (HAS_F) CF3_PAIRS(OFF_F, f00, f10, f01, f11);
-        if constexpr (NF == 3) CF3_LDS_WAIT(8, u00, u10, u01, u11);
-        else if constexpr (NF == 2) CF3_LDS_WAIT(4, u00, u10, u01, u11);
-        else CF3_LDS_WAIT(0, u00, u10, u01, u11);
+#define CF3_LDS_WAIT(N, q0, q1, q2, q3) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "n"((N) > 15 ? 15 : (N)))
+        CF3_LDS_WAIT(4 * (NF - 1) + LATER, RP.u00, RP.u10, RP.u01, RP.u11);
         {
+            const v2f u00 = RP.u00, u10 = RP.u10, u01 = RP.u01, u11 = RP.u11;
+            S.own = u00;
             const v2f dx0 = u10 - u00, dx1 = u11 - u01, dy0 = u01 - u00, xy = dx1 - dx0;
             S.BX[0] = vfma(k.t0, xy, dx0); S.BX[1] = vfma(k.t1, xy, dx0);
             S.CY[0] = vfma(k.t0, xy, dy0); S.CY[1] = vfma(k.t1, xy, dy0);
@@ -330,19 +338,16 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
             S.U[1][0] = vfma(k.t0, S.BX[1], A1); S.U[1][1] = vfma(k.t1, S.BX[1], A1);
         }
         if constexpr (HAS_NU) {
-            if constexpr (HAS_F) CF3_LDS_WAIT(4, n00, n10, n01, n11);
-            else CF3_LDS_WAIT(0, n00, n10, n01, n11);
-            stage_vals(n00, n10, n01, n11, S.V);
+            CF3_LDS_WAIT((HAS_F ? 4 : 0) + LATER, RP.n00, RP.n10, RP.n01, RP.n11);
+            stage_vals(RP.n00, RP.n10, RP.n01, RP.n11, S.V);
         }
         if constexpr (HAS_F) {
-            CF3_LDS_WAIT(0, f00, f10, f01, f11);
-            stage_vals(f00, f10, f01, f11, F);
+            CF3_LDS_WAIT(LATER, RP.f00, RP.f10, RP.f01, RP.f11);
+            stage_vals(RP.f00, RP.f10, RP.f01, RP.f11, F);
         }
 #undef CF3_LDS_WAIT
-#undef CF3_PAIRS
         __builtin_amdgcn_sched_barrier(0);
     };
-
     PlaneC SA, SB;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -367,7 +372,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         o[0][1] = okv * o10; o[1][1] = okv * g_xy; o[1][0] = okv * o01; o[0][0] = okv * (g_u00 - o10 - g_dy0);
     };
 
-    const unsigned out_row = (unsigned)ey * (unsigned)p.nx;
+    const unsigned out_base = (unsigned)ey * (unsigned)p.nx + (unsigned)x0;     // the own pair's offset in a plane of the output
     const int from_left = (int)(((unsigned)tid - 1u) & 63u) << 2;
     const float nfirst = tx > 0 ? 1.f : 0.f;
     float2 pend_v = make_float2(0.f, 0.f);
@@ -377,28 +382,42 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         if (pend_st) st_at<float2>(sb.out, pend_off, pend_v);
         pend_st = false;
     };
-    // o[node row][node column of the element]: contributions of the thread's two elements (.x, .y) to their 2 x 2 nodes in the plane being
-    // finished.  The thread's node columns: c0 = o[.][0].x (+ the left thread's o[.][1].y), c1 = o[.][1].x + o[.][0].y; o[.][1].y goes right.
-    // zslot: the LDS slot of plane z (and of the plane published here, two planes on); xslot: the hand-over slot of this call (they alternate)
-    auto emit_plane = [&](const v2f (&o)[2][2], int z, int zslot, int xslot, bool owned_plane, const RawNodes* W, int zpub) {
+    // One element layer between the staged plane L (lower, plane ez, LDS slot zslot) and the plane above (slot 1 - zslot), whose node pairs were
+    // requested from LDS right after the previous layer's barrier.  Order of a layer (every step overlaps the latencies of the ones before it):
+    //   1  request the node pairs of the upper plane from LDS (asm, not waited for yet); read the own pair's load vector of plane ez
+    //   2  publish plane ez + 2 (requested from memory two layers ago) into slot zslot: every thread gathered plane ez before the previous barrier
+    //   3  request plane ez + 4 from memory into the raw set just published; the deferred store of plane ez - 1
+    //   4  stage the upper plane (its LDS reads have had steps 2-3 to land), element arithmetic, adjoint of the in-plane stage
+    //   5  hand-over: right-hand contributions to the lane on the right (ds_bpermute), the upper node row's to the thread above (LDS slot)
+    //   6  ONE barrier (LDS only): it publishes plane ez + 2 and the hand-over slots
+    //   7  read the hand-over slot and the own pair's keep
+    //   8  finish the own node pair of plane ez: sums, Dirichlet rows, value to store
+    // o[node row][node column of the element]: contributions of the thread's two elements (.x, .y) to their 2 x 2 nodes.  The thread's node columns:
+    // c0 = o[.][0].x (+ the left thread's o[.][1].y), c1 = o[.][1].x + o[.][0].y; o[.][1].y goes right.
+    // (the own pair's u' is the first pair of the plane's gather, carried from there; keep lies in a four-slot array of its own -- plane & 3 -- and is
+    // read when it is needed; only the load vector has to be taken from the plane's slot before step 2)
+    struct OwnVals { v2f b; };
+    auto own_read = [&](int zslot, OwnVals& ov) {
+        ov.b = v2f{0.f, 0.f};
+        if constexpr (LOADV) ov.b = lds_rd2(lds_own, zslot * PLANE + OFF_F, zslot * PLANE + OFF_F + HALF);       // the load vector at the own node pair
+    };
+    // steps 5-8
+    auto emit_plane = [&](const v2f (&o)[2][2], const v2f uown, const OwnVals& ov, int z, int zslot, bool owned_plane) {
         DN_STAMP(stamp_C);
-        // keep and the value of the own node pair in the plane being finished: re-read from the thread's own LDS entries (issued BEFORE this call's
-        // publish overwrites the entries of the same parity -- a wave's LDS accesses execute in order -- and landing under the barrier)
-        const v2f uown = lds_rd2(lds_own, zslot * PLANE + OFF_U, zslot * PLANE + OFF_U + HALF);
-        v2f keep = {1.f, 1.f}, bown = {0.f, 0.f};
-        if constexpr (IMG || BOX) keep = lds_ld2(lds_pair, OFF_K + zslot * 512);
-        if constexpr (LOADV) bown = lds_rd2(lds_own, zslot * PLANE + OFF_F, zslot * PLANE + OFF_F + HALF);       // the load vector at the own node pair
         const float left0 = cf3_from_left(o[0][1].y, from_left, nfirst);
-        lds_st2(lds_pair, OFF_X + xslot * 512, o[1][0].x + cf3_from_left(o[1][1].y, from_left, nfirst), o[1][1].x + o[1][0].y);
-        if (W != nullptr) plane_publish(*W, zpub, zslot);
+        lds_st2(lds_pair, OFF_X + zslot * 512, o[1][0].x + cf3_from_left(o[1][1].y, from_left, nfirst), o[1][1].x + o[1][0].y);
 #ifdef DN_CF3_ABL_BAR                      // timing experiment only (results are wrong): no workgroup barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
         DN_STAMP(stamp_D);
+        v2f up = {0.f, 0.f};
+        if (ty > 0) up = lds_ld2(lds_pair, OFF_X + zslot * 512 - 32);       // the hand-over of the thread one node row below (tid - 16)
+        v2f keep = {1.f, 1.f};
+        if constexpr (IMG || BOX) keep = lds_ld2(lds_pair + (z & 3) * 2048, OFF_K);
         v2f t = {o[0][0].x + left0, o[0][1].x + o[0][0].y};
-        if (ty > 0) t += lds_ld2(lds_pair, OFF_X + xslot * 512 - 32);       // the hand-over of the thread one node row below (tid - 16)
+        t += up;
         const bool st = owned_plane && owner && noderow_ok;
         // the sums take the owned nodes only: factor 1 / 0 (threads beyond the mesh in x hold clamped duplicates with contributions 0; the load
         // vector's share needs the explicit test)
@@ -406,7 +425,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         if constexpr (LOADV) {
             // out_a -= beta * wscale * b_a,  sum f u = sum_a u_a b_a (u after the Dirichlet conditions): one FMA each per owned node
             const float inm = (st && x0 < p.nx) ? 1.f : 0.f;
-            const v2f bm = inm * bown;
+            const v2f bm = inm * ov.b;
             t = vfma(k.nbw, bm, t);
             const v2f ub = uown * bm;
             e2_acc += ub.x + ub.y;
@@ -414,15 +433,29 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         t *= stf;
         const v2f tu = t * uown;               // sum_a u_a out_a, before the Dirichlet rows are zeroed
         ut_acc += tu.x + tu.y;
-        t *= keep;
+        if constexpr (IMG || BOX) t *= keep;
         sq_acc = fmaf(t.x, t.x, fmaf(t.y, t.y, sq_acc));
         pend_v = make_float2(t.x * p.out_scale, t.y * p.out_scale);
-        pend_off = (unsigned)z * npl + out_row + (unsigned)x0;
+        pend_off = (unsigned)z * npl + out_base;
         pend_st = st && sb.out != nullptr && x0 < p.nx;
     };
-    // one element layer between the staged planes L (lower, plane ez) and Up (plane ez + 1, its forcing stage F): finishes plane ez
-    auto layer = [&](int ez, int zslot, const PlaneC& L, const PlaneC& Up, const v2f (&F)[2][2], const RawNodes* W) {
+    // W: the raw set holding plane ez + 2 (nullptr: the strip's last layers publish and request nothing)
+    auto layer = [&](int ez, int zslot, const PlaneC& L, PlaneC& Up, RawNodes* W) {
         const bool own_layer = ez >= ez_own;
+        // (the reads are issued and waited for inside ONE layer: carried over the loop's back edge, their target registers could be copied by the
+        // compiler before the data has landed -- it does not know that an asm LDS read completes later)
+        gather_issue(1 - zslot);
+        OwnVals ov;
+        own_read(zslot, ov);
+        if (W != nullptr) {
+            plane_publish(*W, ez + 2, zslot);
+            plane_request(ez + 4, *W);
+        }
+        flush_store();
+        DN_STAMP(stamp_A);
+        v2f F[2][2];
+        gather_stage(Up, F);
+        DN_STAMP(stamp_B);
         v2f GX[2], GY[2], GU[2][2], Sz[2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -456,10 +489,8 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         }
         v2f o[2][2];
         plane_adjoint(GX, GY, GU, o);
-#ifndef DN_CF3_NOSB
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        emit_plane(o, ez, zslot, zslot, own_layer, W, ez + 2);
+        emit_plane(o, L.own, ov, ez, zslot, own_layer);
+        DN_STAMP(stamp_E);
     };
 
     // prologue: planes ez_begin (slot 0) and ez_begin + 1 (slot 1) into LDS (requested together), the lower one staged
@@ -484,7 +515,8 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     __syncthreads();
     {
         v2f F0[2][2];
-        plane_gather(0, SA, F0);
+        gather_issue(0);
+        gather_stage(SA, F0);
         // the first plane's own terms (they matter for the mesh's bottom plane only: every other strip recomputes its first layer for the plane above)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -502,28 +534,16 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
             e2_acc += cs.x + cs.y;
         }
     }
-    __syncthreads();              // every thread has read plane ez_begin before the first layer publishes plane ez_begin + 2 into its slot
+    // every thread has read plane ez_begin (slot 0) before the first layer publishes plane ez_begin + 2 into that slot
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int ez = ez_begin;
 #if defined(DN_STAMP3D)
     stamp_last = __builtin_amdgcn_s_memtime();
 #endif
-    v2f FU[2][2];
 #pragma nounroll
     for (; ez + 1 < ez_end; ez += 2) {
-        plane_gather(1, SB, FU);
-        DN_STAMP(stamp_B);
-        layer(ez, 0, SA, SB, FU, &WA);            // publishes plane ez + 2 (requested two layers ago) before its barrier
-        DN_STAMP(stamp_E);
-        plane_request(ez + 4, WA);
-        flush_store();
-        DN_STAMP(stamp_A);
-        plane_gather(0, SA, FU);
-        DN_STAMP(stamp_B);
-        layer(ez + 1, 1, SB, SA, FU, &WB);
-        DN_STAMP(stamp_E);
-        plane_request(ez + 5, WB);
-        flush_store();
-        DN_STAMP(stamp_A);
+        layer(ez, 0, SA, SB, &WA);                // publishes plane ez + 2 (requested two layers ago), requests plane ez + 4
+        layer(ez + 1, 1, SB, SA, &WB);
 #if defined(DN_STAMP3D)
         stamp_n += 2;
 #endif
@@ -532,19 +552,19 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     // or SB by name: selecting between the two states through a reference would put both into scratch memory.)
     auto top_plane = [&](const PlaneC& Tp, int zslot) {
         v2f GX[2], GY[2], o[2][2];
+        OwnVals ov;
+        own_read(zslot, ov);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             GX[j] = vfma(-k.kappa, (Tp.V[j][0] + Tp.V[j][1]) * Tp.BX[j], cX[j]);
             GY[j] = vfma(-k.kappa, (Tp.V[0][j] + Tp.V[1][j]) * Tp.CY[j], cY[j]);
         }
         plane_adjoint(GX, GY, cU, o);
-        emit_plane(o, p.nz - 1, zslot, zslot, true, nullptr, 0);
+        emit_plane(o, Tp.own, ov, p.nz - 1, zslot, true);
         flush_store();
     };
     if (ez < ez_end) {
-        flush_store();
-        plane_gather(1, SB, FU);
-        layer(ez, 0, SA, SB, FU, nullptr);
+        layer(ez, 0, SA, SB, nullptr);
         flush_store();
         if (ez_end == p.nelz) top_plane(SB, 1);
     } else {
