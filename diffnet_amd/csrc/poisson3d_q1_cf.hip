@@ -48,6 +48,9 @@ struct Cf3Consts {
     float inv_esc, beta, inv_alpha;
 };
 
+#ifndef DN_CF3_PF
+#define DN_CF3_PF 1                   // planes in flight per thread (raw register sets): 1, or 2 (9 VGPRs more; measured equal: profiles/r4_3d_cf_times.txt)
+#endif
 #ifndef DN_Q1CF_WAVES
 #define DN_Q1CF_WAVES 3               // waves per SIMD asked of the compiler (<= 168 VGPRs)
 #endif
@@ -118,7 +121,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     const v2f okv = {(ey < p.nely && x0 < p.nelx) ? 1.f : 0.f, (ey < p.nely && x0 + 1 < p.nelx) ? 1.f : 0.f};
     const v2f okown = owner ? okv : zero2;         // elements this workgroup counts in the element sums
 #if defined(DN_STAMP3D)
-    unsigned long long stamp_A = 0, stamp_B = 0, stamp_C = 0, stamp_D = 0, stamp_E = 0, stamp_n = 0, stamp_last = 0;
+    unsigned long long stamp_A = 0, stamp_A1 = 0, stamp_B = 0, stamp_C = 0, stamp_D = 0, stamp_E = 0, stamp_n = 0, stamp_last = 0;
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -449,7 +452,8 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         own_read(zslot, ov);
         if (W != nullptr) {
             plane_publish(*W, ez + 2, zslot);
-            plane_request(ez + 4, *W);
+            DN_STAMP(stamp_A1);
+            plane_request(ez + 2 + DN_CF3_PF, *W);
         }
         flush_store();
         DN_STAMP(stamp_A);
@@ -494,8 +498,8 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     };
 
     // prologue: planes ez_begin (slot 0) and ez_begin + 1 (slot 1) into LDS (requested together), the lower one staged
-    // TWO planes are in flight per thread (round 4: with one, the launch held ~6 MB in flight over the whole chip -- by Little's law 2.9 TB/s at the
-    // ~2 us a loaded memory system takes, which is what it ran at: profiles/r4_stamp3d_cf.txt): WA carries the even, WB the odd planes after the first
+    // DN_CF3_PF planes are in flight per thread: the plane published at the start of a layer was requested DN_CF3_PF layers earlier (with two, WA
+    // carries the even and WB the odd planes after the first; measured equal to one, which is the default)
     RawNodes WA, WB;
     {
         RawNodes& W0 = WA;
@@ -510,7 +514,9 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         plane_publish(W0, ez_begin, 0);
         plane_publish(W, ez_begin + 1, 1);
         plane_request(ez_begin + 2, WA);
+#if DN_CF3_PF == 2
         plane_request(ez_begin + 3, WB);
+#endif
     }
     __syncthreads();
     {
@@ -543,7 +549,11 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
 #pragma nounroll
     for (; ez + 1 < ez_end; ez += 2) {
         layer(ez, 0, SA, SB, &WA);                // publishes plane ez + 2 (requested two layers ago), requests plane ez + 4
+#if DN_CF3_PF == 2
         layer(ez + 1, 1, SB, SA, &WB);
+#else
+        layer(ez + 1, 1, SB, SA, &WA);
+#endif
 #if defined(DN_STAMP3D)
         stamp_n += 2;
 #endif
@@ -577,7 +587,7 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         if (slot < 8192u) {
             unsigned long long* d = dn_stamp_buf + slot * 8u;
             const unsigned long long hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
-            d[0] = stamp_A; d[1] = stamp_B; d[2] = stamp_C; d[3] = stamp_D;
+            d[0] = stamp_A | (stamp_A1 << 32); d[1] = stamp_B; d[2] = stamp_C; d[3] = stamp_D;       // A1 (gather issue + publish) in the upper half
             d[4] = stamp_E | ((__builtin_amdgcn_s_memrealtime() - stamp_rt0) << 40);
             d[5] = stamp_n | (hwid << 16) | ((xcc & 0xffull) << 48);
             d[6] = stamp_t0; d[7] = __builtin_amdgcn_s_memtime();

@@ -39,6 +39,8 @@ sh = (hwid >> 12) & 0x1
 se = (hwid >> 13) & 0x7
 rt = (r[:, 4] >> np.uint64(40)).astype(np.float64)          # node-owner build: wave lifetime on the constant 100 MHz clock
 r[:, 4] = r[:, 4] & np.uint64((1 << 40) - 1)
+a1 = (r[:, 0] >> np.uint64(32)).astype(np.float64)            # closed-form kernel (round 4): the part of phase A before the memory requests
+r[:, 0] = r[:, 0] & np.uint64((1 << 32) - 1)
 r = r.astype(np.float64)
 r[:, 5] = (r[:, 5].astype(np.uint64) & np.uint64(0xffff)).astype(np.float64)
 print(f"n={n} B={B} plan={plan or 'default'}: {len(r)} sampled waves, layers per wave in the loop: {r[:,5].mean():.1f}")
@@ -47,6 +49,10 @@ names = ["A request loads+store", "B gather (LDS) + stage", "C layer arithmetic"
 tot = per.sum(1)
 for i, nm in enumerate(names):
     print(f"  {nm:22s} mean {per[:, i].mean():8.0f}  median {np.median(per[:, i]):8.0f}  p10 {np.percentile(per[:, i], 10):8.0f}  p90 {np.percentile(per[:, i], 90):8.0f}  cycles per layer")
+if a1.any():
+    print(f"  (closed-form kernel: of phase A, LDS gather issue + publish {np.mean(a1 / r[:, 5]):.0f}, memory requests + deferred store {np.mean(r[:, 0] / r[:, 5]):.0f})")
+    per[:, 0] += a1 / r[:, 5]
+    tot = per.sum(1)
 print(f"  {'total per layer':22s} mean {tot.mean():8.0f}  median {np.median(tot):8.0f}")
 life = r[:, 7] - r[:, 6]
 if rt.any():
