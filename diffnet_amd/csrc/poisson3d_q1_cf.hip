@@ -458,6 +458,19 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         flush_store();
         DN_STAMP(stamp_A);
         v2f F[2][2];
+#ifdef DN_CF3_ABL_MATH                     // timing experiment only (results are wrong): the memory side alone -- every load, LDS access, hand-over, barrier and store, no element arithmetic
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(RP.u00), "+v"(RP.u10), "+v"(RP.u01), "+v"(RP.u11));
+            v2f acc = RP.u00 + RP.u10 + RP.u01 + RP.u11;
+            if constexpr (HAS_NU) { asm volatile("" : "+v"(RP.n00), "+v"(RP.n10), "+v"(RP.n01), "+v"(RP.n11)); acc += RP.n00 + RP.n10 + RP.n01 + RP.n11; }
+            if constexpr (HAS_F) { asm volatile("" : "+v"(RP.f00), "+v"(RP.f10), "+v"(RP.f01), "+v"(RP.f11)); acc += RP.f00 + RP.f10 + RP.f01 + RP.f11; }
+            v2f oa[2][2] = {{acc, acc * 0.5f}, {acc * 0.25f, acc * 0.125f}};
+            Up.own = RP.u00;
+            emit_plane(oa, L.own, ov, ez, zslot, own_layer);
+            DN_STAMP(stamp_E);
+            return;
+        }
+#endif
         gather_stage(Up, F);
         DN_STAMP(stamp_B);
         v2f GX[2], GY[2], GU[2][2], Sz[2][2];
