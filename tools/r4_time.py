@@ -2,7 +2,7 @@
 """Round-4 timing harness: one fused Poisson launch (2-D or 3-D Q1) over NSETS field sets in rotation, prepared launches back to back,
 steady state.  usage: r4_time.py <2|3> <n> <B> <bc: none|u8|f32|bits|box> [key=value ...]
 keys: sums=1|0|defer|fold (in-kernel final reduction / no sums / per-workgroup partials only / partials folded by the next launch), load=1 (forcing as LoadVector), nsets=4, plan=<PLAN2D|PLAN3D override>,
-      nu=1|0, f=1|0, reps=3, iters=400, tag=<label>, cfg=KEY:VALUE[,...] (dn_config_set).  DN_LIB_PATH selects a variant build."""
+      nu=1|0, f=1|0, pad=<bytes> (stagger the fields' start addresses), reps=3, iters=400, tag=<label>, cfg=KEY:VALUE[,...] (dn_config_set).  DN_LIB_PATH selects a variant build."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffnet_amd import BoxFaces, DiffNet2DFEM, DiffNet3DFEM, LoadVector, PackedMask, _lib, ops
@@ -19,8 +19,24 @@ shape = (B, 1) + (n,) * nsd
 g = torch.Generator().manual_seed(1)
 nsets = int(kv.get("nsets", 4))
 sets = []
+pad = int(kv.get("pad", 0))             # pad=<bytes>: every field starts at a different multiple of this many bytes inside its allocation (array-to-array alignment experiments)
+_slot = [0]
+
+
+def _padded(t):
+    if pad == 0:
+        return t
+    n_el = t.numel()
+    buf = torch.empty(n_el + 16 * (pad // 4), device=dev)
+    off = (_slot[0] % 16) * (pad // 4)
+    _slot[0] += 5
+    v = buf[off:off + n_el].view(t.shape)
+    v.copy_(t)
+    return v
+
+
 for k in range(nsets):
-    u, nu, f = (torch.rand(shape, generator=g).to(dev) for _ in range(3))
+    u, nu, f = (_padded(torch.rand(shape, generator=g).to(dev)) for _ in range(3))
     nu += 0.5
     sets.append((u, nu if kv.get("nu", "1") == "1" else None, f if kv.get("f", "1") == "1" else None))
 bc = torch.zeros(shape, dtype=torch.uint8, device=dev)
