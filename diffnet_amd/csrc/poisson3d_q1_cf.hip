@@ -447,7 +447,9 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         const bool own_layer = ez >= ez_own;
         // (the reads are issued and waited for inside ONE layer: carried over the loop's back edge, their target registers could be copied by the
         // compiler before the data has landed -- it does not know that an asm LDS read completes later)
+#ifndef DN_CF3_ABL_GATHER                  // timing experiment only (with DN_CF3_ABL_MATH; results are wrong): no LDS gather
         gather_issue(1 - zslot);
+#endif
         OwnVals ov;
         own_read(zslot, ov);
         if (W != nullptr) {
@@ -460,6 +462,9 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         v2f F[2][2];
 #ifdef DN_CF3_ABL_MATH                     // timing experiment only (results are wrong): the memory side alone -- every load, LDS access, hand-over, barrier and store, no element arithmetic
         {
+#ifdef DN_CF3_ABL_GATHER
+            RP.u00 = RP.u10 = RP.u01 = RP.u11 = RP.n00 = RP.n10 = RP.n01 = RP.n11 = RP.f00 = RP.f10 = RP.f01 = RP.f11 = L.own;
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(RP.u00), "+v"(RP.u10), "+v"(RP.u01), "+v"(RP.u11));
             v2f acc = RP.u00 + RP.u10 + RP.u01 + RP.u11;
             if constexpr (HAS_NU) { asm volatile("" : "+v"(RP.n00), "+v"(RP.n10), "+v"(RP.n01), "+v"(RP.n11)); acc += RP.n00 + RP.n10 + RP.n01 + RP.n11; }

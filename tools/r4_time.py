@@ -10,12 +10,17 @@ from diffnet_amd import BoxFaces, DiffNet2DFEM, DiffNet3DFEM, LoadVector, Packed
 nsd, n, B, form = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 kv = dict(a.split("=", 1) for a in sys.argv[5:])
 dev = torch.device("cuda:0")
-m = (DiffNet3DFEM(None, domain_size=n, nsd=3) if nsd == 3 else DiffNet2DFEM(None, domain_size=n, ngp_1d=int(kv.get("ngp", 3)))).to(dev)
+sizes = tuple(int(v) for v in kv["sizes"].split(",")) if "sizes" in kv else None      # sizes=nx,ny[,nz]: a non-cubic mesh (n is then ignored)
+if sizes:
+    m = (DiffNet3DFEM(None, domain_size=sizes[0], domain_sizes=sizes, domain_lengths=tuple(float(v - 1) for v in sizes), nsd=3) if nsd == 3 else
+         DiffNet2DFEM(None, domain_size=sizes[0], domain_sizes=sizes, domain_lengths=tuple(float(v - 1) for v in sizes), ngp_1d=int(kv.get("ngp", 3)))).to(dev)
+else:
+    m = (DiffNet3DFEM(None, domain_size=n, nsd=3) if nsd == 3 else DiffNet2DFEM(None, domain_size=n, ngp_1d=int(kv.get("ngp", 3)))).to(dev)
 for c in filter(None, kv.get("cfg", "").split(",")):          # cfg=KEY:VALUE[,KEY:VALUE]: dn_config_set switches (e.g. cfg=Q1_3D_N2:1)
     _lib.config_set(*c.split(":", 1))
 if "plan" in kv:
     _lib.config_set("PLAN3D" if nsd == 3 else "PLAN2D", kv["plan"])
-shape = (B, 1) + (n,) * nsd
+shape = (B, 1) + (tuple(reversed(sizes)) if sizes else (n,) * nsd)
 g = torch.Generator().manual_seed(1)
 nsets = int(kv.get("nsets", 4))
 sets = []
@@ -90,7 +95,7 @@ for _ in range(reps):
     b.record()
     torch.cuda.synchronize()
     ts.append(a.elapsed_time(b) * 1000.0 / iters)
-nodes = B * n ** nsd
+nodes = B * (sizes[0] * sizes[1] * (sizes[2] if nsd == 3 else 1) if sizes else n ** nsd)
 med = sorted(ts)[len(ts) // 2]
-print(f"{kv.get('tag', '')} lib={os.path.basename(os.environ.get('DN_LIB_PATH', 'default'))} {nsd}-D n={n} B={B} bc={form} sums={sums} plan={kv.get('plan', 'default')} cfg={kv.get('cfg', '-')} "
+print(f"{kv.get('tag', '')} sizes={kv.get('sizes', '-')} lib={os.path.basename(os.environ.get('DN_LIB_PATH', 'default'))} {nsd}-D n={n} B={B} bc={form} sums={sums} plan={kv.get('plan', 'default')} cfg={kv.get('cfg', '-')} "
       f"nu={kv.get('nu', '1')} f={kv.get('f', '1')} nsets={nsets}: {med:.2f} us per launch  ({16.0 * nodes / med * 1e-6:.3f} TB/s of 16 B/node)  {[round(t, 2) for t in ts]}", flush=True)
