@@ -207,13 +207,25 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
 #endif
         if constexpr (HAS_NU) W.n = ld_pair(sb.nu, oo);
         if constexpr (F_ARR) W.f = ld_pair(sb.f, zoff_f + own_off);
+#ifdef DN_CF3_ABL_HALO                     // timing experiment only (results are wrong): no halo requests
+        W.h = W.u.x; W.hm[0] = W.hm[1] = 0; W.hmf[0] = W.hmf[1] = 0.f;
+#else
         W.h = halo_src[oh];
+#endif
         if constexpr (IMG) {
             const unsigned ohm = zoff + halo_off;
 #pragma unroll
             for (int kk = 0; kk < NMASK; ++kk) {
-                if constexpr (MASK_F32) { W.mf[kk] = ld_pair(mask32[kk], oo); W.hmf[kk] = ld_at<float>(mask32[kk], ohm); }
-                else { W.m[kk] = ld_at<uint16_t>(mask8[kk], oo); W.hm[kk] = ld_at<uint8_t>(mask8[kk], ohm); }
+#ifdef DN_CF3_ABL_MASK                     // timing experiment only (results are wrong): no mask requests for the own pair
+                W.m[kk] = (uint16_t)(W.u.x == 123.456f); W.mf[kk] = 0.f;
+#else
+                if constexpr (MASK_F32) W.mf[kk] = ld_pair(mask32[kk], oo);
+                else W.m[kk] = ld_at<uint16_t>(mask8[kk], oo);
+#endif
+#ifndef DN_CF3_ABL_HALO
+                if constexpr (MASK_F32) W.hmf[kk] = ld_at<float>(mask32[kk], ohm);
+                else W.hm[kk] = ld_at<uint8_t>(mask8[kk], ohm);
+#endif
             }
         }
     };
@@ -379,10 +391,17 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     const int from_left = (int)(((unsigned)tid - 1u) & 63u) << 2;
     const float nfirst = tx > 0 ? 1.f : 0.f;
     float2 pend_v = make_float2(0.f, 0.f);
+#ifdef DN_CF3_ABL_PUB
+    float abl_sink = 0.f;
+#endif
     unsigned pend_off = 0u;
     bool pend_st = false;
     auto flush_store = [&]() {
+#ifdef DN_CF3_ABL_STORE                    // timing experiment only (results are wrong): nothing is stored
+        if (pend_st && pend_v.x == 123.456f) st_at<float2>(sb.out, pend_off, pend_v);
+#else
         if (pend_st) st_at<float2>(sb.out, pend_off, pend_v);
+#endif
         pend_st = false;
     };
     // One element layer between the staged plane L (lower, plane ez, LDS slot zslot) and the plane above (slot 1 - zslot), whose node pairs were
@@ -407,8 +426,12 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     // steps 5-8
     auto emit_plane = [&](const v2f (&o)[2][2], const v2f uown, const OwnVals& ov, int z, int zslot, bool owned_plane) {
         DN_STAMP(stamp_C);
+#ifdef DN_CF3_ABL_XCH                      // timing experiment only (results are wrong): no lane exchange, no hand-over slot
+        const float left0 = o[0][1].y;
+#else
         const float left0 = cf3_from_left(o[0][1].y, from_left, nfirst);
         lds_st2(lds_pair, OFF_X + zslot * 512, o[1][0].x + cf3_from_left(o[1][1].y, from_left, nfirst), o[1][1].x + o[1][0].y);
+#endif
 #ifdef DN_CF3_ABL_BAR                      // timing experiment only (results are wrong): no workgroup barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
@@ -416,7 +439,9 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
 #endif
         DN_STAMP(stamp_D);
         v2f up = {0.f, 0.f};
+#ifndef DN_CF3_ABL_XCH
         if (ty > 0) up = lds_ld2(lds_pair, OFF_X + zslot * 512 - 32);       // the hand-over of the thread one node row below (tid - 16)
+#endif
         v2f keep = {1.f, 1.f};
         if constexpr (IMG || BOX) keep = lds_ld2(lds_pair + (z & 3) * 2048, OFF_K);
         v2f t = {o[0][0].x + left0, o[0][1].x + o[0][0].y};
@@ -439,6 +464,9 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         if constexpr (IMG || BOX) t *= keep;
         sq_acc = fmaf(t.x, t.x, fmaf(t.y, t.y, sq_acc));
         pend_v = make_float2(t.x * p.out_scale, t.y * p.out_scale);
+#ifdef DN_CF3_ABL_PUB
+        pend_v.x += abl_sink;
+#endif
         pend_off = (unsigned)z * npl + out_base;
         pend_st = st && sb.out != nullptr && x0 < p.nx;
     };
@@ -453,7 +481,14 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         OwnVals ov;
         own_read(zslot, ov);
         if (W != nullptr) {
+#ifndef DN_CF3_ABL_PUB                     // timing experiment only (results are wrong): nothing is published into LDS -- the loaded values only feed the stored value
             plane_publish(*W, ez + 2, zslot);
+#else
+            abl_sink += W->u.x + W->u.y + W->h;
+            if constexpr (HAS_NU) abl_sink += W->n.x + W->n.y;
+            if constexpr (F_ARR) abl_sink += W->f.x + W->f.y;
+            if constexpr (IMG && !MASK_F32) abl_sink += (float)(W->m[0] + W->hm[0]);
+#endif
             DN_STAMP(stamp_A1);
             plane_request(ez + 2 + DN_CF3_PF, *W);
         }
