@@ -4,6 +4,7 @@ include/diffnet_hip.h, host-built tables are bit-identical to the reference's, t
 import glob
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -218,3 +219,17 @@ def test_torch_library_registration_and_fake_shapes():
         out, sums, loss = torch.ops.diffnet_mi.poisson_apply(u, None, None, None, None, None, 0.0, None, None, 0.0,
                                                              *torch_ops.geometry_args(m.geom), 1.0, 1.0, 0.5, 1.0, 1.0, 1.0)
         assert out.shape == u.shape and tuple(sums.shape) == (2,) and sums.dtype == torch.float64 and loss.dim() == 0
+
+
+def test_closed_form_3d_kernel_lds_waits_and_prototype():
+    """The closed-form 3-D Q1 kernel (csrc/poisson3d_q1_cf.hip) reads its node pairs from LDS with inline asm and writes the `s_waitcnt lgkmcnt`
+    for them by hand; tools/check_lds_waits.py disassembles every instantiation (hipcc cross-compiles without a GPU) and verifies that no
+    register of an LDS read is used before a covering wait.  tools/q1cf3d_proto.py is the float64 restatement of the kernel's formulas
+    (monomial stages, closed-form z integration, mass-stencil forcing) checked against the oracle -- DiffNetFEM.py:7-18 + IBN_3D.py:114-136."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_lds_waits.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "violations: 0" in r.stdout and "instantiations: 48" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "q1cf3d_proto.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
