@@ -180,6 +180,15 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
     };
     const bool bxy0[2] = {box_xy(0, x0, ey), box_xy(1, x0, ey)}, bxy1[2] = {box_xy(0, x0 + 1, ey), box_xy(1, x0 + 1, ey)};
     const bool bxyh[2] = {box_xy(0, nx0 + hcol, ny0 + hrow), box_xy(1, nx0 + hcol, ny0 + hrow)};
+    // box faces without a mask image: what the in-plane faces do to a node is the same on every plane -- "fixed", and to which value (the LAST condition
+    // that names one of its faces), worked out once.  Planes on a z face of a condition (two per mesh at most; wave-uniform) take the general path.
+    auto box_fix = [&](const bool (&bx)[2], float& val) {
+        val = bx[1] ? p.bc[1].value : p.bc[0].value;
+        return bx[0] || bx[1];
+    };
+    float bval0 = 0.f, bval1 = 0.f, bvalh = 0.f;
+    const bool bfix0 = box_fix(bxy0, bval0), bfix1 = box_fix(bxy1, bval1), bfixh = box_fix(bxyh, bvalh);
+    const float bkeep0 = bfix0 ? 0.f : 1.f, bkeep1 = bfix1 ? 0.f : 1.f;
 
     struct RawNodes {
         v2f u, n, f;                  // own pair (f: one plane AHEAD of u and nu when it is nodal forcing)
@@ -285,20 +294,32 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
             fz = W.f;
         }
         float u0 = W.u.x, u1 = W.u.y, k0, k1;
-        fix_node(u0, k0, s0, b0);
-        fix_node(u1, k1, s1, b1);
+        bool box_fast = false;
+        if constexpr (BOX && !IMG) {
+            const bool zf0 = ((bfaces[0] & DN_FACE_ZLO) && zc == 0) || ((bfaces[0] & DN_FACE_ZHI) && zc == p.nz - 1);
+            const bool zf1 = ((bfaces[1] & DN_FACE_ZLO) && zc == 0) || ((bfaces[1] & DN_FACE_ZHI) && zc == p.nz - 1);
+            box_fast = !(zf0 || zf1);                        // (wave-uniform)
+        }
+        if (box_fast) {
+            u0 = bfix0 ? bval0 : u0; k0 = bkeep0;
+            u1 = bfix1 ? bval1 : u1; k1 = bkeep1;
+        } else {
+            fix_node(u0, k0, s0, b0);
+            fix_node(u1, k1, s1, b1);
+        }
         lds_wr2(lds_own, slot * PLANE + OFF_U, slot * PLANE + OFF_U + HALF, u0, u1);
         if constexpr (HAS_NU) {
             const v2f nr = k.snu * W.n;
             lds_wr2(lds_own, slot * PLANE + OFF_N, slot * PLANE + OFF_N + HALF, nr.x, nr.y);
         }
         if constexpr (F_ARR) lds_wr2(lds_own, slot * PLANE + OFF_F, slot * PLANE + OFF_F + HALF, fz.x, fz.y);
-        if constexpr (IMG || BOX) *reinterpret_cast<float2*>(lds_pair + (OFF_K + (zpl & 3) * 512) * 4) = make_float2(k0, k1);
+        if constexpr (IMG) *reinterpret_cast<float2*>(lds_pair + (OFF_K + (zpl & 3) * 512) * 4) = make_float2(k0, k1);      // (box faces alone: keep is known per thread)
         if (halo_lane) {
             if constexpr (IMG || BOX) {
                 float kh;
                 float hu = hv;
-                fix_node(hu, kh, sh, bh);
+                if (box_fast) hu = bfixh ? bvalh : hu;
+                else fix_node(hu, kh, sh, bh);
                 hv = hgrp == 0 ? hu : hv;
             }
             halo_lds[slot * PLANE] = hv;
@@ -396,6 +417,8 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
 #endif
     unsigned pend_off = 0u;
     bool pend_st = false;
+    // (The store as one asm block that selects the owning lanes through the exec mask -- no branch, so that the compiler's vmcnt waits for the raw
+    // plane's loads stay exact instead of vmcnt(0) -- was built and measured, with one and two planes in flight: equal, profiles/r4_3d_cf_times.txt.)
     auto flush_store = [&]() {
 #ifdef DN_CF3_ABL_STORE                    // timing experiment only (results are wrong): nothing is stored
         if (pend_st && pend_v.x == 123.456f) st_at<float2>(sb.out, pend_off, pend_v);
@@ -443,7 +466,12 @@ __global__ void __launch_bounds__(256, DN_Q1CF_WAVES) poisson3d_q1_cf_kernel(con
         if (ty > 0) up = lds_ld2(lds_pair, OFF_X + zslot * 512 - 32);       // the hand-over of the thread one node row below (tid - 16)
 #endif
         v2f keep = {1.f, 1.f};
-        if constexpr (IMG || BOX) keep = lds_ld2(lds_pair + (z & 3) * 2048, OFF_K);
+        if constexpr (IMG) keep = lds_ld2(lds_pair + (z & 3) * 2048, OFF_K);
+        if constexpr (BOX && !IMG) {           // in-plane faces: per thread; a plane on a fixed z face: every node
+            const bool zfix = (((bfaces[0] | bfaces[1]) & DN_FACE_ZLO) && z == 0) || (((bfaces[0] | bfaces[1]) & DN_FACE_ZHI) && z == p.nz - 1);
+            const float zk = cf3_usel_lt(0, zfix ? 1 : 0, 0.f, 1.f);
+            keep = v2f{bkeep0 * zk, bkeep1 * zk};
+        }
         v2f t = {o[0][0].x + left0, o[0][1].x + o[0][0].y};
         t += up;
         const bool st = owned_plane && owner && noderow_ok;
