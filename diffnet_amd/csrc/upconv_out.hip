@@ -142,10 +142,10 @@ constexpr int UC_CCH = 64;      // channels staged per pass
 constexpr int UC_TP = 128;      // pixels per tile (44 KB of LDS per workgroup: three workgroups per CU)
 __global__ void __launch_bounds__(256) upconv_bwd_weight_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                                 const float* __restrict__ y, float* __restrict__ part, int B, int C, int h,
-                                                                int w, int act, int tiles_per_wg) {
+                                                                int w, int act, int tiles_per_wg, int vec16) {
     // row strides 16 / 132 floats: the MFMA operand reads (16 lanes along a row, 4 lane groups along k) hit distinct banks
     __shared__ __attribute__((aligned(16))) float S[UC_TP][16];      // [pixel][tap]
-    __shared__ float V[UC_CCH][UC_TP + 4];                            // [channel][pixel]
+    __shared__ __attribute__((aligned(16))) float V[UC_CCH][UC_TP + 4];   // [channel][pixel]
     __shared__ double red[8];
     const int tid = threadIdx.x;
     const int H = 2 * h, W = 2 * w;
@@ -184,13 +184,30 @@ __global__ void __launch_bounds__(256) upconv_bwd_weight_kernel(const float* __r
                     }
                 if (pass == 0) bias_acc += (G[1 * 5 + 1] + G[1 * 5 + 2]) + (G[2 * 5 + 1] + G[2 * 5 + 2]);   // rows 2i, 2i+1
             }
-            const float* ib = in + (size_t)b * C * plane + (size_t)i * w + j;
-            // (unconditional loads of clamped channels, zeroed by an opaque mask: a load in a branch waits for the one before it, see gz_patch)
+            if (vec16) {
+                // planes of a multiple of 128 pixels (the U-Net's shapes): a tile is 128 CONSECUTIVE floats of every channel plane -- 16 bytes per lane,
+                // 8 loads per thread and tile instead of 32 (round 4: the launch was bound by its vector-memory instruction count, 360 -> see profiles)
+                const long p0 = ((long)blockIdx.x * tiles_per_wg + t) * UC_TP;
+                const bool tok = p0 < npix;
+                const float* ib0 = in + (tok ? (size_t)(p0 / (long)plane) * C * plane + (size_t)(p0 % (long)plane) : (size_t)0);
+#pragma unroll
+                for (int kq = 0; kq < (UC_CCH * UC_TP / 4) / 256; ++kq) {
+                    const int idx = tid + 256 * kq, c = idx >> 5, q = idx & 31;
+                    unsigned mk = (tok && c0 + c < C) ? 0xffffffffu : 0u;
+                    asm volatile("" : "+v"(mk));
+                    const float4 v = *reinterpret_cast<const float4*>(ib0 + (size_t)min(c0 + c, C - 1) * plane + 4 * q);
+                    *reinterpret_cast<float4*>(&V[c][4 * q]) = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk),
+                                                                          __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
+                }
+            } else {
+                const float* ib = in + (size_t)b * C * plane + (size_t)i * w + j;
+                // (unconditional loads of clamped channels, zeroed by an opaque mask: a load in a branch waits for the one before it, see gz_patch)
 #pragma unroll 8
-            for (int c = half; c < UC_CCH; c += 2) {
-                unsigned mk = (ok && c0 + c < C) ? 0xffffffffu : 0u;
-                asm volatile("" : "+v"(mk));
-                V[c][pp] = __uint_as_float(__float_as_uint(ib[(size_t)min(c0 + c, C - 1) * plane]) & mk);
+                for (int c = half; c < UC_CCH; c += 2) {
+                    unsigned mk = (ok && c0 + c < C) ? 0xffffffffu : 0u;
+                    asm volatile("" : "+v"(mk));
+                    V[c][pp] = __uint_as_float(__float_as_uint(ib[(size_t)min(c0 + c, C - 1) * plane]) & mk);
+                }
             }
             __syncthreads();
 #pragma unroll 8
@@ -283,8 +300,9 @@ extern "C" int dn_upconv_out_bwd(const float* in, const float* weight, const flo
         if (!in) return DN_E_BADARG;
         int nwg, tpw;
         uc_plan(B * h * w, nwg, tpw);
+        const int vec16 = ((long long)h * w) % UC_TP == 0 && (reinterpret_cast<uintptr_t>(in) % 16) == 0;
         hipLaunchKernelGGL(upconv_bwd_weight_kernel, dim3((unsigned)nwg), dim3(256), 0, s, in, grad_out, act ? out : nullptr, part, (int)B, (int)C,
-                           (int)h, (int)w, act, tpw);
+                           (int)h, (int)w, act, tpw, vec16);
         const int n = (int)C * 16;
         hipLaunchKernelGGL(upconv_wsum_kernel, dim3((unsigned)((n + 1 + 3) / 4)), dim3(256), 0, s, part, grad_weight, grad_bias, nwg, n);
     }
