@@ -8,10 +8,10 @@
 //
 // The memory side is the node-owner form of poisson3d_q1n2_kernel (poisson3d_q1.inl): a 16 x 16 workgroup marches a tile of 32 x 16 elements
 // over R element layers; a thread owns two nodes of a node row (one 8-byte load per field and plane, one 8-byte store) and the two elements to
-// their right; every node is requested once per workgroup and plane and published as a 16-byte record {u', nu', f', keep} in LDS, one LDS-only
-// barrier per layer, contributions to nodes of neighbouring threads handed over through ds_bpermute (x) and an LDS slot (y).  The
-// ARITHMETIC is new.  The round-3 kernel was bound by its instruction count (~260 VALU instructions per thread and layer on packed fp32,
-// VALU busy 73 % of the launch, profiles/r3_stamp3d_n2.txt); this form needs ~150:
+// their right; every node is requested once per workgroup and plane and published into LDS planes (one array per field, even and odd node
+// columns apart), one LDS-only barrier per layer, contributions to nodes of neighbouring threads handed over through ds_bpermute (x) and an LDS
+// slot (y).  The ARITHMETIC is new.  The round-3 kernel was bound by its instruction count (~260 VALU instructions per thread and layer on
+// packed fp32, VALU busy 73 % of the launch, profiles/r3_stamp3d_n2.txt); this form needs ~180 (126 packed):
 //   * in-plane stages in MONOMIAL form: with u(x, y) = u00 + dx0 x + dy0 y + xy x y on an element face, the x-derivative at the y-Gauss points,
 //     the y-derivative at the x-Gauss points and the value at the four in-plane points cost 14 instructions, their adjoint 22 (was 15 + 33);
 //   * the x- and y-flux terms are integrated along z IN CLOSED FORM: for nu and du/dx both linear in z the sum over the two z-Gauss points of
@@ -25,6 +25,10 @@
 //   * the stiffness part of the energy comes from the finished nodal values (sum_a u_a out_a), as in round 3.
 // Results differ from the per-Gauss-point kernels by fp32 rounding only (tools/q1cf3d_proto.py: the same formulas in float64 against the CPU
 // oracle; tests/test_gpu_q1cf3d.py: this kernel against the oracle and against the round-3 kernels).
+// Measured (profiles/r4_3d_cf_times.txt): 256^3 121 -> 95 us, 128^3 26 -> 22 us.  With the arithmetic cut down the launch is bound by its ACCESS
+// PATTERN (89.6 us with every LDS access, hand-over, barrier and all arithmetic removed: pair loads 44.5 + store 22 + mask bytes 7 + halo 16) and,
+// right behind it, by the per-layer chain of publish / hand-over / finish; the DN_CF3_ABL_* switches below are the timing experiments that showed it
+// (their results are wrong by construction; none is defined in the library build).
 #include <cmath>
 
 #include "poisson_common.h"
