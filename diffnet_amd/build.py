@@ -14,8 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffnet_hip.so")
 STAMP = os.path.join(HERE, ".libdiffnet_hip.stamp")
 ARCH = "gfx950"
-SOURCES = ["dn_api.hip", "probe.hip", "poisson_fused.hip", "poisson2d_q1_cf.hip", "poisson2d_q1_g2.hip", "poisson2d_q1_g3.hip", "poisson2d_q1_g4.hip", "poisson3d_q1_g2.hip", "poisson3d_q1_g3.hip", "poisson3d_q1_g4.hip", "poisson3d_q1_cf.hip", "poisson3d_gen.hip", "gauss_pt_eval.hip", "winding.hip", "fdm.hip", "instnorm_act.hip", "fsdt.hip", "upconv_out.hip", "upconv3d_out.hip", "conv3d_wrw.hip", "conv2d_k4s2.hip", "conv2d_k4s2_v2.hip", "conv3d_k4s2.hip", "conv2d_direct.hip"]
-HEADERS = ["dn_common.h", "poisson_elem.h", "poisson_common.h", "poisson2d_q1.inl", "poisson3d_q1.inl", os.path.join("..", "..", "include", "diffnet_hip.h")]
+SOURCES = ["dn_api.hip", "probe.hip", "poisson_fused.hip", "poisson2d_q1_cf.hip", "poisson2d_q1_g2.hip", "poisson2d_q1_g3.hip", "poisson2d_q1_g4.hip", "poisson3d_q1_g2.hip", "poisson3d_q1_g3.hip", "poisson3d_q1_g4.hip", "poisson3d_q1_cf.hip", "poisson3d_gen.hip", "gauss_pt_eval.hip", "winding.hip", "fdm.hip", "instnorm_act.hip", "fsdt.hip", "fsdt_st.hip", "upconv_out.hip", "upconv3d_out.hip", "conv3d_wrw.hip", "conv2d_k4s2.hip", "conv2d_k4s2_v2.hip", "conv3d_k4s2.hip", "conv2d_direct.hip"]
+HEADERS = ["dn_common.h", "fsdt_common.h", "poisson_elem.h", "poisson_common.h", "poisson2d_q1.inl", "poisson3d_q1.inl", os.path.join("..", "..", "include", "diffnet_hip.h")]
 # -amdgpu-sdwa-peephole=0: on gfx950 an SDWA (like a DPP or v_readlane) instruction costs a SIMD ~33 cycles once two or more waves
 # share it -- 14 plain VALU instructions -- so the byte-select forms the peephole creates for mask tests are a large net loss
 # (tools/micro/valu_mem.hip, profiles/r2_valu_mem.txt)

@@ -16,7 +16,7 @@ extern "C" const char* dn_build_info(void) {
 
 // ---- tuning switches: one table, filled from DN_<KEY> when the library is loaded, changed only through dn_config_set ----
 namespace {
-const char* const kKeys[dn::CFG_COUNT] = {"PLAN2D", "PLAN3D", "PLAN_FSDT", "Q1_RULE_KERNEL", "GPE_GATHER", "GPE_TILED", "Q1_3D_T16", "Q1_3D_E1SUM", "FSDT_GENERIC", "Q1_3D_E1", "HANDOVER_SPIN_LIMIT", "CONV2D_V1", "CONV_WRW_WGS", "Q1_3D_N2"};
+const char* const kKeys[dn::CFG_COUNT] = {"PLAN2D", "PLAN3D", "PLAN_FSDT", "Q1_RULE_KERNEL", "GPE_GATHER", "GPE_TILED", "Q1_3D_T16", "Q1_3D_E1SUM", "FSDT_GENERIC", "Q1_3D_E1", "HANDOVER_SPIN_LIMIT", "CONV2D_V1", "CONV_WRW_WGS", "Q1_3D_N2", "FSDT_FORM"};
 char g_cfg[dn::CFG_COUNT][64];
 
 int key_index(const char* key) {

@@ -17,7 +17,7 @@ namespace dn {
 
 // Tuning switches (dn_config_set / DN_<KEY> at load time, dn_api.hip): value of a switch, nullptr when unset.  A plain table
 // lookup -- nothing on the launch path touches the process environment.
-enum ConfigKey : int { CFG_PLAN2D = 0, CFG_PLAN3D, CFG_PLAN_FSDT, CFG_Q1_RULE_KERNEL, CFG_GPE_GATHER, CFG_GPE_TILED, CFG_Q1_3D_T16, CFG_Q1_3D_E1SUM, CFG_FSDT_GENERIC, CFG_Q1_3D_E1, CFG_HANDOVER_SPIN_LIMIT, CFG_CONV2D_V1, CFG_CONV_WRW_WGS, CFG_Q1_3D_N2, CFG_COUNT };
+enum ConfigKey : int { CFG_PLAN2D = 0, CFG_PLAN3D, CFG_PLAN_FSDT, CFG_Q1_RULE_KERNEL, CFG_GPE_GATHER, CFG_GPE_TILED, CFG_Q1_3D_T16, CFG_Q1_3D_E1SUM, CFG_FSDT_GENERIC, CFG_Q1_3D_E1, CFG_HANDOVER_SPIN_LIMIT, CFG_CONV2D_V1, CFG_CONV_WRW_WGS, CFG_Q1_3D_N2, CFG_FSDT_FORM, CFG_COUNT };
 const char* config(ConfigKey k);
 
 __device__ __forceinline__ double wave_sum(double v) {

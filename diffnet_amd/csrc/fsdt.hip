@@ -21,7 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "poisson_common.h"
+#include "fsdt_common.h"
 
 namespace dn {
 
@@ -43,87 +43,6 @@ __device__ __forceinline__ unsigned fs_lds_ld_u(unsigned a) {
 constexpr unsigned FS_SPIN_MAX = 1u << 20;     // bound of every LDS flag poll: a producer that never arrives must not hang the GPU; reaching it poisons the wave's
                                                // outputs and sums with NaN and sets the workspace's sticky error word (dn_workspace_status) -- see poisson2d_q1_cf.hip
 constexpr int FS_CH_MAXW = 12;                 // sub-strips (waves) per chained workgroup: 12 waves = 3 per SIMD at <= 168 VGPRs
-
-struct FsdtParams {
-    float b[4][4], dx[4][4], dy[4][4];     // 1-D tables at the Gauss points (derivatives scaled by 2/h)
-    float w2[4][4];                        // w[jg] * w[ig] * wscale
-    float D11, D12, D22, D66, A44, A55, q;
-    const float* fld[3];                   // w, phi_x, phi_y
-    const float* in_scale;                 // optional 3 device floats: field k is scaled as it is loaded
-    const float* in_num;                   // optional 3 + 3 device floats: field k is scaled by in_num[k] / in_den[k] (0 where in_den[k] <= 0)
-    const float* in_den;
-    float* norms;                          // optional 3 device floats: sqrt of the three sums of squares, written by the last workgroup
-    const void* mask;
-    int mask_is_u8, mask_batched;
-    const float* bcf[3];
-    int bcf_batched[3];
-    float bcv[3];
-    float* out[3];
-    double* part;                          // [3][nblocks] partial sums of squares
-    unsigned* counter;
-    double* sumsq;                         // 3 doubles
-    int nx, ny, nelx, nely, rows_per_strip, want_sums, spin_limit;
-};
-
-// Deterministic in-kernel final reduction of three scalars (same protocol as finish_sums in poisson_common.h).
-__device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&sq)[3], int tid, int nthreads, double* red, int* flag) {
-    const int nblocks = gridDim.x * gridDim.y * gridDim.z;
-    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    double s[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s[k] = block_sum((double)sq[k], red, tid, nthreads);
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) __hip_atomic_store(&p.part[(size_t)k * nblocks + blk], s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int nshard = nblocks < DN_NSHARD ? nblocks : DN_NSHARD;
-        const int shard = blk % nshard;
-        const unsigned in_shard = (unsigned)((nblocks - shard + nshard - 1) / nshard);
-        unsigned* sc = p.counter + 16 * (1 + shard);
-        int last = 0;
-        const unsigned prev = __hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == in_shard - 1) {
-            __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned prev2 = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (prev2 == (unsigned)(nshard - 1)) ? 1 : 0;
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    if (*flag) {
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        // on the critical path of the whole launch: the partials of all three sums are requested eight at a time before any is added
-        // (one L2 round trip per 24 loads instead of per load; same per-thread order of additions: bitwise the same sums)
-        double e3[3] = {0.0, 0.0, 0.0};
-        for (int i0 = tid; i0 < nblocks; i0 += nthreads * 8) {
-            double v[3][8];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = i0 + j * nthreads;
-                    v[k][j] = __hip_atomic_load(&p.part[(size_t)k * nblocks + (i < nblocks ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) e3[k] += (i0 + j * nthreads < nblocks) ? v[k][j] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double e = block_sum(e3[k], red, tid, nthreads);
-            if (tid == 0) {
-                if (p.sumsq) p.sumsq[k] = e;
-                if (p.norms) p.norms[k] = (float)sqrt(e);
-            }
-        }
-        if (tid == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
 
 // One element: nodal values F[k][jb][ib] of the three fields; its nodal residual contributions are ADDED to g[k][jb][ib]
 // (the caller's partially assembled rows: no separate per-element result).
@@ -690,7 +609,7 @@ extern "C" int64_t dn_fsdt_workspace_bytes(const dn_mesh* m) {
     if (fsdt_validate(m) != 0) return DN_E_BADARG;
     const FsdtGeom g = fsdt_plan(m, false), gc = fsdt_plan(m, true);         // either plan fits (un-chained has the most workgroups per strip)
     const int64_t n1 = (int64_t)g.chunks * g.strips * m->batch, n2 = (int64_t)gc.chunks * gc.strips * m->batch;
-    return FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * std::max(n1, n2);
+    return FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * std::max(std::max(n1, n2), fsdt_st_workgroups(m));
 }
 
 extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stream) {
@@ -702,7 +621,11 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     const bool want_red = a->sumsq || a->norms;
     const bool any_bcf = a->bc_mask && (a->bc_field[0] || a->bc_field[1] || a->bc_field[2]);
     const FsdtGeom g = fsdt_plan(m, !any_bcf);
-    const int64_t nwg = (int64_t)g.chunks * g.strips * m->batch;
+    // round 4: the assembled-stencil form (fsdt_st.hip) is the default; dn_config_set("FSDT_FORM", "elem"), "FSDT_GENERIC" or a chained
+    // launch plan ("PLAN_FSDT" "64,R,W") keep the element form of rounds 1-3
+    const char* form = config(CFG_FSDT_FORM);
+    const bool stencil = !(form && form[0] == 'e') && config(CFG_FSDT_GENERIC) == nullptr && g.W == 1;
+    const int64_t nwg = stencil ? fsdt_st_workgroups(m) : (int64_t)g.chunks * g.strips * m->batch;
     if (want_red && (!a->workspace || a->workspace_bytes < FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
 
     FsdtParams pp;
@@ -731,6 +654,12 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     pp.want_sums = want_red ? 1 : 0;
     pp.spin_limit = config(CFG_HANDOVER_SPIN_LIMIT) ? std::atoi(config(CFG_HANDOVER_SPIN_LIMIT)) : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (stencil) {
+        rc = fsdt_st_launch(m, a->wscale, pp, s);
+        if (rc) return rc;
+        DN_LAUNCH_CHECK();
+        return 0;
+    }
     switch (m->degree) {
         case 1: rc = fsdt_launch<1>(pp, g, m->ngp, m->batch, false, s); break;
         case 2: {

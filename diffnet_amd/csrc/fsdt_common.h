@@ -1,0 +1,93 @@
+// Shared by the two FSDT kernels (fsdt.hip: element form; fsdt_st.hip: assembled-stencil form): kernel parameters and the
+// deterministic in-kernel reduction of the three sums of squares.
+#pragma once
+#include "poisson_common.h"
+
+namespace dn {
+
+struct FsdtParams {
+    float b[4][4], dx[4][4], dy[4][4];     // 1-D tables at the Gauss points (derivatives scaled by 2/h)
+    float w2[4][4];                        // w[jg] * w[ig] * wscale
+    float D11, D12, D22, D66, A44, A55, q;
+    const float* fld[3];                   // w, phi_x, phi_y
+    const float* in_scale;                 // optional 3 device floats: field k is scaled as it is loaded
+    const float* in_num;                   // optional 3 + 3 device floats: field k is scaled by in_num[k] / in_den[k] (0 where in_den[k] <= 0)
+    const float* in_den;
+    float* norms;                          // optional 3 device floats: sqrt of the three sums of squares, written by the last workgroup
+    const void* mask;
+    int mask_is_u8, mask_batched;
+    const float* bcf[3];
+    int bcf_batched[3];
+    float bcv[3];
+    float* out[3];
+    double* part;                          // [3][nblocks] partial sums of squares
+    unsigned* counter;
+    double* sumsq;                         // 3 doubles
+    int nx, ny, nelx, nely, rows_per_strip, want_sums, spin_limit;
+};
+
+// Deterministic in-kernel final reduction of three scalars (same protocol as finish_sums in poisson_common.h).
+__device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&sq)[3], int tid, int nthreads, double* red, int* flag) {
+    const int nblocks = gridDim.x * gridDim.y * gridDim.z;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    double s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = block_sum((double)sq[k], red, tid, nthreads);
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) __hip_atomic_store(&p.part[(size_t)k * nblocks + blk], s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int nshard = nblocks < DN_NSHARD ? nblocks : DN_NSHARD;
+        const int shard = blk % nshard;
+        const unsigned in_shard = (unsigned)((nblocks - shard + nshard - 1) / nshard);
+        unsigned* sc = p.counter + 16 * (1 + shard);
+        int last = 0;
+        const unsigned prev = __hip_atomic_fetch_add(sc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == in_shard - 1) {
+            __hip_atomic_store(sc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned prev2 = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (prev2 == (unsigned)(nshard - 1)) ? 1 : 0;
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag) {
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        // on the critical path of the whole launch: the partials of all three sums are requested eight at a time before any is added
+        // (one L2 round trip per 24 loads instead of per load; same per-thread order of additions: bitwise the same sums)
+        double e3[3] = {0.0, 0.0, 0.0};
+        for (int i0 = tid; i0 < nblocks; i0 += nthreads * 8) {
+            double v[3][8];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = i0 + j * nthreads;
+                    v[k][j] = __hip_atomic_load(&p.part[(size_t)k * nblocks + (i < nblocks ? i : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e3[k] += (i0 + j * nthreads < nblocks) ? v[k][j] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double e = block_sum(e3[k], red, tid, nthreads);
+            if (tid == 0) {
+                if (p.sumsq) p.sumsq[k] = e;
+                if (p.norms) p.norms[k] = (float)sqrt(e);
+            }
+        }
+        if (tid == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// fsdt_st.hip: the assembled-stencil form
+int fsdt_st_launch(const dn_mesh* m, float wscale, FsdtParams& pp, hipStream_t s);
+int64_t fsdt_st_workgroups(const dn_mesh* m);
+
+}  // namespace dn

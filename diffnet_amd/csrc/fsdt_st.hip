@@ -1,0 +1,440 @@
+// Fused FSDT (Mindlin) plate residuals, ASSEMBLED-STENCIL form (round 4; the element form is fsdt.hip).
+//
+// Same operator as fsdt.hip -- examples/elasticity/single_instance/e1_plate_bending_fsdt.py:128-232 of the reference: Dirichlet
+// substitution, nine Gauss-point evaluations, constitutive law, three weak-form residuals, assembly, Dirichlet rows, Frobenius sums --
+// on a different factorisation.  The constitutive coefficients are constants and the mesh is uniform, so every term of the residuals is
+// a tensor product of two 1-D element matrices of the quadrature rule applied to one nodal field:
+//     M[a][b] = sum_g w_g N_a N_b     K[a][b] = sum_g w_g N_a' N_b'     C[a][b] = sum_g w_g N_a' N_b     (C^T: test value, trial derivative)
+//     R1 = A55 (C_x (x) M_y) phi_x + A55 (K_x (x) M_y) w + A44 (M_x (x) C_y) phi_y + A44 (M_x (x) K_y) w - q l_x (x) l_y
+//     R2 = D11 (K_x (x) M_y) phi_x + D12 (C_x (x) C_y^T) phi_y + D66 (M_x (x) K_y) phi_x + D66 (C_x^T (x) C_y) phi_y + A55 (M_x (x) M_y) phi_x + A55 (C_x^T (x) M_y) w
+//     R3 = D66 (C_x (x) C_y^T) phi_x + D66 (K_x (x) M_y) phi_y + D12 (C_x^T (x) C_y) phi_x + D22 (M_x (x) K_y) phi_y + A44 (M_x (x) M_y) phi_y + A44 (M_x (x) C_y^T) w
+// (exact for ANY rule: the quadrature of a tensor-product integrand with constant coefficients factorises; the matrices are built on the
+// host from the mesh's own tables).  Assembled over the elements the x factor is a banded operator along a node row: applied at the
+// thread's OWN nodes (the vertex node takes the left element's last row and the right element's first row, interior nodes one row),
+// 11 products per node row; the y factor is applied by scattering a row's products into the node rows it couples to (a window of 2 P + 1
+// accumulator rows marches with the strip).  Against the element form (sum-factorised Gauss-point loop, ~920 VALU instructions per Q2
+// element) this is ~11 x 4.5 x 2 multiply-adds per NODE (4 nodes per Q2 element), no per-element result to hand to a neighbour thread:
+// the only exchange is the left neighbour's node values (ds_bpermute), so a wave is self-contained -- no LDS slot, no barrier, and a
+// workgroup is just a bundle of independent one-wave chunks of 63 element columns (lane 0 of every chunk but the first is a ghost that
+// only supplies the halo).
+//
+// Launch: grid = (ceil(chunks / waves per workgroup), strips of R element rows, B).  A strip recomputes the layer under its first row
+// (as the element form does); bitwise repeatable, no atomics on the data path.
+#include <algorithm>
+#include <cstdlib>
+
+#include "fsdt_common.h"
+
+namespace dn {
+
+struct FsdtMats {
+    float x[3][4][4];      // op 0: M, 1: K, 2: C; x axis: weights gpw, derivatives scaled by 2 / hx
+    float y[3][4][4];      // y axis: weights gpw * wscale, derivatives scaled by 2 / hy
+    float lx[4], ly[4];    // sum_g w_g N_a (ly carries wscale)
+};
+
+enum { ST_M = 0, ST_K = 1, ST_C = 2 };
+
+// x factor at the thread's own nodes: o[0] = left element's row P against (left nodes, own node 0) + right element's row 0; o[n] = row n
+template <int P, int OP, bool TR>
+__device__ __forceinline__ void st_xop(const FsdtMats& m, const float (&uL)[P + 1], const float (&uR)[P + 1], float (&o)[P]) {
+    float s = (TR ? m.x[OP][0][P] : m.x[OP][P][0]) * uL[0];
+#pragma unroll
+    for (int b = 1; b <= P; ++b) s = fmaf(TR ? m.x[OP][b][P] : m.x[OP][P][b], uL[b], s);
+#pragma unroll
+    for (int b = 0; b <= P; ++b) s = fmaf(TR ? m.x[OP][b][0] : m.x[OP][0][b], uR[b], s);
+    o[0] = s;
+#pragma unroll
+    for (int n = 1; n < P; ++n) {
+        float t = (TR ? m.x[OP][0][n] : m.x[OP][n][0]) * uR[0];
+#pragma unroll
+        for (int b = 1; b <= P; ++b) t = fmaf(TR ? m.x[OP][b][n] : m.x[OP][n][b], uR[b], t);
+        o[n] = t;
+    }
+}
+
+// y factor: the products of the node row at local index JIN of an element layer go to that layer's rows, window rows BASE .. BASE + P
+template <int P, int OP, bool TR, int BASE, int JIN>
+__device__ __forceinline__ void st_yscatter(const FsdtMats& m, const float (&g)[P], float (&acc)[2 * P + 1][P]) {
+#pragma unroll
+    for (int jo = 0; jo <= P; ++jo) {
+        const float t = TR ? m.y[OP][JIN][jo] : m.y[OP][jo][JIN];
+#pragma unroll
+        for (int n = 0; n < P; ++n) acc[BASE + jo][n] = fmaf(t, g[n], acc[BASE + jo][n]);
+    }
+}
+
+// The eleven (y operator, residual) groups of one node row, after the x factor and the constitutive coefficients
+template <int P>
+struct StGroups {
+    float r1m[P], r1c[P], r1k[P];
+    float r2m[P], r2ct[P], r2k[P], r2c[P];
+    float r3ct[P], r3m[P], r3c[P], r3k[P];
+};
+
+template <int P>
+__device__ __forceinline__ void st_stage(const FsdtParams& p, const FsdtMats& m, const float (&cu)[3][P + 1], float lf, float okf, StGroups<P>& G) {
+    float uL[3][P + 1], uR[3][P + 1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+            float t = __shfl_up(cu[k][b], 1, 64);        // the left neighbour's own nodes = the left element's first P nodes
+            asm volatile("" : "+v"(t));                  // (the exchange stays where every lane takes part)
+            uL[k][b] = lf * t;
+        }
+        uL[k][P] = lf * cu[k][0];
+#pragma unroll
+        for (int b = 0; b <= P; ++b) uR[k][b] = okf * cu[k][b];
+    }
+    float wK[P], wM[P], wCT[P], xC[P], xK[P], xM[P], xCT[P], yM[P], yC[P], yCT[P], yK[P];
+    st_xop<P, ST_K, false>(m, uL[0], uR[0], wK);
+    st_xop<P, ST_M, false>(m, uL[0], uR[0], wM);
+    st_xop<P, ST_C, true>(m, uL[0], uR[0], wCT);
+    st_xop<P, ST_C, false>(m, uL[1], uR[1], xC);
+    st_xop<P, ST_K, false>(m, uL[1], uR[1], xK);
+    st_xop<P, ST_M, false>(m, uL[1], uR[1], xM);
+    st_xop<P, ST_C, true>(m, uL[1], uR[1], xCT);
+    st_xop<P, ST_M, false>(m, uL[2], uR[2], yM);
+    st_xop<P, ST_C, false>(m, uL[2], uR[2], yC);
+    st_xop<P, ST_C, true>(m, uL[2], uR[2], yCT);
+    st_xop<P, ST_K, false>(m, uL[2], uR[2], yK);
+#pragma unroll
+    for (int n = 0; n < P; ++n) {
+        const float a44wM = p.A44 * wM[n], a44yM = p.A44 * yM[n];
+        G.r1m[n] = p.A55 * (xC[n] + wK[n]);
+        G.r1c[n] = a44yM;
+        G.r1k[n] = a44wM;
+        G.r2m[n] = fmaf(p.D11, xK[n], p.A55 * (xM[n] + wCT[n]));
+        G.r2ct[n] = p.D12 * yC[n];
+        G.r2k[n] = p.D66 * xM[n];
+        G.r2c[n] = p.D66 * yCT[n];
+        G.r3ct[n] = fmaf(p.D66, xC[n], a44wM);
+        G.r3m[n] = fmaf(p.D66, yK[n], a44yM);
+        G.r3c[n] = p.D12 * xCT[n];
+        G.r3k[n] = p.D22 * yM[n];
+    }
+}
+
+template <int P, int BASE, int JIN>
+__device__ __forceinline__ void st_scatter(const FsdtMats& m, const StGroups<P>& G, float (&acc)[3][2 * P + 1][P]) {
+    st_yscatter<P, ST_M, false, BASE, JIN>(m, G.r1m, acc[0]);
+    st_yscatter<P, ST_C, false, BASE, JIN>(m, G.r1c, acc[0]);
+    st_yscatter<P, ST_K, false, BASE, JIN>(m, G.r1k, acc[0]);
+    st_yscatter<P, ST_M, false, BASE, JIN>(m, G.r2m, acc[1]);
+    st_yscatter<P, ST_C, true, BASE, JIN>(m, G.r2ct, acc[1]);
+    st_yscatter<P, ST_K, false, BASE, JIN>(m, G.r2k, acc[1]);
+    st_yscatter<P, ST_C, false, BASE, JIN>(m, G.r2c, acc[1]);
+    st_yscatter<P, ST_C, true, BASE, JIN>(m, G.r3ct, acc[2]);
+    st_yscatter<P, ST_M, false, BASE, JIN>(m, G.r3m, acc[2]);
+    st_yscatter<P, ST_C, false, BASE, JIN>(m, G.r3c, acc[2]);
+    st_yscatter<P, ST_K, false, BASE, JIN>(m, G.r3k, acc[2]);
+}
+
+// MK: Dirichlet mask kind (0 none, 1 uint8, 2 fp32 compared with 0.5); BCF: some boundary value is a field.  Compile-time for the reason
+// given in fsdt.hip: no load may sit inside a wave-uniform branch.
+template <int P, int MK, bool BCF>
+__global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, const FsdtMats m, const int nchunks) {
+    constexpr int NB = P + 1, NW = P, NWIN = 2 * P + 1;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = (int)threadIdx.x & 63;
+    const int chunk = (int)blockIdx.x * ((int)blockDim.x >> 6) + wave;      // one wave = one chunk of 63 element columns (+ the ghost lane)
+    const int b = blockIdx.z;
+    const int R = p.rows_per_strip;
+    const int ey_own = (int)blockIdx.y * R;
+    const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;                       // the layer under the strip's first node row is recomputed
+    const int ey_end = min(ey_own + R, p.nely);
+    const int q = chunk * 63 + lane;
+    const int x0 = q * P;
+    const bool col_owner = !(chunk > 0 && lane == 0);
+    const float okf = q < p.nelx ? 1.f : 0.f;      // the closing thread column (and lanes right of the mesh) have no element to their right
+    const float lf = q > 0 ? 1.f : 0.f;            // the first thread column has none to its left
+    const int64_t nps = (int64_t)p.nx * p.ny;
+    const int ymax = p.ny - 1;
+
+    __shared__ double red[16];
+    __shared__ int last_flag;
+    float sq[3] = {0.f, 0.f, 0.f};
+
+    if (chunk < nchunks) {
+        const float* fb[3];
+        const float* bcf[3];
+        bool has_bcf[3];
+        float* ob[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            fb[k] = p.fld[k] + (int64_t)b * nps;
+            has_bcf[k] = p.bcf[k] != nullptr;
+            bcf[k] = has_bcf[k] ? p.bcf[k] + (p.bcf_batched[k] ? (int64_t)b * nps : 0) : fb[k];
+            ob[k] = p.out[k] ? p.out[k] + (int64_t)b * nps : nullptr;
+        }
+        const int64_t mo = p.mask_batched ? (int64_t)b * nps : 0;
+        const uint8_t* m8 = reinterpret_cast<const uint8_t*>(p.mask) + (MK == 1 ? mo : 0);
+        const float* mf = reinterpret_cast<const float*>(p.mask) + (MK == 2 ? mo : 0);
+
+        float fscale[3] = {1.f, 1.f, 1.f};
+        if (p.in_scale) { fscale[0] = p.in_scale[0]; fscale[1] = p.in_scale[1]; fscale[2] = p.in_scale[2]; }
+        if (p.in_num) {               // cotangent of the norms over the norms (the VJP of ||R_k||), torch's convention at ||R_k|| == 0: zero
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float den = p.in_den[k];
+                fscale[k] = den > 0.f ? p.in_num[k] / den : 0.f;
+            }
+        }
+
+        struct RawRow {
+            float v[3][NW + 1], bf[3][NW + 1], mfl[NW + 1];
+            uint8_t mb[NW + 1];
+        };
+        auto row_issue = [&](int yr, RawRow& w) {
+            const unsigned rowoff = (unsigned)min(yr, ymax) * (unsigned)p.nx;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) load_seg<NW, false>(fb[k], rowoff, x0, p.nx, w.v[k]);
+            if constexpr (MK == 1) load_seg<NW, false>(m8, rowoff, x0, p.nx, w.mb);
+            if constexpr (MK == 2) load_seg<NW, false>(mf, rowoff, x0, p.nx, w.mfl);
+            if constexpr (BCF && MK != 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) load_seg<NW, false>(bcf[k], rowoff, x0, p.nx, w.bf[k]);
+            }
+        };
+        // landed row: input scaling, Dirichlet nodes (mask >= 0.5) take the boundary values
+        auto row_consume = [&](const RawRow& w, float (&cu)[3][NB], unsigned& bits_out) {
+            unsigned bits = 0u;
+            if constexpr (MK == 1) {
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) bits |= (w.mb[n] != 0) ? (1u << n) : 0u;
+            }
+            if constexpr (MK == 2) {
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) bits |= (w.mfl[n] >= 0.5f) ? (1u << n) : 0u;
+            }
+            bits_out = bits;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int n = 0; n <= NW; ++n) {
+                    float v = w.v[k][n] * fscale[k];
+                    if constexpr (MK != 0) {
+                        float bv = p.bcv[k];
+                        if constexpr (BCF) bv = has_bcf[k] ? w.bf[k][n] : bv;
+                        v = (bits & (1u << n)) ? bv : v;
+                    }
+                    cu[k][n] = v;
+                }
+        };
+
+        // window of accumulator rows: [0 .. P] the current element layer's node rows, [P + 1 .. 2 P] the rest of the next layer's
+        float acc[3][NWIN][P];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j)
+#pragma unroll
+                for (int n = 0; n < P; ++n) acc[k][j][n] = 0.f;
+        unsigned fixed[NB];                           // Dirichlet bits of the window's rows 0 .. P (own nodes)
+        float kv[BCF ? NB : 1][3][P];                 // BCF: their boundary values (= the substituted node values)
+
+        // the load vector's x factor at the own nodes, times -q
+        float cq[P];
+        cq[0] = -p.q * fmaf(lf, m.lx[P], okf * m.lx[0]);
+#pragma unroll
+        for (int n = 1; n < P; ++n) cq[n] = -p.q * m.lx[n];
+
+        // finished node rows wait here until flush_rows() stores them (after the next rows have been requested: fsdt.hip)
+        float pend[P][3][NW];
+        unsigned pend_off[P];
+        bool pend_st[P];
+#pragma unroll
+        for (int r = 0; r < P; ++r) pend_st[r] = false;
+        auto flush_rows = [&]() {
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                if (pend_st[r]) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (ob[k]) store_seg<NW, false>(ob[k], pend_off[r], x0, p.nx, pend[r][k]);
+                }
+                pend_st[r] = false;
+            }
+        };
+        // window row jo is complete: Dirichlet rows of the residual carry the boundary values (e1_plate_bending_fsdt.py:222-228)
+        auto emit_row = [&](int jo, int slot, int yr, bool owned_row) {
+            const bool st = owned_row && col_owner;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    float v = acc[k][jo][n];
+                    if constexpr (MK != 0) {
+                        float bv = p.bcv[k];
+                        if constexpr (BCF) bv = has_bcf[k] ? kv[jo][k][n] : bv;
+                        v = (fixed[jo] & (1u << n)) ? bv : v;
+                    }
+                    sq[k] = (st && x0 + n < p.nx) ? fmaf(v, v, sq[k]) : sq[k];
+                    pend[slot][k][n] = v;
+                }
+            pend_off[slot] = (unsigned)yr * (unsigned)p.nx;
+            pend_st[slot] = st;
+        };
+        auto keep_row = [&](int j, const float (&cu)[3][NB], unsigned bits) {
+            fixed[j] = bits;
+            if constexpr (BCF) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int n = 0; n < P; ++n) kv[j][k][n] = cu[k][n];
+            }
+        };
+
+        RawRow W[P];
+        {
+            RawRow w0;
+            row_issue(ey_begin * P, w0);
+#pragma unroll
+            for (int r = 1; r <= P; ++r) row_issue(ey_begin * P + r, W[r - 1]);       // all P + 1 rows of the first layer in flight together
+            float cu[3][NB];
+            unsigned bits;
+            row_consume(w0, cu, bits);
+            keep_row(0, cu, bits);
+            StGroups<P> G;
+            st_stage<P>(p, m, cu, lf, okf, G);
+            st_scatter<P, 0, 0>(m, G, acc);          // the strip's first node row as row 0 of the first layer
+        }
+        for (int ey = ey_begin; ey < ey_end; ++ey) {
+            float cuR[P][3][NB];
+            unsigned bitsR[P];
+#pragma unroll
+            for (int r = 0; r < P; ++r) row_consume(W[r], cuR[r], bitsR[r]);
+#pragma unroll
+            for (int r = 1; r <= P; ++r) row_issue((ey + 1) * P + r, W[r - 1]);      // rows beyond the mesh re-read the last one (unused)
+            flush_rows();
+#pragma unroll
+            for (int jo = 0; jo <= P; ++jo)
+#pragma unroll
+                for (int n = 0; n < P; ++n) acc[0][jo][n] = fmaf(m.ly[jo], cq[n], acc[0][jo][n]);      // - q l_x (x) l_y of this layer
+            const bool has_next = ey + 1 < p.nely;
+#pragma unroll
+            for (int j = 1; j <= P; ++j) {
+                keep_row(j, cuR[j - 1], bitsR[j - 1]);
+                StGroups<P> G;
+                st_stage<P>(p, m, cuR[j - 1], lf, okf, G);
+                if (j == 1) st_scatter<P, 0, (P >= 1 ? 1 : 0)>(m, G, acc);
+                if constexpr (P >= 2) { if (j == 2) st_scatter<P, 0, 2>(m, G, acc); }
+                if constexpr (P >= 3) { if (j == 3) st_scatter<P, 0, 3>(m, G, acc); }
+                if (j == P && has_next) st_scatter<P, P, 0>(m, G, acc);            // the layer's top row is row 0 of the layer above
+            }
+            const bool own_layer = ey >= ey_own;
+#pragma unroll
+            for (int jo = 0; jo < P; ++jo) emit_row(jo, jo, ey * P + jo, own_layer);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int n = 0; n < P; ++n) {
+#pragma unroll
+                    for (int j = 0; j <= P; ++j) acc[k][j][n] = acc[k][j + P][n];
+#pragma unroll
+                    for (int j = P + 1; j < NWIN; ++j) acc[k][j][n] = 0.f;
+                }
+            fixed[0] = fixed[P];
+            if constexpr (BCF) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int n = 0; n < P; ++n) kv[0][k][n] = kv[P][k][n];
+            }
+        }
+        flush_rows();
+        if (ey_end == p.nely) {
+            emit_row(0, 0, p.ny - 1, true);
+            flush_rows();
+        }
+    }
+    if (p.want_sums) finish_sums3(p, sq, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
+}
+
+struct FsdtStGeom { int wpb, chunks, gx, R, strips; };
+
+static inline int st_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+static FsdtStGeom fsdt_st_plan(const dn_mesh* m) {
+    FsdtStGeom g;
+    const int P = m->degree;
+    const int nelx = (m->nx - 1) / P, nely = (m->ny - 1) / P;
+    g.chunks = nelx <= 63 ? 1 : st_ceil_div(nelx, 63);
+    // waves per workgroup: the bundle with the fewest idle waves in the last workgroup of a chunk row (ties: the larger)
+    g.wpb = 1;
+    int best_pad = 1 << 30;
+    for (int w = 4; w >= 1; --w) {
+        const int pad = st_ceil_div(g.chunks, w) * w - g.chunks;
+        if (pad < best_pad) { best_pad = pad; g.wpb = w; }
+    }
+    // strip height: enough waves for ~4 per SIMD, at the price of one recomputed layer per strip
+    const long long per_strip = (long long)g.chunks * m->batch;
+    int R = 32;
+    while (R > 2 && per_strip * st_ceil_div(nely, R) < 4096) R /= 2;
+    const char* e = config(CFG_PLAN_FSDT);      // "T,R": T = 64 x waves per workgroup (tuning experiments only)
+    int T, RR;
+    if (e && sscanf(e, "%d,%d", &T, &RR) == 2 && T >= 64 && T <= 256 && RR >= 1) { g.wpb = T / 64; R = RR; }
+    if (R > nely) R = nely;
+    g.R = R < 1 ? 1 : R;
+    g.strips = st_ceil_div(nely, g.R);
+    g.gx = st_ceil_div(g.chunks, g.wpb);
+    return g;
+}
+
+int64_t fsdt_st_workgroups(const dn_mesh* m) {
+    const FsdtStGeom g = fsdt_st_plan(m);
+    return (int64_t)g.gx * g.strips * m->batch;
+}
+
+template <int P>
+static int fsdt_st_launch_p(const FsdtParams& pp, const FsdtMats& mm, const FsdtStGeom& g, int batch, hipStream_t s) {
+    const int mk = !pp.mask ? 0 : (pp.mask_is_u8 ? 1 : 2);
+    const bool bcf = mk != 0 && (pp.bcf[0] || pp.bcf[1] || pp.bcf[2]);
+    dim3 grid(g.gx, g.strips, batch), block(64 * g.wpb);
+    switch (mk * 2 + (bcf ? 1 : 0)) {
+        case 0: case 1: hipLaunchKernelGGL((fsdt2d_st_kernel<P, 0, false>), grid, block, 0, s, pp, mm, g.chunks); return 0;
+        case 2: hipLaunchKernelGGL((fsdt2d_st_kernel<P, 1, false>), grid, block, 0, s, pp, mm, g.chunks); return 0;
+        case 3: hipLaunchKernelGGL((fsdt2d_st_kernel<P, 1, true>), grid, block, 0, s, pp, mm, g.chunks); return 0;
+        case 4: hipLaunchKernelGGL((fsdt2d_st_kernel<P, 2, false>), grid, block, 0, s, pp, mm, g.chunks); return 0;
+        default: hipLaunchKernelGGL((fsdt2d_st_kernel<P, 2, true>), grid, block, 0, s, pp, mm, g.chunks); return 0;
+    }
+}
+
+// pp: as filled by dn_fsdt_apply (rows_per_strip is set here); the 1-D matrices are formed from the mesh's tables in double precision
+int fsdt_st_launch(const dn_mesh* m, float wscale, FsdtParams& pp, hipStream_t s) {
+    const FsdtStGeom g = fsdt_st_plan(m);
+    pp.rows_per_strip = g.R;
+    FsdtMats mm;
+    const int nb = m->degree + 1;
+    for (int a = 0; a < 4; ++a) {
+        double la = 0.0;
+        for (int gp = 0; gp < m->ngp; ++gp) la += (a < nb) ? (double)m->gpw[gp] * m->basis[gp][a] : 0.0;
+        mm.lx[a] = (float)la;
+        mm.ly[a] = (float)(la * wscale);
+        for (int b = 0; b < 4; ++b) {
+            double M = 0.0, K = 0.0, C = 0.0;
+            if (a < nb && b < nb)
+                for (int gp = 0; gp < m->ngp; ++gp) {
+                    const double w = m->gpw[gp], na = m->basis[gp][a], nbv = m->basis[gp][b], da = m->dbasis[gp][a], db = m->dbasis[gp][b];
+                    M += w * na * nbv;
+                    K += w * da * db;
+                    C += w * da * nbv;
+                }
+            const double sx = m->scale[0], sy = m->scale[1];
+            mm.x[ST_M][a][b] = (float)M;
+            mm.x[ST_K][a][b] = (float)(K * sx * sx);
+            mm.x[ST_C][a][b] = (float)(C * sx);
+            mm.y[ST_M][a][b] = (float)(M * wscale);
+            mm.y[ST_K][a][b] = (float)(K * sy * sy * wscale);
+            mm.y[ST_C][a][b] = (float)(C * sy * wscale);
+        }
+    }
+    switch (m->degree) {
+        case 1: return fsdt_st_launch_p<1>(pp, mm, g, m->batch, s);
+        case 2: return fsdt_st_launch_p<2>(pp, mm, g, m->batch, s);
+        default: return fsdt_st_launch_p<3>(pp, mm, g, m->batch, s);
+    }
+}
+
+}  // namespace dn

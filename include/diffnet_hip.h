@@ -49,7 +49,9 @@ extern "C" {
  *   error path of dn_workspace_status; a small value makes healthy launches fail), "CONV2D_V1" (non-empty: the round-2 im2col forms of
  *   dn_conv2d_k4s2_down / _up / _wrw also where the raw-row-tile forms of round 4 apply), "CONV_WRW_WGS" (integer: workgroups a
  *   dn_conv2d_k4s2_wrw launch aims at when it splits K; default 1024), "Q1_3D_N2" (non-empty: the round-3 per-Gauss-point form of the 3-D Q1
- *   two-element kernel also where the closed-form-in-z kernel of round 4, csrc/poisson3d_q1_cf.hip, applies).  value NULL or "" clears the switch.
+ *   two-element kernel also where the closed-form-in-z kernel of round 4, csrc/poisson3d_q1_cf.hip, applies),
+ *   "FSDT_FORM" ("elem": dn_fsdt_apply runs the element form of rounds 1-3, csrc/fsdt.hip, instead of the assembled-stencil form of round 4,
+ *   csrc/fsdt_st.hip).  value NULL or "" clears the switch.
  * Returns 0, or DN_E_BADARG for an unknown key / over-long value.  Not thread-safe against concurrent launches.
  * No reference counterpart (the reference has no tuning surface). */
 int dn_config_set(const char *key, const char *value);
