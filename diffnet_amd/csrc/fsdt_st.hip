@@ -35,32 +35,66 @@ struct FsdtMats {
 
 enum { ST_M = 0, ST_K = 1, ST_C = 2 };
 
+// The matrices are read from the kernel-argument segment through a pointer the compiler cannot see through (st_fresh), once per phase of a
+// layer: 54 matrix entries + the coefficients + the launch's pointers do not fit the 100 SGPRs, and what does not fit is spilled into VGPR
+// lanes and read back with v_readlane (~33 cycles of the SIMD each: 150 of them per layer in the first packed build).  A phase (x factor of the
+// layer's rows; y factor) re-reads its <= 21 entries with scalar loads that hit the scalar cache; M and K are symmetric: the upper triangle.
+typedef const FsdtMats __attribute__((address_space(4)))* st_mats_ptr;
+__device__ __forceinline__ st_mats_ptr st_fresh(st_mats_ptr m) {
+    asm volatile("" : "+s"(m));
+    return m;
+}
+template <int OP, bool TR>
+__device__ __forceinline__ float st_mx(st_mats_ptr m, int a, int b) {
+    if constexpr (OP == ST_C) return TR ? m->x[OP][b][a] : m->x[OP][a][b];
+    return a <= b ? m->x[OP][a][b] : m->x[OP][b][a];
+}
+template <int OP, bool TR>
+__device__ __forceinline__ float st_my(st_mats_ptr m, int a, int b) {
+    if constexpr (OP == ST_C) return TR ? m->y[OP][b][a] : m->y[OP][a][b];
+    return a <= b ? m->y[OP][a][b] : m->y[OP][b][a];
+}
+
+// Value types: float, or v2f = (phi_x, phi_y) / two neighbouring own nodes in the halves of a 64-bit register pair (v_pk_fma_f32 / v_pk_mul_f32: one
+// issue slot for two multiply-adds; wave-uniform matrix entries broadcast into both halves through op_sel) -- poisson_elem.h
+typedef float st_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float st_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ st_v2f st_fma(float a, st_v2f b, st_v2f c) { return __builtin_elementwise_fma((st_v2f)(a), b, c); }
+__device__ __forceinline__ float st_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ st_v2f st_mul(float a, st_v2f b) { return (st_v2f)(a) * b; }
+
 // x factor at the thread's own nodes: o[0] = left element's row P against (left nodes, own node 0) + right element's row 0; o[n] = row n
-template <int P, int OP, bool TR>
-__device__ __forceinline__ void st_xop(const FsdtMats& m, const float (&uL)[P + 1], const float (&uR)[P + 1], float (&o)[P]) {
-    float s = (TR ? m.x[OP][0][P] : m.x[OP][P][0]) * uL[0];
+template <int P, int OP, bool TR, typename V>
+__device__ __forceinline__ void st_xop(st_mats_ptr m, const V (&uL)[P + 1], const V (&uR)[P + 1], V (&o)[P]) {
+    V s = st_mul(st_mx<OP, TR>(m, P, 0), uL[0]);
 #pragma unroll
-    for (int b = 1; b <= P; ++b) s = fmaf(TR ? m.x[OP][b][P] : m.x[OP][P][b], uL[b], s);
+    for (int b = 1; b <= P; ++b) s = st_fma(st_mx<OP, TR>(m, P, b), uL[b], s);
 #pragma unroll
-    for (int b = 0; b <= P; ++b) s = fmaf(TR ? m.x[OP][b][0] : m.x[OP][0][b], uR[b], s);
+    for (int b = 0; b <= P; ++b) s = st_fma(st_mx<OP, TR>(m, 0, b), uR[b], s);
     o[0] = s;
 #pragma unroll
     for (int n = 1; n < P; ++n) {
-        float t = (TR ? m.x[OP][0][n] : m.x[OP][n][0]) * uR[0];
+        V t = st_mul(st_mx<OP, TR>(m, n, 0), uR[0]);
 #pragma unroll
-        for (int b = 1; b <= P; ++b) t = fmaf(TR ? m.x[OP][b][n] : m.x[OP][n][b], uR[b], t);
+        for (int b = 1; b <= P; ++b) t = st_fma(st_mx<OP, TR>(m, n, b), uR[b], t);
         o[n] = t;
     }
 }
 
-// y factor: the products of the node row at local index JIN of an element layer go to that layer's rows, window rows BASE .. BASE + P
+// y factor: the products of the node row at local index JIN of an element layer go to that layer's rows, window rows BASE .. BASE + P;
+// the own nodes two at a time in packed registers
 template <int P, int OP, bool TR, int BASE, int JIN>
-__device__ __forceinline__ void st_yscatter(const FsdtMats& m, const float (&g)[P], float (&acc)[2 * P + 1][P]) {
+__device__ __forceinline__ void st_yscatter(st_mats_ptr m, const float (&g)[P], float (&acc)[2 * P + 1][P]) {
 #pragma unroll
     for (int jo = 0; jo <= P; ++jo) {
-        const float t = TR ? m.y[OP][JIN][jo] : m.y[OP][jo][JIN];
+        const float t = st_my<OP, TR>(m, jo, JIN);
 #pragma unroll
-        for (int n = 0; n < P; ++n) acc[BASE + jo][n] = fmaf(t, g[n], acc[BASE + jo][n]);
+        for (int n = 0; n + 1 < P; n += 2) {
+            const st_v2f r = st_fma(t, (st_v2f){g[n], g[n + 1]}, (st_v2f){acc[BASE + jo][n], acc[BASE + jo][n + 1]});
+            acc[BASE + jo][n] = r.x;
+            acc[BASE + jo][n + 1] = r.y;
+        }
+        if constexpr (P % 2 == 1) acc[BASE + jo][P - 1] = fmaf(t, g[P - 1], acc[BASE + jo][P - 1]);
     }
 }
 
@@ -72,52 +106,54 @@ struct StGroups {
     float r3ct[P], r3m[P], r3c[P], r3k[P];
 };
 
+// cw: w, cxy: (phi_x, phi_y) at the own nodes + the node shared with the right neighbour (after scaling and the Dirichlet substitution)
 template <int P>
-__device__ __forceinline__ void st_stage(const FsdtParams& p, const FsdtMats& m, const float (&cu)[3][P + 1], float lf, float okf, StGroups<P>& G) {
-    float uL[3][P + 1], uR[3][P + 1];
+__device__ __forceinline__ void st_stage(const FsdtParams& p, st_mats_ptr m, const float (&cw)[P + 1], const st_v2f (&cxy)[P + 1], float lf, float okf,
+                                         StGroups<P>& G) {
+    float wL[P + 1], wR[P + 1];
+    st_v2f xyL[P + 1], xyR[P + 1];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int b = 0; b < P; ++b) {
-            float t = __shfl_up(cu[k][b], 1, 64);        // the left neighbour's own nodes = the left element's first P nodes
-            asm volatile("" : "+v"(t));                  // (the exchange stays where every lane takes part)
-            uL[k][b] = lf * t;
-        }
-        uL[k][P] = lf * cu[k][0];
-#pragma unroll
-        for (int b = 0; b <= P; ++b) uR[k][b] = okf * cu[k][b];
+    for (int b = 0; b < P; ++b) {            // the left neighbour's own nodes = the left element's first P nodes
+        float t0 = __shfl_up(cw[b], 1, 64), t1 = __shfl_up(cxy[b].x, 1, 64), t2 = __shfl_up(cxy[b].y, 1, 64);
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));         // (the exchange stays where every lane takes part)
+        wL[b] = lf * t0;
+        xyL[b] = st_mul(lf, (st_v2f){t1, t2});
     }
-    float wK[P], wM[P], wCT[P], xC[P], xK[P], xM[P], xCT[P], yM[P], yC[P], yCT[P], yK[P];
-    st_xop<P, ST_K, false>(m, uL[0], uR[0], wK);
-    st_xop<P, ST_M, false>(m, uL[0], uR[0], wM);
-    st_xop<P, ST_C, true>(m, uL[0], uR[0], wCT);
-    st_xop<P, ST_C, false>(m, uL[1], uR[1], xC);
-    st_xop<P, ST_K, false>(m, uL[1], uR[1], xK);
-    st_xop<P, ST_M, false>(m, uL[1], uR[1], xM);
-    st_xop<P, ST_C, true>(m, uL[1], uR[1], xCT);
-    st_xop<P, ST_M, false>(m, uL[2], uR[2], yM);
-    st_xop<P, ST_C, false>(m, uL[2], uR[2], yC);
-    st_xop<P, ST_C, true>(m, uL[2], uR[2], yCT);
-    st_xop<P, ST_K, false>(m, uL[2], uR[2], yK);
+    wL[P] = lf * cw[0];
+    xyL[P] = st_mul(lf, cxy[0]);
+#pragma unroll
+    for (int b = 0; b <= P; ++b) {
+        wR[b] = okf * cw[b];
+        xyR[b] = st_mul(okf, cxy[b]);
+    }
+    float wK[P], wM[P], wCT[P];
+    st_v2f C[P], K[P], M[P], CT[P];          // .x: of phi_x, .y: of phi_y
+    st_xop<P, ST_K, false>(m, wL, wR, wK);
+    st_xop<P, ST_M, false>(m, wL, wR, wM);
+    st_xop<P, ST_C, true>(m, wL, wR, wCT);
+    st_xop<P, ST_C, false>(m, xyL, xyR, C);
+    st_xop<P, ST_K, false>(m, xyL, xyR, K);
+    st_xop<P, ST_M, false>(m, xyL, xyR, M);
+    st_xop<P, ST_C, true>(m, xyL, xyR, CT);
 #pragma unroll
     for (int n = 0; n < P; ++n) {
-        const float a44wM = p.A44 * wM[n], a44yM = p.A44 * yM[n];
-        G.r1m[n] = p.A55 * (xC[n] + wK[n]);
+        const float a44wM = p.A44 * wM[n], a44yM = p.A44 * M[n].y;
+        G.r1m[n] = p.A55 * (C[n].x + wK[n]);
         G.r1c[n] = a44yM;
         G.r1k[n] = a44wM;
-        G.r2m[n] = fmaf(p.D11, xK[n], p.A55 * (xM[n] + wCT[n]));
-        G.r2ct[n] = p.D12 * yC[n];
-        G.r2k[n] = p.D66 * xM[n];
-        G.r2c[n] = p.D66 * yCT[n];
-        G.r3ct[n] = fmaf(p.D66, xC[n], a44wM);
-        G.r3m[n] = fmaf(p.D66, yK[n], a44yM);
-        G.r3c[n] = p.D12 * xCT[n];
-        G.r3k[n] = p.D22 * yM[n];
+        G.r2m[n] = fmaf(p.D11, K[n].x, p.A55 * (M[n].x + wCT[n]));
+        G.r2ct[n] = p.D12 * C[n].y;
+        G.r2k[n] = p.D66 * M[n].x;
+        G.r2c[n] = p.D66 * CT[n].y;
+        G.r3ct[n] = fmaf(p.D66, C[n].x, a44wM);
+        G.r3m[n] = fmaf(p.D66, K[n].y, a44yM);
+        G.r3c[n] = p.D12 * CT[n].x;
+        G.r3k[n] = p.D22 * M[n].y;
     }
 }
 
 template <int P, int BASE, int JIN>
-__device__ __forceinline__ void st_scatter(const FsdtMats& m, const StGroups<P>& G, float (&acc)[3][2 * P + 1][P]) {
+__device__ __forceinline__ void st_scatter(st_mats_ptr m, const StGroups<P>& G, float (&acc)[3][2 * P + 1][P]) {
     st_yscatter<P, ST_M, false, BASE, JIN>(m, G.r1m, acc[0]);
     st_yscatter<P, ST_C, false, BASE, JIN>(m, G.r1c, acc[0]);
     st_yscatter<P, ST_K, false, BASE, JIN>(m, G.r1k, acc[0]);
@@ -134,8 +170,10 @@ __device__ __forceinline__ void st_scatter(const FsdtMats& m, const StGroups<P>&
 // MK: Dirichlet mask kind (0 none, 1 uint8, 2 fp32 compared with 0.5); BCF: some boundary value is a field.  Compile-time for the reason
 // given in fsdt.hip: no load may sit inside a wave-uniform branch.
 template <int P, int MK, bool BCF>
-__global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, const FsdtMats m, const int nchunks) {
+__global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, const FsdtMats mats_by_value, const int nchunks) {
     constexpr int NB = P + 1, NW = P, NWIN = 2 * P + 1;
+    static_assert(sizeof(FsdtParams) % 8 == 0 && alignof(FsdtMats) == 4, "kernel-argument layout: the matrices follow the parameters");
+    const st_mats_ptr km = (st_mats_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(FsdtParams));
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
     const int chunk = (int)blockIdx.x * ((int)blockDim.x >> 6) + wave;      // one wave = one chunk of 63 element columns (+ the ghost lane)
@@ -198,7 +236,7 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
             }
         };
         // landed row: input scaling, Dirichlet nodes (mask >= 0.5) take the boundary values
-        auto row_consume = [&](const RawRow& w, float (&cu)[3][NB], unsigned& bits_out) {
+        auto row_consume = [&](const RawRow& w, float (&cw)[NB], st_v2f (&cxy)[NB], unsigned& bits_out) {
             unsigned bits = 0u;
             if constexpr (MK == 1) {
 #pragma unroll
@@ -219,7 +257,9 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
                         if constexpr (BCF) bv = has_bcf[k] ? w.bf[k][n] : bv;
                         v = (bits & (1u << n)) ? bv : v;
                     }
-                    cu[k][n] = v;
+                    if (k == 0) cw[n] = v;
+                    else if (k == 1) cxy[n].x = v;
+                    else cxy[n].y = v;
                 }
         };
 
@@ -236,9 +276,9 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
 
         // the load vector's x factor at the own nodes, times -q
         float cq[P];
-        cq[0] = -p.q * fmaf(lf, m.lx[P], okf * m.lx[0]);
+        cq[0] = -p.q * fmaf(lf, km->lx[P], okf * km->lx[0]);
 #pragma unroll
-        for (int n = 1; n < P; ++n) cq[n] = -p.q * m.lx[n];
+        for (int n = 1; n < P; ++n) cq[n] = -p.q * km->lx[n];
 
         // finished node rows wait here until flush_rows() stores them (after the next rows have been requested: fsdt.hip)
         float pend[P][3][NW];
@@ -276,13 +316,11 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
             pend_off[slot] = (unsigned)yr * (unsigned)p.nx;
             pend_st[slot] = st;
         };
-        auto keep_row = [&](int j, const float (&cu)[3][NB], unsigned bits) {
+        auto keep_row = [&](int j, const float (&cw)[NB], const st_v2f (&cxy)[NB], unsigned bits) {
             fixed[j] = bits;
             if constexpr (BCF) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int n = 0; n < P; ++n) kv[j][k][n] = cu[k][n];
+                for (int n = 0; n < P; ++n) { kv[j][0][n] = cw[n]; kv[j][1][n] = cxy[n].x; kv[j][2][n] = cxy[n].y; }
             }
         };
 
@@ -292,36 +330,68 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
             row_issue(ey_begin * P, w0);
 #pragma unroll
             for (int r = 1; r <= P; ++r) row_issue(ey_begin * P + r, W[r - 1]);       // all P + 1 rows of the first layer in flight together
-            float cu[3][NB];
+            float cw[NB];
+            st_v2f cxy[NB];
             unsigned bits;
-            row_consume(w0, cu, bits);
-            keep_row(0, cu, bits);
+            row_consume(w0, cw, cxy, bits);
+            keep_row(0, cw, cxy, bits);
             StGroups<P> G;
-            st_stage<P>(p, m, cu, lf, okf, G);
-            st_scatter<P, 0, 0>(m, G, acc);          // the strip's first node row as row 0 of the first layer
+            st_stage<P>(p, st_fresh(km), cw, cxy, lf, okf, G);
+            st_scatter<P, 0, 0>(st_fresh(km), G, acc);          // the strip's first node row as row 0 of the first layer
         }
         for (int ey = ey_begin; ey < ey_end; ++ey) {
-            float cuR[P][3][NB];
+            float cwR[P][NB];
+            st_v2f cxyR[P][NB];
             unsigned bitsR[P];
 #pragma unroll
-            for (int r = 0; r < P; ++r) row_consume(W[r], cuR[r], bitsR[r]);
+            for (int r = 0; r < P; ++r) row_consume(W[r], cwR[r], cxyR[r], bitsR[r]);
 #pragma unroll
             for (int r = 1; r <= P; ++r) row_issue((ey + 1) * P + r, W[r - 1]);      // rows beyond the mesh re-read the last one (unused)
             flush_rows();
+            if constexpr (P <= 2) {
+                // x phase: the layer's P new node rows
+                StGroups<P> G[P];
+                {
+                    const st_mats_ptr mx = st_fresh(km);
 #pragma unroll
-            for (int jo = 0; jo <= P; ++jo)
+                    for (int j = 1; j <= P; ++j) {
+                        keep_row(j, cwR[j - 1], cxyR[j - 1], bitsR[j - 1]);
+                        st_stage<P>(p, mx, cwR[j - 1], cxyR[j - 1], lf, okf, G[j - 1]);
+                    }
+                }
+                // y phase
+                {
+                    const st_mats_ptr my = st_fresh(km);
 #pragma unroll
-                for (int n = 0; n < P; ++n) acc[0][jo][n] = fmaf(m.ly[jo], cq[n], acc[0][jo][n]);      // - q l_x (x) l_y of this layer
-            const bool has_next = ey + 1 < p.nely;
+                    for (int jo = 0; jo <= P; ++jo)
 #pragma unroll
-            for (int j = 1; j <= P; ++j) {
-                keep_row(j, cuR[j - 1], bitsR[j - 1]);
-                StGroups<P> G;
-                st_stage<P>(p, m, cuR[j - 1], lf, okf, G);
-                if (j == 1) st_scatter<P, 0, (P >= 1 ? 1 : 0)>(m, G, acc);
-                if constexpr (P >= 2) { if (j == 2) st_scatter<P, 0, 2>(m, G, acc); }
-                if constexpr (P >= 3) { if (j == 3) st_scatter<P, 0, 3>(m, G, acc); }
-                if (j == P && has_next) st_scatter<P, P, 0>(m, G, acc);            // the layer's top row is row 0 of the layer above
+                        for (int n = 0; n < P; ++n) acc[0][jo][n] = fmaf(my->ly[jo], cq[n], acc[0][jo][n]);      // - q l_x (x) l_y of this layer
+                    st_scatter<P, 0, 1>(my, G[0], acc);
+                    if constexpr (P >= 2) st_scatter<P, 0, 2>(my, G[1], acc);
+                    if (ey + 1 < p.nely) st_scatter<P, P, 0>(my, G[P - 1], acc);            // the layer's top row is row 0 of the layer above
+                }
+            } else {
+                // Q3: one node row at a time (three rows' groups at once are 99 registers: the build then spills into the accumulation registers)
+                {
+                    const st_mats_ptr my = st_fresh(km);
+#pragma unroll
+                    for (int jo = 0; jo <= P; ++jo)
+#pragma unroll
+                        for (int n = 0; n < P; ++n) acc[0][jo][n] = fmaf(my->ly[jo], cq[n], acc[0][jo][n]);
+                }
+#pragma unroll
+                for (int j = 1; j <= P; ++j) {
+                    keep_row(j, cwR[j - 1], cxyR[j - 1], bitsR[j - 1]);
+                    StGroups<P> G;
+                    st_stage<P>(p, st_fresh(km), cwR[j - 1], cxyR[j - 1], lf, okf, G);
+                    const st_mats_ptr my = st_fresh(km);
+                    if (j == 1) st_scatter<P, 0, 1>(my, G, acc);
+                    if (j == 2) st_scatter<P, 0, 2>(my, G, acc);
+                    if constexpr (P >= 3) {
+                        if (j == 3) st_scatter<P, 0, 3>(my, G, acc);
+                    }
+                    if (j == P && ey + 1 < p.nely) st_scatter<P, P, 0>(my, G, acc);
+                }
             }
             const bool own_layer = ey >= ey_own;
 #pragma unroll
