@@ -15,8 +15,8 @@
 // accumulator rows marches with the strip).  Against the element form (sum-factorised Gauss-point loop, ~920 VALU instructions per Q2
 // element) this is ~11 x 4.5 x 2 multiply-adds per NODE (4 nodes per Q2 element), no per-element result to hand to a neighbour thread:
 // the only exchange is the left neighbour's node values (ds_bpermute), so a wave is self-contained -- no LDS slot, no barrier, and a
-// workgroup is just a bundle of independent one-wave chunks of 63 element columns (lane 0 of every chunk but the first is a ghost that
-// only supplies the halo).
+// workgroup is just a bundle of independent one-wave chunks of 62 element columns: lanes 0 and 63 are ghosts that only supply their
+// neighbours' halo (lane 0 of the first chunk owns the mesh's first column), so no node is loaded by two lanes of a wave.
 //
 // Launch: grid = (ceil(chunks / waves per workgroup), strips of R element rows, B).  A strip recomputes the layer under its first row
 // (as the element form does); bitwise repeatable, no atomics on the data path.
@@ -110,6 +110,14 @@ struct StGroups {
 template <int P>
 __device__ __forceinline__ void st_stage(const FsdtParams& p, st_mats_ptr m, const float (&cw)[P + 1], const st_v2f (&cxy)[P + 1], float lf, float okf,
                                          StGroups<P>& G) {
+#ifdef DN_ST_ABL_MATH             // measurement build (tools/variant_build.sh): the access pattern without the arithmetic
+#pragma unroll
+    for (int n = 0; n < P; ++n) {
+        const float t = cw[n] + cxy[n].x + cxy[n].y + cw[P] * lf + okf;
+        G.r1m[n] = G.r1c[n] = G.r1k[n] = G.r2m[n] = G.r2ct[n] = G.r2k[n] = G.r2c[n] = G.r3ct[n] = G.r3m[n] = G.r3c[n] = G.r3k[n] = t;
+    }
+    return;
+#endif
     float wL[P + 1], wR[P + 1];
     st_v2f xyL[P + 1], xyR[P + 1];
 #pragma unroll
@@ -154,6 +162,11 @@ __device__ __forceinline__ void st_stage(const FsdtParams& p, st_mats_ptr m, con
 
 template <int P, int BASE, int JIN>
 __device__ __forceinline__ void st_scatter(st_mats_ptr m, const StGroups<P>& G, float (&acc)[3][2 * P + 1][P]) {
+#ifdef DN_ST_ABL_MATH
+#pragma unroll
+    for (int n = 0; n < P; ++n) { acc[0][BASE][n] += G.r1m[n]; acc[1][BASE + 1][n] += G.r2m[n]; acc[2][BASE][n] -= G.r3m[n]; }
+    return;
+#endif
     st_yscatter<P, ST_M, false, BASE, JIN>(m, G.r1m, acc[0]);
     st_yscatter<P, ST_C, false, BASE, JIN>(m, G.r1c, acc[0]);
     st_yscatter<P, ST_K, false, BASE, JIN>(m, G.r1k, acc[0]);
@@ -176,15 +189,15 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
     const st_mats_ptr km = (st_mats_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(FsdtParams));
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
-    const int chunk = (int)blockIdx.x * ((int)blockDim.x >> 6) + wave;      // one wave = one chunk of 63 element columns (+ the ghost lane)
+    const int chunk = (int)blockIdx.x * ((int)blockDim.x >> 6) + wave;      // one wave = one chunk of 62 element columns + two ghost lanes
     const int b = blockIdx.z;
     const int R = p.rows_per_strip;
     const int ey_own = (int)blockIdx.y * R;
     const int ey_begin = ey_own > 0 ? ey_own - 1 : 0;                       // the layer under the strip's first node row is recomputed
     const int ey_end = min(ey_own + R, p.nely);
-    const int q = chunk * 63 + lane;
+    const int q = chunk * 62 + lane;
     const int x0 = q * P;
-    const bool col_owner = !(chunk > 0 && lane == 0);
+    const bool col_owner = lane != 63 && !(chunk > 0 && lane == 0);       // lanes 0 and 63 are ghosts: they supply their neighbours' halo
     const float okf = q < p.nelx ? 1.f : 0.f;      // the closing thread column (and lanes right of the mesh) have no element to their right
     const float lf = q > 0 ? 1.f : 0.f;            // the first thread column has none to its left
     const int64_t nps = (int64_t)p.nx * p.ny;
@@ -220,19 +233,19 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
             }
         }
 
-        struct RawRow {
-            float v[3][NW + 1], bf[3][NW + 1], mfl[NW + 1];
-            uint8_t mb[NW + 1];
+        struct RawRow {              // the thread's OWN nodes only: the node it shares with the right neighbour comes from that lane
+            float v[3][NW], bf[3][NW], mfl[NW];
+            uint8_t mb[NW];
         };
         auto row_issue = [&](int yr, RawRow& w) {
             const unsigned rowoff = (unsigned)min(yr, ymax) * (unsigned)p.nx;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) load_seg<NW, false>(fb[k], rowoff, x0, p.nx, w.v[k]);
-            if constexpr (MK == 1) load_seg<NW, false>(m8, rowoff, x0, p.nx, w.mb);
-            if constexpr (MK == 2) load_seg<NW, false>(mf, rowoff, x0, p.nx, w.mfl);
+            for (int k = 0; k < 3; ++k) load_own<NW, false>(fb[k], rowoff, x0, p.nx, w.v[k]);
+            if constexpr (MK == 1) load_own<NW, false>(m8, rowoff, x0, p.nx, w.mb);
+            if constexpr (MK == 2) load_own<NW, false>(mf, rowoff, x0, p.nx, w.mfl);
             if constexpr (BCF && MK != 0) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) load_seg<NW, false>(bcf[k], rowoff, x0, p.nx, w.bf[k]);
+                for (int k = 0; k < 3; ++k) load_own<NW, false>(bcf[k], rowoff, x0, p.nx, w.bf[k]);
             }
         };
         // landed row: input scaling, Dirichlet nodes (mask >= 0.5) take the boundary values
@@ -240,17 +253,17 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
             unsigned bits = 0u;
             if constexpr (MK == 1) {
 #pragma unroll
-                for (int n = 0; n <= NW; ++n) bits |= (w.mb[n] != 0) ? (1u << n) : 0u;
+                for (int n = 0; n < NW; ++n) bits |= (w.mb[n] != 0) ? (1u << n) : 0u;
             }
             if constexpr (MK == 2) {
 #pragma unroll
-                for (int n = 0; n <= NW; ++n) bits |= (w.mfl[n] >= 0.5f) ? (1u << n) : 0u;
+                for (int n = 0; n < NW; ++n) bits |= (w.mfl[n] >= 0.5f) ? (1u << n) : 0u;
             }
             bits_out = bits;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int n = 0; n <= NW; ++n) {
+                for (int n = 0; n < NW; ++n) {
                     float v = w.v[k][n] * fscale[k];
                     if constexpr (MK != 0) {
                         float bv = p.bcv[k];
@@ -261,6 +274,11 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
                     else if (k == 1) cxy[n].x = v;
                     else cxy[n].y = v;
                 }
+            // the node shared with the right neighbour: that lane's first own node, after ITS scaling and substitution (lane 63 is a ghost)
+            float t0 = __shfl_down(cw[0], 1, 64), t1 = __shfl_down(cxy[0].x, 1, 64), t2 = __shfl_down(cxy[0].y, 1, 64);
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2));
+            cw[NW] = t0;
+            cxy[NW] = (st_v2f){t1, t2};
         };
 
         // window of accumulator rows: [0 .. P] the current element layer's node rows, [P + 1 .. 2 P] the rest of the next layer's
@@ -430,7 +448,7 @@ static FsdtStGeom fsdt_st_plan(const dn_mesh* m) {
     FsdtStGeom g;
     const int P = m->degree;
     const int nelx = (m->nx - 1) / P, nely = (m->ny - 1) / P;
-    g.chunks = nelx <= 63 ? 1 : st_ceil_div(nelx, 63);
+    g.chunks = nelx <= 62 ? 1 : st_ceil_div(nelx, 62);       // 62 owner lanes per wave (the first chunk owns 63 thread columns: 0 .. 62)
     // waves per workgroup: the bundle with the fewest idle waves in the last workgroup of a chunk row (ties: the larger)
     g.wpb = 1;
     int best_pad = 1 << 30;
@@ -438,10 +456,13 @@ static FsdtStGeom fsdt_st_plan(const dn_mesh* m) {
         const int pad = st_ceil_div(g.chunks, w) * w - g.chunks;
         if (pad < best_pad) { best_pad = pad; g.wpb = w; }
     }
-    // strip height: enough waves for ~4 per SIMD, at the price of one recomputed layer per strip
+    // strip height: >= 2304 waves (2.25 per SIMD; 4096 once a row of strips has >= 64 waves) where the mesh has them, at the price of one recomputed
+    // layer per strip; 1025^2 Q2 measured (gpurun_out/t2_times_st.txt, t5_, t6_): B = 1: R = 2 / 4 / 8 -> 21.3 / 22.5 / 24.9 us, B = 2: 27.8 / 26.0 / 30.8,
+    // B = 4: R = 4 / 8 / 16 -> 46.3 / 37.7 / 48.1, B = 8: R = 8 / 16 -> 59.4 / 61.3
     const long long per_strip = (long long)g.chunks * m->batch;
+    const long long want = per_strip >= 64 ? 4096 : 2304;
     int R = 32;
-    while (R > 2 && per_strip * st_ceil_div(nely, R) < 4096) R /= 2;
+    while (R > 2 && per_strip * st_ceil_div(nely, R) < want) R /= 2;
     const char* e = config(CFG_PLAN_FSDT);      // "T,R": T = 64 x waves per workgroup (tuning experiments only)
     int T, RR;
     if (e && sscanf(e, "%d,%d", &T, &RR) == 2 && T >= 64 && T <= 256 && RR >= 1) { g.wpb = T / 64; R = RR; }

@@ -1,0 +1,132 @@
+"""GPU tests of the assembled-stencil form of the fused FSDT plate residuals (diffnet_amd/csrc/fsdt_st.hip, the default of dn_fsdt_apply
+since round 4): against the oracle's reference formulation (oracle/fem_oracle.py, pinned to the reference's fixtures by
+tests/test_oracle_golden.py -- examples/elasticity/single_instance/e1_plate_bending_fsdt.py:128-232) and against the element form of
+rounds 1-3 (dn_config_set("FSDT_FORM", "elem")), on the shapes where the two differ in structure: element-column counts around the wave
+chunk of 62 owner lanes, one to four waves per workgroup, strips of every height, Q1 / Q2 / Q3, every rule, every Dirichlet form."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import boundary_mask, close, cu, dev, module, seeded
+
+pytestmark = pytest.mark.gpu
+
+CONSTS = dict(D11=1.3, D12=0.4, D22=1.1, D66=0.6, A44=0.8, A55=0.9, q=1.2, wscale=0.3)
+
+
+def cfg(key, value):
+    """A launch-plan switch changes the number of workgroups: prepared calls and workspace sizes of the earlier plan are dropped."""
+    from diffnet_amd import _lib, ops
+    _lib.config_set(key, value)
+    ops.call_cache_clear()
+
+
+def both_forms(fn):
+    cfg("FSDT_FORM", "elem")
+    try:
+        ref = fn()
+    finally:
+        cfg("FSDT_FORM", "")
+    return ref, fn()
+
+
+# element columns per row: 61, 62, 63 (one chunk / the closing column on a ghost lane / two chunks), 124, 125 (two / three chunks), 187
+@pytest.mark.parametrize("deg,ngp,nelx,nely,B", [(2, 3, 61, 5, 2), (2, 3, 62, 3, 1), (2, 3, 63, 4, 2), (2, 2, 124, 2, 1), (2, 4, 125, 3, 1), (2, 3, 187, 7, 1),
+                                                 (1, 2, 62, 9, 2), (1, 3, 63, 6, 1), (1, 4, 130, 5, 1), (3, 3, 62, 3, 1), (3, 4, 63, 4, 2), (3, 3, 125, 2, 1),
+                                                 (2, 3, 1, 1, 1), (1, 2, 1, 1, 2), (3, 4, 2, 1, 1), (2, 3, 3, 40, 1)])
+def test_stencil_form_equals_element_form(deg, ngp, nelx, nely, B):
+    from diffnet_amd import _lib, ops
+    sizes = (deg * nelx + 1, deg * nely + 1)
+    m = module(dict(nsd=2, domain_sizes=sizes, domain_lengths=(1.0, 0.8), domain_size=sizes[0], fem_basis_deg=deg, ngp_1d=ngp))
+    shape = (B, 1, sizes[1], sizes[0])
+    flds = [cu(seeded(shape, 40 + i)) for i in range(3)]
+    bcm = boundary_mask(shape).to(dev())
+    if sizes[0] > 12 and sizes[1] > 4:
+        bcm[0, 0, sizes[1] // 2, 3:9] = 1.0
+    wbc = cu(seeded(shape, 50))
+    try:
+        for mask in (None, bcm, bcm.to(torch.uint8)):
+            for plan in ("", "64,1", "128,2", "192,3", "256,5", "64,64"):
+                cfg("PLAN_FSDT", plan)
+                (ref, rsums, rnorms), (got, sums, norms) = both_forms(
+                    lambda: ops.fsdt_apply(m.geom, *flds, mask, (0.1, -0.2, 0.3), want_norms=True, **CONSTS))
+                for k in range(3):
+                    scale = float(ref[k].abs().max())
+                    assert float((got[k] - ref[k]).abs().max()) <= 4e-6 * scale, f"plan {plan!r} field {k} mask {None if mask is None else mask.dtype}"
+                np.testing.assert_allclose(sums.cpu().numpy(), rsums.cpu().numpy(), rtol=2e-6)
+                np.testing.assert_allclose(norms.cpu().numpy(), np.sqrt(rsums.cpu().numpy()), rtol=2e-6)
+            if mask is not None:
+                cfg("PLAN_FSDT", "")
+                # Dirichlet values as fields (one batched, one broadcast over the batch) next to a constant
+                bcs = (wbc, -0.2, wbc[:1] * 0.5)
+                (ref, _), (got, _) = both_forms(lambda: ops.fsdt_apply(m.geom, *flds, mask, bcs, **CONSTS))
+                for k in range(3):
+                    assert float((got[k] - ref[k]).abs().max()) <= 4e-6 * float(ref[k].abs().max()), f"value fields, field {k}"
+    finally:
+        cfg("PLAN_FSDT", "")
+        cfg("FSDT_FORM", "")
+
+
+@pytest.mark.parametrize("deg,ngp,n", [(1, 2, 40), (2, 3, 129), (2, 2, 33), (3, 4, 190)])
+def test_stencil_form_vs_oracle(deg, ngp, n):
+    """The default launch against the oracle's per-Gauss-point reference formulation and its autograd VJP (two chunks / four at Q3)."""
+    from diffnet_amd.elasticity import fsdt_loss, fsdt_residuals
+    from oracle.fem_oracle import Oracle
+    kw = dict(domain_size=n, fem_basis_deg=deg, ngp_1d=ngp)
+    m, o = module(kw), Oracle(**kw)
+    shape = (1, 1, n, n)
+    flds = [seeded(shape, 20 + i) for i in range(3)]
+    bc = boundary_mask(shape)
+    par = dict(E=2.0, v=0.3, q=1.5)
+    ref_in = [t.clone().requires_grad_(True) for t in flds]
+    Rref = o.fsdt_residuals(*ref_in, bc, th=0.2, Ks=5.0 / 6.0, **par)
+    gpu_in = [t.to(dev()).requires_grad_(True) for t in flds]
+    R = fsdt_residuals(m, *gpu_in, bc.to(dev()), h=0.2, K_s=5.0 / 6.0, **par)
+    for a, b in zip(R, Rref):
+        close(a, b.detach().numpy(), rtol=1e-4, arel=2e-5)
+    cots = [seeded(shape, 30 + i) for i in range(3)]
+    gref = torch.autograd.grad(Rref, ref_in, cots)
+    g = torch.autograd.grad(R, gpu_in, [c.to(dev()) for c in cots])
+    for a, b in zip(g, gref):
+        close(a, b.numpy(), rtol=1e-4, arel=1e-4)
+    norms = fsdt_loss(m, *gpu_in, bc.to(dev()), h=0.2, K_s=5.0 / 6.0, **par)
+    for nv, b in zip(norms, Rref):
+        np.testing.assert_allclose(float(nv), float(torch.linalg.vector_norm(b.double())), rtol=2e-5)
+
+
+def test_stencil_form_full_size_properties():
+    """configs[4] of BASELINE.json at its full size (1025 x 1025 nodes = 512 x 512 Q2 elements, 3 x 3 points): bitwise repeatable; Dirichlet rows carry
+    the boundary values; the homogeneous operator is symmetric (<a, K b> == <K a, b>: it is the Hessian of the plate energy); the same numbers as the
+    element form and as a differently partitioned launch."""
+    from diffnet_amd import _lib, ops
+    n = 1025
+    m = module(dict(domain_size=n, fem_basis_deg=2, ngp_1d=3))
+    shape = (1, 1, n, n)
+    a = [cu(seeded(shape, 1 + i)) for i in range(3)]
+    b = [cu(seeded(shape, 11 + i)) for i in range(3)]
+    bc = boundary_mask(shape).to(torch.uint8).to(dev())
+    consts = dict(CONSTS, q=0.0)
+    Ka, _ = ops.fsdt_apply(m.geom, *a, bc, (0.0, 0.0, 0.0), **consts)
+    Ka2, _ = ops.fsdt_apply(m.geom, *a, bc, (0.0, 0.0, 0.0), **consts)
+    assert all(torch.equal(x, y) for x, y in zip(Ka, Ka2))
+    Kb, _ = ops.fsdt_apply(m.geom, *b, bc, (0.0, 0.0, 0.0), **consts)
+    free = (bc == 0).double()
+    lhs = sum(float((x.double() * y.double() * free).sum()) for x, y in zip(a, Kb))
+    rhs = sum(float((x.double() * y.double() * free).sum()) for x, y in zip(Ka, b))
+    # (the masked rows / columns: boundary values 0 make K act on the free nodes only)
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs)), (lhs, rhs)
+    for k in range(3):
+        assert float((Ka[k] * bc).abs().max()) == 0.0
+    try:
+        cfg("PLAN_FSDT", "128,7")
+        Kp, _ = ops.fsdt_apply(m.geom, *a, bc, (0.0, 0.0, 0.0), **consts)
+        cfg("PLAN_FSDT", "")
+        cfg("FSDT_FORM", "elem")
+        Ke, _ = ops.fsdt_apply(m.geom, *a, bc, (0.0, 0.0, 0.0), **consts)
+    finally:
+        cfg("PLAN_FSDT", "")
+        cfg("FSDT_FORM", "")
+    for k in range(3):
+        scale = float(Ke[k].abs().max())
+        assert float((Ka[k] - Ke[k]).abs().max()) <= 4e-6 * scale
+        assert torch.equal(Ka[k], Kp[k])          # strips of another height: the seam layer is recomputed exactly

@@ -202,7 +202,9 @@ def test_fsdt_q2_middle_point_form_equals_the_generic_form():
     try:
         for plan in ("192,4", "64,3,4"):
             _lib.config_set("PLAN_FSDT", plan)
+            _lib.config_set("FSDT_FORM", "elem")          # (round 4: the default is the assembled-stencil form, tests/test_gpu_fsdt_stencil.py)
             a, sa = ops.fsdt_apply(m.geom, *flds, bc, (0.0, 0.1, 0.0), **consts)
+            _lib.config_set("FSDT_FORM", "")
             _lib.config_set("FSDT_GENERIC", "1")
             b, sb = ops.fsdt_apply(m.geom, *flds, bc, (0.0, 0.1, 0.0), **consts)
             _lib.config_set("FSDT_GENERIC", "")
@@ -212,6 +214,7 @@ def test_fsdt_q2_middle_point_form_equals_the_generic_form():
     finally:
         _lib.config_set("PLAN_FSDT", "")
         _lib.config_set("FSDT_GENERIC", "")
+        _lib.config_set("FSDT_FORM", "")
 
 
 @pytest.mark.parametrize("kw,B,cfg", [(dict(domain_size=512, ngp_1d=3), 3, None), (dict(domain_size=96, ngp_1d=2), 2, ("Q1_RULE_KERNEL", "1")),
