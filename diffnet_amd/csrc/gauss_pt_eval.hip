@@ -225,23 +225,31 @@ __global__ void __launch_bounds__(256) gpe_bwd_std_scalar_kernel(const float* __
     }
 }
 
+// (Round 4: a marching 2-D Q1 adjoint -- independent waves of 63 element columns, whole rows read once, hand-over by ds_bpermute -- was built and
+// measured against this kernel through the C ABI, 512^2 B = 16: 2 x 2 rule 17.2 vs 16.5 us, 3 x 3 35.8 vs 27.3 us (6.1 TB/s), 4 x 4 65.6 vs 46.8 us;
+// not kept: profiles/r4_adjoint_sizes.txt.  The 56 us / 2.97 TB/s of profiles/r2_ops_b.txt was the HOST time of the autograd call, not this kernel.)
 // Element-centric adjoint for the standard layout (the fast path): a workgroup owns a tile of 32 x 32 elements (2-D) or
 // 32 x 8 x 8 elements (3-D); thread (tx, ty) walks the tile's element rows / planes.  Phase A: per element the G
 // gradient values are read once (coalesced) and its NB^NSD nodal contributions sum_g tab[g][a] gout[g] (table through
 // scalar loads: uniform index) go to LDS as contrib[a][element] -- one slot per (element, a), no conflicts.  Phase B: the
 // tile's nodes are gathered from LDS (<= 2^NSD slots each, lower element first: fixed order) and written once.  Tiles
 // overlap by one element layer on the high side (recomputed) and own the nodes above their low face.
-template <int NSD, int NB>
+// SMALL (round 4, 3-D Q2 / Q3): tiles of 8 x 8 x 8 (Q2: 55 KB of LDS) / 8 x 8 x 4 (Q3: 64 KB) elements, elements dealt to the threads in
+// tile order -- the 32 x 8 x 8 tile needs 221 KB at Q2, and the per-node gather that served these meshes instead ran at 113 GB/s (27 Gauss points x
+// 8 candidate elements = 216 scattered loads per node: profiles/r2_ops_b.txt).
+template <int NSD, int NB, bool SMALL = false>
 __global__ void __launch_bounds__(256) gpe_bwd_tiled_kernel(const float* __restrict__ gout, const float* __restrict__ tables,
                                                             float* __restrict__ gin, const GpeGeom g, const int tiles_x, const int tiles_y,
                                                             const int tiles_z) {
     constexpr int S = NB - 1;
     constexpr int NBT = NSD == 2 ? NB * NB : NB * NB * NB;
-    constexpr int TX = 32, TY = NSD == 2 ? 32 : 8, TZ = NSD == 2 ? 1 : 8;       // elements per tile (incl. the recomputed layer)
+    constexpr int TX = SMALL ? 8 : 32, TY = SMALL ? 8 : (NSD == 2 ? 32 : 8), TZ = SMALL ? (NB >= 4 ? 4 : 8) : (NSD == 2 ? 1 : 8);       // elements per tile (incl. the recomputed layer)
+    static_assert(!SMALL || NSD == 3, "small tiles: 3-D");
     constexpr int TE = TX * TY * TZ;
     constexpr int LX = TX * S + 1, LY = TY * S + 1, LZ = NSD == 2 ? 1 : TZ * S + 1;
     extern __shared__ float contrib[];                                          // [NBT][TZ][TY][TX]
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                     // 32 x 8 threads
+    const int tx = SMALL ? (int)(threadIdx.x & 7) : (int)(threadIdx.x & 31), ty = SMALL ? (int)((threadIdx.x >> 3) & 7) : (int)(threadIdx.x >> 5);       // 32 x 8 threads (small: 8 x 8 x 4)
+    const int tzs = (int)(threadIdx.x >> 6);                                    // small tiles: the thread's first element plane
     unsigned t = blockIdx.x;
     {   // XCD-aware decode: x-neighbouring tiles share cache lines of every element row (rows are not line-aligned); a contiguous range of
         // the logical tile order per XCD lets them meet in one L2
@@ -266,7 +274,7 @@ __global__ void __launch_bounds__(256) gpe_bwd_tiled_kernel(const float* __restr
     float c[R][NBT];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int ly_e = NSD == 2 ? ty + 8 * r : ty, lz_e = NSD == 2 ? 0 : r;
+        const int ly_e = NSD == 2 ? ty + 8 * r : ty, lz_e = NSD == 2 ? 0 : (SMALL ? tzs + 4 * r : r);
         const int ey = ey0 + ly_e, ez = ez0 + lz_e;
         valid[r] = ex < g.nel[0] && ey < g.nel[1] && ez < g.nel[2];
         eoff[r] = ((unsigned)min(ez, g.nel[2] - 1) * (unsigned)g.nel[1] + (unsigned)min(ey, g.nel[1] - 1)) * (unsigned)g.nel[0] +
@@ -297,7 +305,7 @@ __global__ void __launch_bounds__(256) gpe_bwd_tiled_kernel(const float* __restr
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int ly_e = NSD == 2 ? ty + 8 * r : ty, lz_e = NSD == 2 ? 0 : r;
+        const int ly_e = NSD == 2 ? ty + 8 * r : ty, lz_e = NSD == 2 ? 0 : (SMALL ? tzs + 4 * r : r);
         const int slot = (lz_e * TY + ly_e) * TX + tx;
 #pragma unroll
         for (int a = 0; a < NBT; ++a) contrib[a * TE + slot] = valid[r] ? c[r][a] : 0.f;      // elements beyond the mesh contribute zero
@@ -637,6 +645,20 @@ extern "C" int dn_gauss_pt_eval_bwd(const float* grad_out, const float* tables, 
                 DN_LAUNCH_CHECK();
                 return 0;
             }
+        }
+    }
+    if (nsd == 3 && nbf >= 3 && config(CFG_GPE_GATHER) == nullptr) {       // 3-D Q2 / Q3: small tiles
+        const int tz_el = nbf >= 4 ? 4 : 8;
+        const int tx_ = g.nel[0] <= 8 ? 1 : (g.nel[0] - 1 + 6) / 7, ty_ = g.nel[1] <= 8 ? 1 : (g.nel[1] - 1 + 6) / 7;
+        const int tz_ = g.nel[2] <= tz_el ? 1 : (g.nel[2] - 1 + tz_el - 2) / (tz_el - 1);
+        const int64_t nblk = (int64_t)tx_ * ty_ * tz_ * batch;
+        const size_t ldsb = sizeof(float) * (size_t)nbt * 64 * tz_el;
+        // (Q3 on small meshes stays on the per-node gather: 21^3 elements are 63 tiles of 64 planes each -- 110 us against 49, gpurun_out/t11_ops.txt)
+        if (nblk < (1ll << 31) && (nbf == 3 || nblk >= 512)) {
+            if (nbf == 3) hipLaunchKernelGGL((gpe_bwd_tiled_kernel<3, 3, true>), dim3((unsigned)nblk), dim3(256), ldsb, s, grad_out, tables, grad_in, g, tx_, ty_, tz_);
+            else hipLaunchKernelGGL((gpe_bwd_tiled_kernel<3, 4, true>), dim3((unsigned)nblk), dim3(256), ldsb, s, grad_out, tables, grad_in, g, tx_, ty_, tz_);
+            DN_LAUNCH_CHECK();
+            return 0;
         }
     }
 #define K_BWDS(NSD, NB, ...)                                                                                                                  \

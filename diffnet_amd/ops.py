@@ -76,24 +76,69 @@ def _gpe_bwd(gout, tables, shape, nsd, nbf, stride):
     return gin
 
 
+class _GpeFn(torch.autograd.Function):
+    """gauss_pt_eval in eager mode: the launch behind a plain autograd.Function (the registered operator's dispatch costs ~75 us of host time per
+    call -- tools/bench_ops.py: 157 us for a forward + backward whose two kernels take 60 -- and an unchanged reference loss() makes eight such
+    calls per step).  Linear: the backward is the adjoint operator, whose backward is this one again."""
+
+    @staticmethod
+    def forward(ctx, x, tables, nsd, nbf, stride):
+        ctx.save_for_backward(tables)
+        ctx.meta = (tuple(x.shape), nsd, nbf, stride)
+        return _gpe_fwd(x, tables, nsd, nbf, stride)
+
+    @staticmethod
+    def backward(ctx, g):
+        (tables,) = ctx.saved_tensors
+        shape, nsd, nbf, stride = ctx.meta
+        return _GaussPtEvalT.apply(g, tables, shape, nsd, nbf, stride), None, None, None, None
+
+
+class _GpeTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gout, tables, shape, nsd, nbf, stride):
+        ctx.save_for_backward(tables)
+        ctx.meta = (nsd, nbf, stride)
+        return _gpe_bwd(gout, tables, tuple(shape), nsd, nbf, stride)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (tables,) = ctx.saved_tensors
+        nsd, nbf, stride = ctx.meta
+        return _GaussPtEval.apply(gg, tables, nsd, nbf, stride), None, None, None, None, None
+
+
+def _wants_grad(t):
+    return torch.is_grad_enabled() and isinstance(t, torch.Tensor) and t.requires_grad
+
+
 class _GaussPtEval:
-    """`gauss_pt_eval` as a registered operator (diffnet_mi::gauss_pt_eval_fwd, diffnet_amd/torch_ops.py): linear in the field,
-    its backward is the adjoint operator `_GaussPtEvalT`, whose backward is this one again -- differentiable to any order like
-    the reference's conv formulation, and an ordinary graph node for torch.compile / torch.export."""
+    """`gauss_pt_eval`: linear in the field, its backward is the adjoint operator `_GaussPtEvalT`, whose backward is this one again --
+    differentiable to any order like the reference's conv formulation.  Under torch.compile / torch.export the registered operator
+    diffnet_mi::gauss_pt_eval_fwd (diffnet_amd/torch_ops.py: an ordinary graph node); in eager mode the same launch behind a plain
+    autograd.Function, or directly when nothing requires a gradient."""
 
     @staticmethod
     def apply(x, tables, nsd, nbf, stride):
-        from . import torch_ops
-        return torch_ops.gauss_pt_eval_fwd(x, tables, nsd, nbf, stride)
+        if torch.compiler.is_compiling():
+            from . import torch_ops
+            return torch_ops.gauss_pt_eval_fwd(x, tables, nsd, nbf, stride)
+        if _wants_grad(x):
+            return _GpeFn.apply(x, tables, nsd, nbf, stride)
+        return _gpe_fwd(x, tables, nsd, nbf, stride)
 
 
 class _GaussPtEvalT:
-    """Adjoint of `_GaussPtEval` (element / Gauss-point cotangents -> nodal field): diffnet_mi::gauss_pt_eval_bwd."""
+    """Adjoint of `_GaussPtEval` (element / Gauss-point cotangents -> nodal field): diffnet_mi::gauss_pt_eval_bwd under torch.compile."""
 
     @staticmethod
     def apply(gout, tables, shape, nsd, nbf, stride):
-        from . import torch_ops
-        return torch_ops.gauss_pt_eval_bwd(gout, tables, list(shape), nsd, nbf, stride)
+        if torch.compiler.is_compiling():
+            from . import torch_ops
+            return torch_ops.gauss_pt_eval_bwd(gout, tables, list(shape), nsd, nbf, stride)
+        if _wants_grad(gout):
+            return _GpeTFn.apply(gout, tables, tuple(shape), nsd, nbf, stride)
+        return _gpe_bwd(gout, tables, tuple(shape), nsd, nbf, stride)
 
 
 def stack_tables(N, nsd):
@@ -148,8 +193,45 @@ def assemble(r_split, nsd, nbf=2, out=None):
     """Element->node assembly (Q1_2D/3D_vector_assembly of the reference scripts, any degree):
     returns `out + scatter_add(r_split)` (out = zeros when omitted).  Deterministic gather form; registered operator
     diffnet_mi::assemble (linear: its backward is the per-element gather, whose backward is the assembly)."""
-    from . import torch_ops
-    return torch_ops.assemble(r_split, nsd, nbf) if out is None else torch_ops.assemble_onto(r_split, out, nsd, nbf)
+    if torch.compiler.is_compiling():
+        from . import torch_ops
+        return torch_ops.assemble(r_split, nsd, nbf) if out is None else torch_ops.assemble_onto(r_split, out, nsd, nbf)
+    if _wants_grad(r_split) or _wants_grad(out):
+        return _AssembleFn.apply(r_split, out, nsd, nbf)
+    return _assemble_raw(r_split, nsd, nbf, out)
+
+
+class _AssembleFn(torch.autograd.Function):
+    """Assembly in eager mode (see _GpeFn): backward = the per-element gather, whose backward is the assembly again."""
+
+    @staticmethod
+    def forward(ctx, r_split, base, nsd, nbf):
+        ctx.meta = (tuple(r_split.shape), nsd, nbf, base is not None)
+        return _assemble_raw(r_split, nsd, nbf, base)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, nsd, nbf, has_base = ctx.meta
+        gr = _assemble_gather(g, shape, nsd, nbf) if ctx.needs_input_grad[0] else None
+        return gr, (g if has_base and ctx.needs_input_grad[1] else None), None, None
+
+
+class _AssembleGatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, shape, nsd, nbf):
+        ctx.meta = (nsd, nbf)
+        return _assemble_bwd_raw(g.contiguous(), tuple(shape), nsd, nbf)
+
+    @staticmethod
+    def backward(ctx, gg):
+        nsd, nbf = ctx.meta
+        return assemble(gg, nsd, nbf), None, None, None
+
+
+def _assemble_gather(g, shape, nsd, nbf):
+    if _wants_grad(g):
+        return _AssembleGatherFn.apply(g, tuple(shape), nsd, nbf)
+    return _assemble_bwd_raw(g.contiguous(), tuple(shape), nsd, nbf)
 
 
 # ------------------------------------------------------------------------------------------------
