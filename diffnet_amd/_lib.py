@@ -105,6 +105,9 @@ SYMBOLS = {
     "dn_conv2d_k4s2_wrw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int64] * 5 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "dn_conv3d_k4s2_down": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int64] * 6 + [C.c_void_p]),
     "dn_conv3d_k4s2_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int64] * 6 + [C.c_void_p]),
+    "dn_conv3d_k4s2_workspace_bytes": (C.c_int64, [C.c_int32] + [C.c_int64] * 6),
+    "dn_conv3d_k4s2_down_ws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int64] * 6 + [C.c_void_p, C.c_int64, C.c_void_p]),
+    "dn_conv3d_k4s2_up_ws": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int64] * 6 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "dn_conv2d_valid_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] * 6 + [C.c_void_p]),
     "dn_conv2d_valid_bwd_data": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] * 6 + [C.c_void_p]),
     "dn_conv2d_valid_bwd_weight": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] * 6 + [C.c_void_p]),

@@ -9,6 +9,8 @@
 // Implicit GEMMs, 64 x 64 tiles per 256-thread workgroup (2 x 2 waves of 32 x 32), one fine channel (64 taps) per K-step of `down`,
 // two coarse channels per K-step of `up`; `up` runs one GEMM per output parity with K = (m, 2 x 2 x 2 taps), the z parity split
 // over blockIdx.z (halves the accumulators and the staged neighbourhood), both x parities of a position stored as one float2.
+#include <algorithm>
+
 #include "dn_common.h"
 
 namespace dn {
@@ -21,8 +23,13 @@ __device__ __forceinline__ c3_f32x4 mfma4_3(float a, float b, c3_f32x4 c) { retu
 // ---- down ---------------------------------------------------------------------------------------------------------------------
 template <int TM>
 __global__ void __launch_bounds__(256) conv3d_k4s2_down_kernel(const float* __restrict__ fine, const float* __restrict__ w,
-                                                               float* __restrict__ coarse, int B, int C, int M, int D, int H, int W) {
+                                                               float* __restrict__ coarse, int B, int C, int M, int D, int H, int W, int cs,
+                                                               size_t slice_stride) {
     constexpr int RT = TM / 32;
+    // split K (round 4): blockIdx.z = slice of `cs` fine channels, its partial result goes to coarse + slice * slice_stride (conv3d_ksum_kernel adds the
+    // slices in order); one slice = the whole contraction written to `coarse` itself
+    const int c_lo = (int)blockIdx.z * cs, c_hi = min(C, c_lo + cs);
+    coarse += (size_t)blockIdx.z * slice_stride;
     __shared__ __attribute__((aligned(16))) float As[2][TM][C3_SA];
     __shared__ __attribute__((aligned(16))) float Bs[2][64][C3_SB];
     const int tid = threadIdx.x;
@@ -77,12 +84,12 @@ __global__ void __launch_bounds__(256) conv3d_k4s2_down_kernel(const float* __re
             *reinterpret_cast<float2*>(&As[buf][mm][kk + 2]) = make_float2(areg[r].z, areg[r].w);
         }
     };
-    issue(0);
+    issue(c_lo);
     commit(0);
     __syncthreads();
-    for (int c = 0; c < C; ++c) {
-        const int buf = c & 1;
-        const bool more = c + 1 < C;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int buf = (c - c_lo) & 1;
+        const bool more = c + 1 < c_hi;
         if (more) issue(c + 1);
 #pragma unroll 4
         for (int k4 = 0; k4 < 16; ++k4) {
@@ -118,7 +125,8 @@ __global__ void __launch_bounds__(256) conv3d_k4s2_down_kernel(const float* __re
 // blockIdx.z = pz.  One MFMA k-step = one coarse channel x the 4 in-plane taps (a_y, a_x) of one z tap a_z.
 template <int TC>
 __global__ void __launch_bounds__(256) conv3d_k4s2_up_kernel(const float* __restrict__ coarse, const float* __restrict__ w,
-                                                             float* __restrict__ fine, int B, int C, int M, int D, int H, int W) {
+                                                             float* __restrict__ fine, int B, int C, int M, int D, int H, int W, int ss,
+                                                             size_t slice_stride) {
     constexpr int KC = 2;                                // coarse channels per K-step
     constexpr int RT = TC / 32;
     // weights of the step, the 32 taps whose kz has this block's z parity: Ws[mm][az][ky * 4 + kx][c]
@@ -126,7 +134,8 @@ __global__ void __launch_bounds__(256) conv3d_k4s2_up_kernel(const float* __rest
     // coarse neighbourhood: Ps[mm][az][(dj + 1) * 3 + dk + 1][n]
     __shared__ __attribute__((aligned(16))) float Ps[2][KC][2][9][C3_SB];
     const int tid = threadIdx.x;
-    const int pz = blockIdx.z;
+    const int pz = blockIdx.z & 1, slice = blockIdx.z >> 1;      // split K: slice of `ss` K-steps, partial result at fine + slice * slice_stride
+    fine += (size_t)slice * slice_stride;
     const int HW = H * W, vol = D * HW, tiles_per_sample = (vol + C3_TN - 1) / C3_TN;
     const int b = blockIdx.x / tiles_per_sample, p0 = (blockIdx.x % tiles_per_sample) * C3_TN;
     const int c0 = blockIdx.y * TC;
@@ -191,12 +200,13 @@ __global__ void __launch_bounds__(256) conv3d_k4s2_up_kernel(const float* __rest
         }
     };
     const int nsteps = (M + KC - 1) / KC;
-    issue(0);
+    const int st_lo = slice * ss, st_hi = min(nsteps, st_lo + ss);
+    issue(st_lo * KC);
     commit(0);
     __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
-        const int buf = st & 1;
-        const bool more = st + 1 < nsteps;
+    for (int st = st_lo; st < st_hi; ++st) {
+        const int buf = (st - st_lo) & 1;
+        const bool more = st + 1 < st_hi;
         if (more) issue((st + 1) * KC);
 #pragma unroll
         for (int mm = 0; mm < KC; ++mm)
@@ -245,6 +255,28 @@ __global__ void __launch_bounds__(256) conv3d_k4s2_up_kernel(const float* __rest
     }
 }
 
+// out[i] = part[0][i] + part[1][i] + ... in slice order (deterministic)
+__global__ void __launch_bounds__(256) conv3d_ksum_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int S, size_t stride) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = part[i];
+        for (int k = 1; k < S; ++k) v += part[(size_t)k * stride + i];
+        out[i] = v;
+    }
+}
+
+// Split of the contraction over workgroups for the deep, narrow layers of the generator (128 -> 128 channels on 4^3 positions is ONE position tile: two
+// workgroups walked 8192 products each in 250 us -- gpurun_out/t14_kt, the 128^3 step spent 1.7 of its 3.4 ms in launches of <= 32 workgroups): `units`
+// K-steps go to S slices so that the launch has ~512 workgroups, >= 4 steps per slice; returns the steps per slice (S = ceil(units / steps))
+static int c3_split(int64_t wgs, int units, int* S) {
+    *S = 1;
+    if (wgs >= 256 || units < 8) return units;
+    int s = (int)std::min<int64_t>((512 + wgs - 1) / wgs, units / 4);
+    if (s < 2) return units;
+    const int per = (units + s - 1) / s;
+    *S = (units + per - 1) / per;
+    return per;
+}
+
 static int c3_check(int64_t B, int64_t C, int64_t M, int64_t D, int64_t H, int64_t W) {
     if (B < 1 || C < 1 || M < 1 || D < 1 || H < 1 || W < 1) return DN_E_BADARG;
     if (8 * D * H * W >= (1ll << 31) || B * ((D * H * W + 63) / 64) >= (1ll << 31)) return DN_E_UNSUPPORTED;
@@ -255,36 +287,79 @@ static int c3_check(int64_t B, int64_t C, int64_t M, int64_t D, int64_t H, int64
 
 using namespace dn;
 
-extern "C" int dn_conv3d_k4s2_down(const float* fine, const float* w, float* coarse, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
-                                   int64_t W, void* stream) {
+extern "C" int64_t dn_conv3d_k4s2_workspace_bytes(int32_t up, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H, int64_t W) {
+    if (c3_check(B, C, M, D, H, W)) return DN_E_BADARG;
+    const int64_t tiles = B * ((D * H * W + C3_TN - 1) / C3_TN);
+    int S;
+    if (up) {
+        c3_split(tiles * ((C + (C <= 32 ? 31 : 63)) / (C <= 32 ? 32 : 64)) * 2, (int)((M + 1) / 2), &S);
+        return S > 1 ? (int64_t)S * B * C * 8 * D * H * W * (int64_t)sizeof(float) : 0;
+    }
+    c3_split(tiles * ((M + (M <= 32 ? 31 : 63)) / (M <= 32 ? 32 : 64)), (int)C, &S);
+    return S > 1 ? (int64_t)S * B * M * D * H * W * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int dn_conv3d_k4s2_down_ws(const float* fine, const float* w, float* coarse, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
+                                      int64_t W, void* workspace, int64_t workspace_bytes, void* stream) {
     if (int rc = c3_check(B, C, M, D, H, W)) return rc;
     if (!fine || !w || !coarse) return DN_E_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned tiles = (unsigned)(B * ((D * H * W + C3_TN - 1) / C3_TN));
+    const unsigned mtiles = (unsigned)(M <= 32 ? (M + 31) / 32 : (M + 63) / 64);
+    int S = 1, cs = (int)C;
+    const size_t n = (size_t)(B * M * D * H * W);
+    if (workspace) {
+        cs = c3_split((int64_t)tiles * mtiles, (int)C, &S);
+        if (S > 1 && workspace_bytes < (int64_t)((size_t)S * n * sizeof(float))) return DN_E_WORKSPACE;
+    }
+    float* dst = S > 1 ? reinterpret_cast<float*>(workspace) : coarse;
     if (M <= 32) {
-        hipLaunchKernelGGL((conv3d_k4s2_down_kernel<32>), dim3(tiles, (unsigned)((M + 31) / 32)), dim3(256), 0, s, fine, w, coarse, (int)B, (int)C,
-                           (int)M, (int)D, (int)H, (int)W);
+        hipLaunchKernelGGL((conv3d_k4s2_down_kernel<32>), dim3(tiles, mtiles, S), dim3(256), 0, s, fine, w, dst, (int)B, (int)C, (int)M, (int)D, (int)H, (int)W, cs, n);
     } else {
-        hipLaunchKernelGGL((conv3d_k4s2_down_kernel<64>), dim3(tiles, (unsigned)((M + 63) / 64)), dim3(256), 0, s, fine, w, coarse, (int)B, (int)C,
-                           (int)M, (int)D, (int)H, (int)W);
+        hipLaunchKernelGGL((conv3d_k4s2_down_kernel<64>), dim3(tiles, mtiles, S), dim3(256), 0, s, fine, w, dst, (int)B, (int)C, (int)M, (int)D, (int)H, (int)W, cs, n);
     }
     DN_LAUNCH_CHECK();
+    if (S > 1) {
+        hipLaunchKernelGGL(conv3d_ksum_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, dst, coarse, n, S, n);
+        DN_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+extern "C" int dn_conv3d_k4s2_up_ws(const float* coarse, const float* w, float* fine, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
+                                    int64_t W, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (int rc = c3_check(B, C, M, D, H, W)) return rc;
+    if (!fine || !w || !coarse) return DN_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned tiles = (unsigned)(B * ((D * H * W + C3_TN - 1) / C3_TN));
+    const unsigned ctiles = (unsigned)(C <= 32 ? (C + 31) / 32 : (C + 63) / 64);
+    const int nsteps = (int)((M + 1) / 2);
+    int S = 1, ss = nsteps;
+    const size_t n = (size_t)(B * C * 8 * D * H * W);
+    if (workspace) {
+        ss = c3_split((int64_t)tiles * ctiles * 2, nsteps, &S);
+        if (S > 1 && workspace_bytes < (int64_t)((size_t)S * n * sizeof(float))) return DN_E_WORKSPACE;
+    }
+    float* dst = S > 1 ? reinterpret_cast<float*>(workspace) : fine;
+    if (C <= 32) {
+        hipLaunchKernelGGL((conv3d_k4s2_up_kernel<32>), dim3(tiles, ctiles, 2 * S), dim3(256), 0, s, coarse, w, dst, (int)B, (int)C, (int)M, (int)D, (int)H, (int)W, ss, n);
+    } else {
+        hipLaunchKernelGGL((conv3d_k4s2_up_kernel<64>), dim3(tiles, ctiles, 2 * S), dim3(256), 0, s, coarse, w, dst, (int)B, (int)C, (int)M, (int)D, (int)H, (int)W, ss, n);
+    }
+    DN_LAUNCH_CHECK();
+    if (S > 1) {
+        hipLaunchKernelGGL(conv3d_ksum_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, dst, fine, n, S, n);
+        DN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int dn_conv3d_k4s2_down(const float* fine, const float* w, float* coarse, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
+                                   int64_t W, void* stream) {
+    return dn_conv3d_k4s2_down_ws(fine, w, coarse, B, C, M, D, H, W, nullptr, 0, stream);
 }
 
 extern "C" int dn_conv3d_k4s2_up(const float* coarse, const float* w, float* fine, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
                                  int64_t W, void* stream) {
-    if (int rc = c3_check(B, C, M, D, H, W)) return rc;
-    if (!fine || !w || !coarse) return DN_E_BADARG;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const unsigned tiles = (unsigned)(B * ((D * H * W + C3_TN - 1) / C3_TN));
-    if (C <= 32) {
-        hipLaunchKernelGGL((conv3d_k4s2_up_kernel<32>), dim3(tiles, (unsigned)((C + 31) / 32), 2), dim3(256), 0, s, coarse, w, fine, (int)B, (int)C,
-                           (int)M, (int)D, (int)H, (int)W);
-    } else {
-        hipLaunchKernelGGL((conv3d_k4s2_up_kernel<64>), dim3(tiles, (unsigned)((C + 63) / 64), 2), dim3(256), 0, s, coarse, w, fine, (int)B, (int)C,
-                           (int)M, (int)D, (int)H, (int)W);
-    }
-    DN_LAUNCH_CHECK();
-    return 0;
+    return dn_conv3d_k4s2_up_ws(coarse, w, fine, B, C, M, D, H, W, nullptr, 0, stream);
 }

@@ -207,6 +207,15 @@ def _wrw3d(fine, coarse):
     return gw
 
 
+def _c3_workspace(up, B, Cn, M, d, h, wd, device):
+    """Workspace of the split contraction (dn_conv3d_k4s2_workspace_bytes; None where the library does not split): a fresh block from the caching
+    allocator, ordered on the launch stream like the output."""
+    nbytes = _lib.lib().dn_conv3d_k4s2_workspace_bytes(up, B, Cn, M, d, h, wd)
+    if nbytes < 0:
+        _lib.check(int(nbytes), "dn_conv3d_k4s2_workspace_bytes")
+    return (torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None), nbytes
+
+
 def _c3_down(fine, w):
     """coarse = w (*)_s2 fine (dn_conv3d_k4s2_down): Conv3d forward / ConvTranspose3d input gradient."""
     fine, w = fine.contiguous(), w.contiguous()
@@ -214,8 +223,9 @@ def _c3_down(fine, w):
     d, h, wd = (s_ // 2 for s_ in fine.shape[2:])
     M = w.shape[0]
     out = torch.empty((B, M, d, h, wd), dtype=torch.float32, device=fine.device)
-    rc = _lib.lib().dn_conv3d_k4s2_down(_p(fine), _p(w), _p(out), B, Cn, M, d, h, wd, _stream(fine))
-    _lib.check(rc, "dn_conv3d_k4s2_down")
+    ws, nbytes = _c3_workspace(0, B, Cn, M, d, h, wd, fine.device)
+    rc = _lib.lib().dn_conv3d_k4s2_down_ws(_p(fine), _p(w), _p(out), B, Cn, M, d, h, wd, _p(ws), nbytes, _stream(fine))
+    _lib.check(rc, "dn_conv3d_k4s2_down_ws")
     return out
 
 
@@ -225,8 +235,9 @@ def _c3_up(coarse, w):
     B, M, d, h, wd = coarse.shape
     Cn = w.shape[1]
     out = torch.empty((B, Cn, 2 * d, 2 * h, 2 * wd), dtype=torch.float32, device=coarse.device)
-    rc = _lib.lib().dn_conv3d_k4s2_up(_p(coarse), _p(w), _p(out), B, Cn, M, d, h, wd, _stream(coarse))
-    _lib.check(rc, "dn_conv3d_k4s2_up")
+    ws, nbytes = _c3_workspace(1, B, Cn, M, d, h, wd, coarse.device)
+    rc = _lib.lib().dn_conv3d_k4s2_up_ws(_p(coarse), _p(w), _p(out), B, Cn, M, d, h, wd, _p(ws), nbytes, _stream(coarse))
+    _lib.check(rc, "dn_conv3d_k4s2_up_ws")
     return out
 
 

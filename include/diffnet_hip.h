@@ -357,6 +357,16 @@ int dn_conv3d_k4s2_down(const float *fine, const float *w, float *coarse, int64_
                         int64_t W, void *stream);
 int dn_conv3d_k4s2_up(const float *coarse, const float *w, float *fine, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
                       int64_t W, void *stream);
+/* The same contractions with a workspace (round 4): the deep, narrow layers of the generator (128 -> 128 channels on 4^3 positions ...) fill
+ * only a few position tiles, so the contraction itself is split over workgroups -- slices of fine channels (`down`) / coarse channel
+ * pairs (`up`) write partial results into the workspace and a second launch adds them in slice order (deterministic).  The library
+ * decides the split from the shapes; dn_conv3d_k4s2_workspace_bytes (up = 0 / 1) returns what that split needs (0: no split).  A NULL
+ * workspace runs the unsplit launch, which is what dn_conv3d_k4s2_down / _up are. */
+int64_t dn_conv3d_k4s2_workspace_bytes(int32_t up, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H, int64_t W);
+int dn_conv3d_k4s2_down_ws(const float *fine, const float *w, float *coarse, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
+                           int64_t W, void *workspace, int64_t workspace_bytes, void *stream);
+int dn_conv3d_k4s2_up_ws(const float *coarse, const float *w, float *fine, int64_t B, int64_t C, int64_t M, int64_t D, int64_t H,
+                         int64_t W, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Stride-1 "valid" k x k convolutions (k <= 7) with optional bias: the auto-encoder's stem / head layers behind an explicit
  * ReflectionPad2d (DiffNet/networks/autoencoders.py:13 `nn.Conv2d(in_channels, dim*2, 7)`, :75 `nn.Conv2d(.., out_channels, 3)`,
