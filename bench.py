@@ -444,6 +444,36 @@ def config_rows(dev, budget_s=150.0):
         add(name, us, us, ALG_BYTES_PER_NODE * B * n * n, B * fem.geom.nelem_total * fem.geom.ngp_total,
             "whole training step (UNet forward + FEM loss + backward + Adam), wall clock; frac counts the FEM bytes only")
 
+    def gen3d(name, n, B):
+        if time.perf_counter() - t_start > budget_s:
+            return
+        from diffnet_amd.networks.wgan3d import GoodGenerator
+        torch.manual_seed(0)
+        net = GoodGenerator(1, 1).to(dev)
+        fem = DiffNet3DFEM(net, domain_size=n, ngp_1d=2, nsd=3).to(dev)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        nu = torch.rand(B, 1, n, n, n, device=dev) + 0.5
+        bc = torch.zeros(B, 1, n, n, n, device=dev, dtype=torch.uint8)
+        bc[..., 0] = 1; bc[..., -1] = 1
+
+        def fn():
+            opt.zero_grad(set_to_none=True)
+            loss = fem.energy_loss(net(nu), nu, None, dirichlet=[(bc, 0.0)], c=0.5)
+            loss.backward()
+            opt.step()
+
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = 10
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / k * 1e6
+        add(name, us, us, ALG_BYTES_PER_NODE * B * n ** 3, B * fem.geom.nelem_total * fem.geom.ngp_total,
+            "whole training step (GoodGenerator forward + FEM loss + backward + Adam: IBN_3D.py:114-136, wgan3d.py:23-98), wall clock; frac counts the FEM bytes only")
+
     poisson("cfg1 2-D 64^2 Q1 2x2 B=1 energy c=1/2", 2, 64, 2, 1, 0.5)
     poisson("cfg2 2-D 512^2 Q1 3x3 B=1", 2, 512, 3, 1, 1.0)
     poisson("cfg2 2-D 512^2 Q1 3x3 B=16", 2, 512, 3, 16, 1.0, nsets=4)
@@ -457,6 +487,7 @@ def config_rows(dev, budget_s=150.0):
     fsdt("cfg5 FSDT plate 1025^2 nodes (512^2 Q2 elements) 3x3 B=1", 1025, 1)
     fsdt("cfg5 FSDT plate 1025^2 Q2 3x3 B=8", 1025, 8)
     unet("cfg2 UNet(2->1) + FEM loss training step, 512^2 B=16", 512, 16)
+    gen3d("cfg3 GoodGenerator(1->1) + FEM loss training step, 128^3 B=1", 128, 1)
     return rows
 
 

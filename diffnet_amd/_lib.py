@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DN_LIB_PATH") or os.path.join(HERE, "libdiffnet_hip.so")     # DN_LIB_PATH: a variant build (tools/variant_build.sh)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 DN_E = {-1: "DN_E_BADARG", -2: "DN_E_UNSUPPORTED", -3: "DN_E_WORKSPACE", -4: "DN_E_HANDOVER"}
 
@@ -50,7 +50,8 @@ class DnFsdtArgs(C.Structure):
                 ("D11", C.c_float), ("D12", C.c_float), ("D22", C.c_float), ("D66", C.c_float), ("A44", C.c_float),
                 ("A55", C.c_float), ("q", C.c_float), ("wscale", C.c_float),
                 ("out", C.c_void_p * 3), ("sumsq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("in_scale", C.c_void_p), ("norms", C.c_void_p), ("in_num", C.c_void_p), ("in_den", C.c_void_p)]
+                ("in_scale", C.c_void_p), ("norms", C.c_void_p), ("in_num", C.c_void_p), ("in_den", C.c_void_p),
+                ("defer_sums", C.c_int32), ("reserved_", C.c_int32), ("den_workspace", C.c_void_p)]
 
 
 I32x3 = C.c_int32 * 3

@@ -203,12 +203,15 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
     const uint8_t* m8 = reinterpret_cast<const uint8_t*>(p.mask) + (MK == 1 ? mo : 0);
     const float* mf = reinterpret_cast<const float*>(p.mask) + (MK == 2 ? mo : 0);
 
+    __shared__ double den_red[3 * 12], den_bc[3];
+    float den3[3] = {0.f, 0.f, 0.f};
+    if (p.den_part) den_from_partials(p, (int)threadIdx.x, (int)blockDim.x, den_red, den_bc, den3);      // consumer of a deferring launch (fsdt_common.h)
     float fscale[3] = {1.f, 1.f, 1.f};
     if (p.in_scale) { fscale[0] = p.in_scale[0]; fscale[1] = p.in_scale[1]; fscale[2] = p.in_scale[2]; }
     if (p.in_num) {               // cotangent of the norms over the norms (the VJP of ||R_k||), torch's convention at ||R_k|| == 0: zero
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float den = p.in_den[k];
+            const float den = p.den_part ? den3[k] : p.in_den[k];
             fscale[k] = den > 0.f ? p.in_num[k] / den : 0.f;
         }
     }
@@ -489,7 +492,10 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
         for (int k = 0; k < 3; ++k) sq[k] += spin_poison;
         if (spin_poison != spin_poison && p.counter != nullptr && (threadIdx.x & 63u) == 0u) atomicOr(p.counter + 8, 1u);      // DN_WS_ERRWORD
     }
-    if (p.want_sums) finish_sums3(p, sq, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
+    if (p.want_sums) {
+        if (p.defer_sums) store_partials3(p, sq, (int)threadIdx.x, (int)blockDim.x, red);
+        else finish_sums3(p, sq, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
+    }
 }
 
 static inline int fs_ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -616,9 +622,12 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     int rc = fsdt_validate(m);
     if (rc) return rc;
     if (!a || !a->w || !a->phi_x || !a->phi_y) return DN_E_BADARG;
-    if (!a->out[0] && !a->out[1] && !a->out[2] && !a->sumsq && !a->norms) return DN_E_BADARG;
-    if ((a->in_num != nullptr) != (a->in_den != nullptr) || (a->in_num && a->in_scale)) return DN_E_BADARG;
-    const bool want_red = a->sumsq || a->norms;
+    if (!a->out[0] && !a->out[1] && !a->out[2] && !a->sumsq && !a->norms && !a->defer_sums) return DN_E_BADARG;
+    // in_num goes with in_den or, round 4, with den_workspace (the norms formed from a deferring launch's partials), not with both, not with in_scale
+    if (a->in_num ? ((a->in_den != nullptr) == (a->den_workspace != nullptr) || a->in_scale != nullptr) : (a->in_den != nullptr || a->den_workspace != nullptr))
+        return DN_E_BADARG;
+    if (a->defer_sums && a->den_workspace) return DN_E_BADARG;          // (sumsq / norms of a consuming call are the PRODUCER's)
+    const bool want_red = a->defer_sums || (!a->den_workspace && (a->sumsq || a->norms));
     const bool any_bcf = a->bc_mask && (a->bc_field[0] || a->bc_field[1] || a->bc_field[2]);
     const FsdtGeom g = fsdt_plan(m, !any_bcf);
     // round 4: the assembled-stencil form (fsdt_st.hip) is the default; dn_config_set("FSDT_FORM", "elem"), "FSDT_GENERIC" or a chained
@@ -654,6 +663,9 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     pp.nelx = (m->nx - 1) / m->degree; pp.nely = (m->ny - 1) / m->degree;
     pp.rows_per_strip = g.R;
     pp.want_sums = want_red ? 1 : 0;
+    pp.defer_sums = a->defer_sums ? 1 : 0;
+    pp.den_counter = reinterpret_cast<const unsigned*>(a->den_workspace);
+    pp.den_part = a->den_workspace ? reinterpret_cast<const double*>(reinterpret_cast<const char*>(a->den_workspace) + FSDT_WS_HEADER) : nullptr;
     pp.spin_limit = config(CFG_HANDOVER_SPIN_LIMIT) ? std::atoi(config(CFG_HANDOVER_SPIN_LIMIT)) : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (stencil) {

@@ -24,7 +24,12 @@ struct FsdtParams {
     unsigned* counter;
     double* sumsq;                         // 3 doubles
     int nx, ny, nelx, nely, rows_per_strip, want_sums, spin_limit;
+    int defer_sums;                        // the launch stores its per-workgroup partials (and their count) and leaves the reduction to its consumer
+    const unsigned* den_counter;           // consumer: header of the producer's workspace (word 4: its number of workgroups) ...
+    const double* den_part;                // ... and its partials [3][nblocks]
 };
+
+constexpr int FSDT_WS_NBLOCKS_WORD = 4;    // word of the workspace header in which a deferring launch leaves its number of workgroups
 
 // Deterministic in-kernel final reduction of three scalars (same protocol as finish_sums in poisson_common.h).
 __device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&sq)[3], int tid, int nthreads, double* red, int* flag) {
@@ -84,6 +89,66 @@ __device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&
         }
         if (tid == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// defer_sums: the workgroup's three partials and nothing else (no arrival counter, no wait: a kernel boundary orders them before the consumer)
+__device__ __forceinline__ void store_partials3(const FsdtParams& p, const float (&sq)[3], int tid, int nthreads, double* red) {
+    const int nblocks = gridDim.x * gridDim.y * gridDim.z;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double s = block_sum((double)sq[k], red, tid, nthreads);
+        if (tid == 0) p.part[(size_t)k * nblocks + blk] = s;
+    }
+    if (tid == 0 && blk == 0) p.counter[FSDT_WS_NBLOCKS_WORD] = (unsigned)nblocks;
+}
+
+// Consumer of a deferring launch: every workgroup forms the producer's three sums from its partials in the order finish_sums3 uses (thread-strided,
+// then the block sum: bitwise the same numbers) and returns their square roots; workgroup 0 writes the producer's sumsq / norms where asked.
+// Every thread of the workgroup must call it (block sums).
+__device__ __forceinline__ void den_from_partials(const FsdtParams& p, int tid, int nthreads, double* red, double* bc3, float (&den)[3]) {
+    const int nb = (int)p.den_counter[FSDT_WS_NBLOCKS_WORD];
+    // at the start of EVERY workgroup of the consumer: the partials are requested eight per sum at a time before any is added (one L2 round trip per 24
+    // loads; a load-add loop cost the B = 8 launch 29 us), and the three block sums share one LDS exchange (wave sums, then the waves in order: the
+    // additions of block_sum)
+    double e3[3] = {0.0, 0.0, 0.0};
+    for (int i0 = tid; i0 < nb; i0 += nthreads * 8) {
+        double v[3][8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * nthreads;
+                v[k][j] = p.den_part[(size_t)k * nb + (i < nb ? i : 0)];
+            }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e3[k] += (i0 + j * nthreads < nb) ? v[k][j] : 0.0;
+    }
+    const int lane = tid & (DN_WAVE - 1), wave = tid / DN_WAVE, nw = (nthreads + DN_WAVE - 1) / DN_WAVE;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double s = wave_sum(e3[k]);
+        if (lane == 0) red[k * nw + wave] = s;          // red: >= 3 * nthreads / 64 doubles
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double e = 0.0;
+            for (int w = 0; w < nw; ++w) e += red[k * nw + w];
+            bc3[k] = e;
+            if (first) {
+                if (p.sumsq) p.sumsq[k] = e;
+                if (p.norms) p.norms[k] = (float)sqrt(e);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) den[k] = (float)sqrt(bc3[k]);
 }
 
 // fsdt_st.hip: the assembled-stencil form

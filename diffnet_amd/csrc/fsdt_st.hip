@@ -35,6 +35,43 @@ struct FsdtMats {
 
 enum { ST_M = 0, ST_K = 1, ST_C = 2 };
 
+#ifndef DN_ST_VEC2
+#define DN_ST_VEC2 0              // 1 (Q2 only): the two own nodes of a row as ONE 8-byte access (4-byte aligned on rows of an odd number of nodes: the hardware
+#endif                            // takes it) instead of two 4-byte ones -- measurement switch, see the numbers at st_load_own
+// The thread's own nodes of a row.  NW == 2 with DN_ST_VEC2: one access of two elements at min(x0, nx - 2); the closing column (x0 == nx - 1) takes the second half.
+template <int NW, typename T>
+__device__ __forceinline__ void st_load_own(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[NW]) {
+#if DN_ST_VEC2
+    if constexpr (NW == 2) {
+        const unsigned xl = (unsigned)min(x0, nx - 2);
+        const bool last = x0 > nx - 2;
+        if constexpr (sizeof(T) == 4) {
+            const float2 v = ld_at<float2>(base, rowoff + xl);
+            const float a = last ? v.y : v.x;
+            dst[0] = reinterpret_cast<const T&>(a);
+            dst[1] = reinterpret_cast<const T&>(v.y);
+        } else {
+            const uint16_t w = ld_at<uint16_t>(base, rowoff + xl);
+            dst[0] = (T)(last ? (w >> 8) : (w & 0xffu));
+            dst[1] = (T)(w >> 8);
+        }
+        return;
+    }
+#endif
+    load_own<NW, false>(base, rowoff, x0, nx, dst);
+}
+template <int NW>
+__device__ __forceinline__ void st_store_own(float* __restrict__ base, unsigned rowoff, int x0, int nx, const float (&src)[NW]) {
+#if DN_ST_VEC2
+    if constexpr (NW == 2) {
+        if (x0 + 1 < nx) st_at<float2>(base, rowoff + (unsigned)x0, make_float2(src[0], src[1]));
+        else if (x0 < nx) st_at<float>(base, rowoff + (unsigned)x0, src[0]);
+        return;
+    }
+#endif
+    store_seg<NW, false>(base, rowoff, x0, nx, src);
+}
+
 // The matrices are read from the kernel-argument segment through a pointer the compiler cannot see through (st_fresh), once per phase of a
 // layer: 54 matrix entries + the coefficients + the launch's pointers do not fit the 100 SGPRs, and what does not fit is spilled into VGPR
 // lanes and read back with v_readlane (~33 cycles of the SIMD each: 150 of them per layer in the first packed build).  A phase (x factor of the
@@ -203,9 +240,11 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
     const int64_t nps = (int64_t)p.nx * p.ny;
     const int ymax = p.ny - 1;
 
-    __shared__ double red[16];
+    __shared__ double red[16], den_bc[3];
     __shared__ int last_flag;
     float sq[3] = {0.f, 0.f, 0.f};
+    float den3[3] = {0.f, 0.f, 0.f};
+    if (p.den_part) den_from_partials(p, (int)threadIdx.x, (int)blockDim.x, red, den_bc, den3);      // consumer of a deferring launch (fsdt_common.h)
 
     if (chunk < nchunks) {
         const float* fb[3];
@@ -228,7 +267,7 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
         if (p.in_num) {               // cotangent of the norms over the norms (the VJP of ||R_k||), torch's convention at ||R_k|| == 0: zero
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float den = p.in_den[k];
+                const float den = p.den_part ? den3[k] : p.in_den[k];
                 fscale[k] = den > 0.f ? p.in_num[k] / den : 0.f;
             }
         }
@@ -240,12 +279,12 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
         auto row_issue = [&](int yr, RawRow& w) {
             const unsigned rowoff = (unsigned)min(yr, ymax) * (unsigned)p.nx;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) load_own<NW, false>(fb[k], rowoff, x0, p.nx, w.v[k]);
-            if constexpr (MK == 1) load_own<NW, false>(m8, rowoff, x0, p.nx, w.mb);
-            if constexpr (MK == 2) load_own<NW, false>(mf, rowoff, x0, p.nx, w.mfl);
+            for (int k = 0; k < 3; ++k) st_load_own<NW>(fb[k], rowoff, x0, p.nx, w.v[k]);
+            if constexpr (MK == 1) st_load_own<NW>(m8, rowoff, x0, p.nx, w.mb);
+            if constexpr (MK == 2) st_load_own<NW>(mf, rowoff, x0, p.nx, w.mfl);
             if constexpr (BCF && MK != 0) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) load_own<NW, false>(bcf[k], rowoff, x0, p.nx, w.bf[k]);
+                for (int k = 0; k < 3; ++k) st_load_own<NW>(bcf[k], rowoff, x0, p.nx, w.bf[k]);
             }
         };
         // landed row: input scaling, Dirichlet nodes (mask >= 0.5) take the boundary values
@@ -310,7 +349,7 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
                 if (pend_st[r]) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
-                        if (ob[k]) store_seg<NW, false>(ob[k], pend_off[r], x0, p.nx, pend[r][k]);
+                        if (ob[k]) st_store_own<NW>(ob[k], pend_off[r], x0, p.nx, pend[r][k]);
                 }
                 pend_st[r] = false;
             }
@@ -437,7 +476,10 @@ __global__ void __launch_bounds__(256) fsdt2d_st_kernel(const FsdtParams p, cons
             flush_rows();
         }
     }
-    if (p.want_sums) finish_sums3(p, sq, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
+    if (p.want_sums) {
+        if (p.defer_sums) store_partials3(p, sq, (int)threadIdx.x, (int)blockDim.x, red);
+        else finish_sums3(p, sq, (int)threadIdx.x, (int)blockDim.x, red, &last_flag);
+    }
 }
 
 struct FsdtStGeom { int wpb, chunks, gx, R, strips; };

@@ -132,14 +132,17 @@ def fsdt_loss_and_grad(fem, w, phi_x, phi_y, bc, w_bc=0.0, phi_x_bc=0.0, phi_y_b
     hy = fem.h if hy is None else hy
     consts, wscale = _constants(E, v, h, K_s), (0.5 * hx) * (0.5 * hy)
     with torch.no_grad():
-        Rs, _, norms = ops.fsdt_apply(fem.geom, w, phi_x, phi_y, bc, (w_bc, phi_x_bc, phi_y_bc), q=q, wscale=wscale, want_sums=False,
-                                      want_norms=True, **consts)
+        # the first launch leaves per-workgroup partial sums only; the second forms the norms from them, scales by weights / norms and writes the norms
+        # (no arrival protocol / final reduction at the end of the first launch: 21.3 -> 14.7 us at 1025^2 Q2, one sample)
+        Rs, _, partials = ops.fsdt_apply(fem.geom, w, phi_x, phi_y, bc, (w_bc, phi_x_bc, phi_y_bc), q=q, wscale=wscale, want_sums=False,
+                                         defer_norms=True, **consts)
         if weights is None:
             key = (w.device.type, w.device.index)
             weights = _ONES.get(key)
             if weights is None:
                 weights = _ONES[key] = torch.ones(3, dtype=torch.float32, device=w.device)
-        grads, _ = ops.fsdt_apply(fem.geom, *Rs, bc, (0.0, 0.0, 0.0), q=0.0, wscale=wscale, want_sums=False, in_num=weights, in_den=norms, **consts)
+        grads, _, norms = ops.fsdt_apply(fem.geom, *Rs, bc, (0.0, 0.0, 0.0), q=0.0, wscale=wscale, want_sums=False, want_norms=True, in_num=weights,
+                                         norms_from=partials, **consts)
     return norms, grads
 
 

@@ -1082,22 +1082,40 @@ def _fsdt_key(geom, flds, bc, bc_values, consts, in_scale, in_num, in_den, flags
     return tuple(parts)
 
 
+class DeferredNorms:
+    """Handle of a dn_fsdt_apply launch that left its partial sums of squares in the stream's reduction workspace (`defer_norms=True`): pass it as
+    `norms_from` to the NEXT FSDT launch on that stream, which forms the norms itself.  Any other reducing FSDT launch in between overwrites the
+    partials -- the pair is meant to be issued back to back (elasticity.fsdt_loss_and_grad, FsdtPlan)."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+
 def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.0, D12=0.0, D22=1.0, D66=1.0, A44=1.0, A55=1.0,
-               q=0.0, wscale=1.0, want_out=True, want_sums=True, in_scale=None, want_norms=False, in_num=None, in_den=None):
+               q=0.0, wscale=1.0, want_out=True, want_sums=True, in_scale=None, want_norms=False, in_num=None, in_den=None,
+               defer_norms=False, norms_from=None):
     """One launch of dn_fsdt_apply (include/diffnet_hip.h): the three assembled FSDT plate residuals of the fields
     (B,1,ny,nx) and / or the float64 device tensor of their three sums of squares.  `bc`: Dirichlet node mask (fp32,
     `>= 0.5`, or bool/uint8), per sample or shared; `bc_values[k]`: float or tensor the k-th field / residual takes there;
     `in_scale`: optional float32 device tensor of 3 factors applied to the fields as they are loaded; `in_num` / `in_den`: the same
     with the factors in_num[k] / in_den[k] (0 where in_den[k] <= 0) formed by the kernel; `want_norms`: a third result, the float32
     tensor of the three Frobenius norms written by the same launch.  Returns (outs | None, sums | None[, norms]).
+    `defer_norms` (round 4; instead of want_sums / want_norms): the launch leaves per-workgroup partials only -- no arrival protocol, no final
+    reduction at its end (4.5-6.6 us of a 1025^2 launch) -- and the third result is a DeferredNorms handle; `norms_from=handle` (with in_num, without
+    in_den) makes THIS launch form the norms from those partials, use them as in_den, and, with want_norms, return them as its third result.
     Calls on the same buffers reuse their prepared argument structs (small LRU, fresh outputs per call: see poisson_apply)."""
     if geom.nsd != 2:
         raise DiffNetHipError("fsdt_apply: 2-D meshes only")
+    if defer_norms and (want_sums or want_norms or norms_from is not None):
+        raise ValueError("fsdt_apply: defer_norms replaces want_sums / want_norms and does not combine with norms_from")
+    if norms_from is not None and (in_num is None or in_den is not None or want_sums):
+        raise ValueError("fsdt_apply: norms_from goes with in_num, without in_den and without want_sums")
     consts = tuple(float(x) for x in (D11, D12, D22, D66, A44, A55, q, wscale))
     flds = (w, phi_x, phi_y)
     key = None
     if all(isinstance(t, torch.Tensor) and t.is_cuda for t in flds) and tuple(w.shape[1:]) == (1, *geom.node_shape) and w.shape == phi_x.shape == phi_y.shape:
-        key = _fsdt_key(geom, flds, bc, bc_values, consts, in_scale, in_num, in_den, (want_out, want_sums, want_norms))
+        key = _fsdt_key(geom, flds, bc, bc_values, consts, in_scale, in_num, in_den,
+                        (want_out, want_sums, want_norms, bool(defer_norms), None if norms_from is None else norms_from.ws.data_ptr()))
     ent = None
     if key is not None:
         with _WS_LOCK:
@@ -1106,10 +1124,12 @@ def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.
                 _FSDT_CACHE.move_to_end(key)
     if ent is None:
         _CALL_STATS["miss" if key is not None else "uncached"] += 1
-        mesh, args, keep, shape = _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num, in_den, want_sums or want_norms)
+        mesh, args, keep, shape = _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num, in_den,
+                                                (want_sums or want_norms or defer_norms) and norms_from is None, defer_norms, norms_from)
         with _WS_LOCK:
             live_ws = list(_WS.values())
-        ent = (mesh, args, C.byref(mesh), C.byref(args), shape, [t for t in keep if any(t is x for x in live_ws)])
+        ent = (mesh, args, C.byref(mesh), C.byref(args), shape, [t for t in keep if any(t is x for x in live_ws)],
+               next((t for t in keep if any(t is x for x in live_ws)), None))
         if key is not None:
             with _WS_LOCK:
                 _FSDT_CACHE[key] = ent
@@ -1117,7 +1137,7 @@ def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.
                     _FSDT_CACHE.popitem(last=False)
     else:
         _CALL_STATS["hit"] += 1
-    mesh, args, mref, aref, shape, _ = ent
+    mesh, args, mref, aref, shape = ent[:5]
     dev = w.device
     outs = sums = norms = None
     if want_out:
@@ -1138,10 +1158,12 @@ def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.
         rc = _lib.lib().dn_fsdt_apply(mref, aref, _stream(w))
     if rc:
         _lib.check(rc, "dn_fsdt_apply")
+    if defer_norms:
+        return outs, None, DeferredNorms(ent[6])
     return (outs, sums, norms) if want_norms else (outs, sums)
 
 
-def _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num, in_den, want_red):
+def _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num, in_den, want_red, defer=False, norms_from=None):
     """Validation + argument struct of a dn_fsdt_apply call, outputs left unset: (mesh, args, tensors to keep alive, field shape)."""
     flds = [_require(t, n, 4) for t, n in ((w, "w"), (phi_x, "phi_x"), (phi_y, "phi_y"))]
     B = flds[0].shape[0]
@@ -1187,8 +1209,12 @@ def _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num
                 raise ValueError(f"{name} must hold 3 floats")
             setattr(args, name, t.data_ptr())
             keep.append(t)
-    if (in_num is None) != (in_den is None) or (in_num is not None and in_scale is not None):
-        raise ValueError("fsdt_apply: in_num and in_den go together, and not with in_scale")
+    if (in_num is None) != (in_den is None and norms_from is None) or (in_num is not None and in_scale is not None):
+        raise ValueError("fsdt_apply: in_num and in_den (or norms_from) go together, and not with in_scale")
+    if norms_from is not None:
+        args.den_workspace = norms_from.ws.data_ptr()
+        keep.append(norms_from.ws)
+    args.defer_sums = 1 if defer else 0
     if want_red:
         key = (mesh.nx, mesh.ny, mesh.degree, mesh.ngp, B)
         nbytes = _FSDT_WS_BYTES.get(key)
@@ -1232,7 +1258,12 @@ class FsdtPlan:
             self.weights = torch.tensor([float(x) for x in weights], dtype=torch.float32, device=dev)
             vconsts = consts[:6] + (0.0, consts[7])          # J = M K M, K symmetric: the VJP is the operator itself on the masked cotangents, q = 0
             R = list(self.residuals.unbind(0))
-            self.vmesh, self.vargs, vkeep, _ = _prepare_fsdt(geom, R[0], R[1], R[2], bc, (0.0, 0.0, 0.0), vconsts, None, self.weights, self.norms, False)
+            # the first launch defers its sums: the second forms the norms from its partials (dn_fsdt_args.defer_sums / den_workspace) and writes them
+            self.vmesh, self.vargs, vkeep, _ = _prepare_fsdt(geom, R[0], R[1], R[2], bc, (0.0, 0.0, 0.0), vconsts, None, self.weights, None, False,
+                                                             False, DeferredNorms(next(t for t in self.keep if t.data_ptr() == self.args.workspace)))
+            self.vargs.norms = self.norms.data_ptr()
+            self.args.norms = None
+            self.args.defer_sums = 1
             self.keep += vkeep
             self.grads = torch.empty((3, *shape), dtype=torch.float32, device=dev)
             for k in range(3):

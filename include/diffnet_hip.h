@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 8
+#define DN_ABI_VERSION 9
 
 #define DN_E_BADARG (-1)    /* null pointer / non-positive size / unsupported combination   */
 #define DN_E_UNSUPPORTED (-2) /* (nsd, degree, ngp) outside the compiled instantiations      */
@@ -279,6 +279,15 @@ typedef struct dn_fsdt_args {
     const float *in_num;   /* optional, both or neither (not with in_scale): field k is multiplied by in_num[k] / in_den[k] as it is */
     const float *in_den;   /* loaded, by 0 where in_den[k] <= 0: the VJP of the norms is this call on the saved residuals with
                               in_num = cotangents of the norms, in_den = the norms (torch's zero subgradient at a zero norm) */
+    int32_t defer_sums;    /* (round 4) non-zero: the launch leaves its per-workgroup partial sums of squares in `workspace` and does NOT form
+                              sumsq / norms (the arrival protocol and the last workgroup's reduction are 4.5-6.6 us at the end of every launch:
+                              a third of the 1025^2 Q2 launch at one sample); sumsq and norms are ignored */
+    int32_t reserved_;
+    const void *den_workspace; /* (round 4) the `workspace` of an earlier launch with defer_sums on the same mesh, stream and launch plan: every
+                              workgroup of THIS launch reduces those partials (fixed order: bitwise the sums the producer would have formed)
+                              and uses their square roots where it would have read in_den (in_num required, in_den NULL); if sumsq / norms of
+                              this call are non-NULL they receive the producer's sums / norms.  The loss + gradient of the plate is then two
+                              launches with no reduction on the critical path of either */
 } dn_fsdt_args;
 int64_t dn_fsdt_workspace_bytes(const dn_mesh *mesh);
 int dn_fsdt_apply(const dn_mesh *mesh, const dn_fsdt_args *args, void *stream);

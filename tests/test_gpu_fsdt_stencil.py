@@ -130,3 +130,40 @@ def test_stencil_form_full_size_properties():
         scale = float(Ke[k].abs().max())
         assert float((Ka[k] - Ke[k]).abs().max()) <= 4e-6 * scale
         assert torch.equal(Ka[k], Kp[k])          # strips of another height: the seam layer is recomputed exactly
+
+
+@pytest.mark.parametrize("deg,ngp,n,B,form", [(2, 3, 129, 2, ""), (2, 3, 129, 2, "elem"), (1, 2, 70, 1, ""), (3, 4, 64, 1, ""), (2, 3, 1025, 1, "")])
+def test_deferred_norms_equal_in_kernel_norms(deg, ngp, n, B, form):
+    """dn_fsdt_args.defer_sums / den_workspace (round 4): the residual launch leaves per-workgroup partials, the VJP launch forms the norms from
+    them.  Same partials, same order of additions as the in-kernel reduction: norms and gradient are BITWISE those of the pair with in-kernel norms
+    (what rounds 2-3 ran); both kernel forms; through ops.fsdt_apply, elasticity.fsdt_loss_and_grad and the prepared FsdtPlan."""
+    from diffnet_amd import ops
+    from diffnet_amd.elasticity import fsdt_loss_and_grad
+    m = module(dict(domain_size=n, fem_basis_deg=deg, ngp_1d=ngp))
+    shape = (B, 1, n, n)
+    flds = [cu(seeded(shape, 5 + i)) for i in range(3)]
+    bc = boundary_mask(shape).to(dev())
+    wts = torch.tensor([1.0, 2.0, 0.5], device=dev())
+    cfg("FSDT_FORM", form)
+    try:
+        R, _, norms = ops.fsdt_apply(m.geom, *flds, bc, (0.1, -0.2, 0.3), want_sums=False, want_norms=True, **CONSTS)
+        vconsts = dict(CONSTS, q=0.0)
+        g, _ = ops.fsdt_apply(m.geom, *R, bc, (0.0, 0.0, 0.0), want_sums=False, in_num=wts, in_den=norms, **vconsts)
+        R2, _, h = ops.fsdt_apply(m.geom, *flds, bc, (0.1, -0.2, 0.3), want_sums=False, defer_norms=True, **CONSTS)
+        g2, _, norms2 = ops.fsdt_apply(m.geom, *R2, bc, (0.0, 0.0, 0.0), want_sums=False, want_norms=True, in_num=wts, norms_from=h, **vconsts)
+        assert torch.equal(norms, norms2)
+        for a, b in zip(R + g, R2 + g2):
+            assert torch.equal(a, b)
+        # the public pair and the prepared plan
+        n3, g3 = fsdt_loss_and_grad(m, *flds, bc, w_bc=0.1, phi_x_bc=-0.2, phi_y_bc=0.3, weights=wts)
+        plan = ops.FsdtPlan(m.geom, *flds, bc, (0.1, -0.2, 0.3), weights=(1.0, 2.0, 0.5), **CONSTS)
+        n4, g4 = plan.launch()
+        n4b, g4b = plan.launch()
+        assert torch.equal(n4, norms) and all(torch.equal(a, b) for a, b in zip(g4, g))
+        assert bool(torch.isfinite(n3).all()) and all(bool(torch.isfinite(t).all()) for t in g3)
+    finally:
+        cfg("FSDT_FORM", "")
+    with pytest.raises(ValueError):
+        ops.fsdt_apply(m.geom, *flds, bc, in_num=wts, in_den=norms, norms_from=h)
+    with pytest.raises(ValueError):
+        ops.fsdt_apply(m.geom, *flds, bc, defer_norms=True, want_sums=True)

@@ -45,14 +45,9 @@ for nsd, n, ngp, deg, B in cases:
     u = torch.rand((B, 1, *m.geom.node_shape), device=dev, requires_grad=True)
     y = m.gauss_pt_evaluation_der_x(u)
     g = torch.rand_like(y)
-    tab = m.dN_x_gp if hasattr(m, "dN_x_gp") else None
-    tables = None
-    # the table tensor the operator was called with: taken from the autograd graph's saved tensors would be fragile -- rebuild through the class
-    tables = m._table("dN_x") if hasattr(m, "_table") else None
     nin, nout = u.numel() * 4, y.numel() * 4
     nbf, stride = deg + 1, deg
-    if tables is None:
-        tables = torch.rand((y.shape[1], nbf ** nsd), device=dev)          # the kernels' time does not depend on the entries
+    tables = m._stacked("dN_x_gp", dev)
     ud = u.detach()
     t_f = timed(lambda: ops._gpe_fwd(ud, tables, nsd, nbf, stride))
     t_b = timed(lambda: ops._gpe_bwd(g, tables, tuple(u.shape), nsd, nbf, stride))

@@ -1,5 +1,5 @@
 import os, sys, torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffnet_amd import DiffNet2DFEM, _lib
 from diffnet_amd.elasticity import fsdt_residuals
 dev = torch.device("cuda:0")
