@@ -46,8 +46,13 @@ ALG_BYTES_PER_NODE = 16        # read u, nu, f + write grad_u, f
 PIPE = 4                       # loss all-reduces in flight (N > 1)
 
 
-def timed_pairs(launch, n):
-    """Duration of n launches, each between its own pair of HIP events recorded on the current (launch) stream.  The events are
+def timed_pairs(launch, n, settle=0):
+    """Duration of n launches, each between its own pair of HIP events recorded on the current (launch) stream, after `settle` untimed
+    launches issued AFTER the events have been created: creating 2 n events takes the host 10-20 ms, about what 400 queued launches take the
+    GPU -- with the untimed launches issued before the events were created (rounds 2-4 until the last session) the queue could run dry just
+    before the first timed launch, which then started from an idle GPU and put launches 30-100 into the load-onset transient (1.3-10 ms
+    after onset, tools/ramp2d.py): 54 -> 60-65 us per launch on the same kernel, depending on which side of that race a build fell
+    (gpurun_out/ab_cur3.json / ab_prev3.json of the round: launch-order series of both).  The events are
     created with hipEventDisableSystemFence -- HIP's flag for events "only being used to measure timing", which skips the system-scope
     cache write-back / invalidate a default event performs when it is recorded: with default events (torch.cuda.Event) that fence is
     charged to the launch between them, 1.8 us here (tools/event_cost.py, profiles/r2_event_cost.txt: 49.4 us per launch between default
@@ -66,12 +71,16 @@ def timed_pairs(launch, n):
             evs.append(e)
     except (StopIteration, OSError, AttributeError):
         pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for _ in range(settle):
+            launch()
         for a, b in pairs:
             a.record()
             launch()
             b.record()
         torch.cuda.synchronize()
         return [a.elapsed_time(b) for a, b in pairs], "torch.cuda.Event (hipEventDefault)"
+    for _ in range(settle):
+        launch()
     for i in range(n):
         hip.hipEventRecord(evs[2 * i], stream)
         launch()
@@ -724,9 +733,8 @@ def main():
     # the GPU past it.  The transient is reported as roofline.kernel_avg_ms_first_launches.
     K, SETTLE = 100, 400
     first_ms, _ = timed_pairs(launch_rot, 20)
-    for _ in range(SETTLE):
-        launch_rot()
-    kern_ms, event_kind = timed_pairs(launch_rot, K)
+    kern_ms, event_kind = timed_pairs(launch_rot, K, settle=SETTLE)
+    kern_series = [round(x * 1e3, 1) for x in kern_ms[:48]]          # in launch order (the rotation has NROT batches): a per-batch pattern shows here
     kern_ms.sort()
     rot_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     rot_region[0].record()
@@ -745,15 +753,11 @@ def main():
             pls[t[0]].launch()
             t[0] = (t[0] + 1) % NROT
 
-        for _ in range(200):
-            go_sync()
-        sync_ms = sorted(timed_pairs(go_sync, K)[0])
+        sync_ms = sorted(timed_pairs(go_sync, K, settle=200)[0])
         del pls
     # side fields: the same launch re-evaluating ONE batch (Infinity-Cache assisted: what rounds 1 and 2 reported as the step), and the
     # rotation with the mask held in the other formats (median of 60 after 200 untimed launches)
-    for _ in range(50):
-        rot[0].launch()
-    same_ms = sorted(timed_pairs(rot[0].launch, K)[0])
+    same_ms = sorted(timed_pairs(rot[0].launch, K, settle=50)[0])
     bc_forms_us = {}
     if args.nsd == 2 and rank == 0:
         for name in forms:
@@ -764,9 +768,8 @@ def main():
                 pls[t[0]].launch()
                 t[0] = (t[0] + 1) % NROT
 
-            for _ in range(200):          # 12 ms under load first: a few warm-up launches would leave the timed ones in the load-onset transient
-                go()
-            bc_forms_us[name] = round(sorted(timed_pairs(go, 60)[0])[30] * 1e3, 2)
+            # 12 ms under load first: a few warm-up launches would leave the timed ones in the load-onset transient
+            bc_forms_us[name] = round(sorted(timed_pairs(go, 60, settle=200)[0])[30] * 1e3, 2)
             del pls
     # stream ceiling: a plain streaming kernel (dn_probe_stream: out = a * b + c, 16-byte vectors) over the SAME arrays and rotation --
     # three arrays read once, one written once; best of its forms / cache policies
@@ -787,9 +790,7 @@ def main():
                     raise RuntimeError(f"dn_probe_stream rc={rc}")
                 t[0] = (t[0] + 1) % NROT
 
-            for _ in range(40):
-                go()
-            ms = sorted(timed_pairs(go, 60)[0])
+            ms = sorted(timed_pairs(go, 60, settle=40)[0])
             avg = sum(ms) / len(ms)
             if best is None or avg < best[0]:
                 best = (avg, mode, ms[len(ms) // 2])
@@ -818,9 +819,7 @@ def main():
             pl16[t[0]].launch()
             t[0] = (t[0] + 1) % 16
 
-        for _ in range(200):
-            go16()
-        ms16 = sorted(timed_pairs(go16, K)[0])
+        ms16 = sorted(timed_pairs(go16, K, settle=200)[0])
         NS, PER = 3, 4
         streams = [torch.cuda.Stream() for _ in range(NS)]
         pls = []
@@ -898,7 +897,7 @@ def main():
                                   "kernel": "the loss is formed inside the launch (its last workgroup adds up the partial sums)"}[args.sums],
                          "kernel_avg_ms_with_in_kernel_sums": None if sync_ms is None else sum(sync_ms) / len(sync_ms),
                          "frac_with_in_kernel_sums": None if sync_ms is None else alg_bytes / (sum(sync_ms) / len(sync_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "kernel_median_ms": kern_med_ms, "kernel_min_ms": kern_ms[0], "kernel_max_ms": kern_ms[-1],
+                         "kernel_median_ms": kern_med_ms, "kernel_min_ms": kern_ms[0], "kernel_max_ms": kern_ms[-1], "kernel_us_first_48_in_launch_order": kern_series,
                          "frac_at_median": alg_bytes / (kern_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_bytes,
                          "batches": "%d different batches in rotation, as in the timed steps" % NROT,
                          "steady_ms_per_launch_back_to_back": steady_region_ms,

@@ -20,6 +20,11 @@
 //
 // Launch: grid = (ceil(chunks / waves per workgroup), strips of R element rows, B).  A strip recomputes the layer under its first row
 // (as the element form does); bitwise repeatable, no atomics on the data path.
+//
+// Measured on MI355X (profiles/r4_fsdt_stencil.txt; 1025^2 nodes, Q2, 3 x 3 points, fp32 mask, in-kernel sums): one sample 27.6 -> 21.3 us, eight
+// samples 95.9 -> 59.4 us against the element form; ~480 VALU instructions (139 packed) per element layer, 117-125 VGPRs.  With the arithmetic removed
+// (-DDN_ST_ABL_MATH) the eight-sample launch takes 52 us: the kernel sits on its access pattern; the in-kernel sums cost 4.5-6.6 us per launch, which
+// the loss + gradient pair avoids by deferring them to the second launch (dn_fsdt_args.defer_sums / den_workspace, fsdt_common.h).
 #include <algorithm>
 #include <cstdlib>
 
@@ -37,7 +42,8 @@ enum { ST_M = 0, ST_K = 1, ST_C = 2 };
 
 #ifndef DN_ST_VEC2
 #define DN_ST_VEC2 0              // 1 (Q2 only): the two own nodes of a row as ONE 8-byte access (4-byte aligned on rows of an odd number of nodes: the hardware
-#endif                            // takes it) instead of two 4-byte ones -- measurement switch, see the numbers at st_load_own
+#endif                            // takes it) instead of two 4-byte ones -- measured equal at eight samples (55.1 vs 55.4 us without sums), slower at one with a
+                                  // uint8 mask (14.7 vs 20.5 us: 2-byte accesses at odd addresses), profiles/r4_fsdt_stencil.txt section 4: off
 // The thread's own nodes of a row.  NW == 2 with DN_ST_VEC2: one access of two elements at min(x0, nx - 2); the closing column (x0 == nx - 1) takes the second half.
 template <int NW, typename T>
 __device__ __forceinline__ void st_load_own(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[NW]) {

@@ -19,6 +19,15 @@ if [ -f variants/libdn_stamp.so ]; then
   DN_LIB_PATH=variants/libdn_stamp.so python tools/stamp3d.py 256 1 2>&1 | grep -v amdgpu.ids | head -12 > $O/stamp256.txt
   DN_LIB_PATH=variants/libdn_stamp.so python tools/stamp3d.py 128 1 2>&1 | grep -v amdgpu.ids | head -12 > $O/stamp128.txt
 fi
+# second half of the round: FSDT stencil form against the element form (single launches, rotation-free: B = 8 fits the 256 MB cache, see the pair), the loss + gradient
+# pair with deferred sums, the cost of the in-kernel sums, the generic operators through the raw launches, the 3-D generator's training step
+(python tools/time_fsdt.py 1025 2; DN_FSDT_FORM=elem python tools/time_fsdt.py 1025 2) 2>&1 | grep -v amdgpu.ids > $O/fsdt_forms.txt
+python tools/time_fsdt_sums.py 2>&1 | grep -v amdgpu.ids > $O/fsdt_sums.txt
+(python tools/time_fsdt_pair.py; DN_FSDT_FORM=elem python tools/time_fsdt_pair.py) 2>&1 | grep -v amdgpu.ids > $O/fsdt_pair.txt
+python tools/bench_ops.py 2>&1 | grep -v amdgpu.ids > $O/ops.txt
+(python tools/step_gen3d.py --steps 10; python tools/step_gen3d.py --steps 5 --size 256) 2>&1 | grep -v amdgpu.ids > $O/gen3d.txt
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$O/kt_gen3d -- python3 $root/tools/step_gen3d.py --steps 10 > $root/$O/kt_gen3d.log 2>&1); python tools/trace_step.py $(ls $O/kt_gen3d/*/*kernel_trace.csv | tail -1) poisson3d_q1_cf 30000 > $O/gen3d_step_kernels.txt 2>&1
+tail -n 20 $O/fsdt_forms.txt $O/fsdt_pair.txt $O/gen3d.txt
 head -4 $O/kt/*/*_kernel_stats.csv | cut -c1-220
 grep -n "FETCH_SIZE\|WRITE_SIZE\|^void\|dn::" gpurun_out/pmc_r4_2d_bits.txt gpurun_out/pmc_r4_3d_256_cf.txt | head -20
 python - <<'PY'
