@@ -496,3 +496,37 @@ def test_conv2d_valid_matches_float64_reference(B, Ci, Co, H, W, K):
     for got, ref, what in ((y.detach(), yd.detach(), "fwd"), (gx, gxd, "dgrad"), (gw, gwd, "wgrad"), (gb, gbd, "bias grad")):
         scale = float(ref.abs().max()) + 1e-30
         assert float((got.cpu().double() - ref).abs().max()) <= 2e-5 * scale, what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,M,D,H,W", [(1, 128, 128, 4, 4, 4), (1, 64, 128, 8, 8, 8), (2, 33, 70, 2, 3, 2), (1, 256, 64, 8, 8, 8), (1, 16, 32, 16, 16, 16), (1, 9, 5, 2, 2, 2)])
+def test_conv3d_split_contraction_equals_unsplit(B, C, M, D, H, W):
+    """dn_conv3d_k4s2_down_ws / _up_ws (round 4: the contraction of the deep, narrow layers split over workgroups, slices summed in order)
+    against the unsplit launches (NULL workspace) through the C ABI: same numbers to fp32 summation order, bitwise repeatable, a workspace
+    that is too small is refused."""
+    import ctypes as C_
+    from diffnet_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    fine = torch.randn((B, C, 2 * D, 2 * H, 2 * W), generator=g).to(dev)
+    coarse = torch.randn((B, M, D, H, W), generator=g).to(dev)
+    w = (torch.randn((M, C, 4, 4, 4), generator=g) * 0.05).to(dev)
+    s = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C_.c_void_p(t.data_ptr())
+    for up in (0, 1):
+        src, shape = (coarse, fine.shape) if up else (fine, coarse.shape)
+        fn, fn_ws = (L.dn_conv3d_k4s2_up, L.dn_conv3d_k4s2_up_ws) if up else (L.dn_conv3d_k4s2_down, L.dn_conv3d_k4s2_down_ws)
+        ref = torch.empty(shape, device=dev)
+        assert fn(p(src), p(w), p(ref), B, C, M, D, H, W, s) == 0
+        nbytes = L.dn_conv3d_k4s2_workspace_bytes(up, B, C, M, D, H, W)
+        assert nbytes >= 0
+        got, got2 = torch.empty(shape, device=dev), torch.empty(shape, device=dev)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        assert fn_ws(p(src), p(w), p(got), B, C, M, D, H, W, p(ws), nbytes, s) == 0
+        assert fn_ws(p(src), p(w), p(got2), B, C, M, D, H, W, p(ws), nbytes, s) == 0
+        assert torch.equal(got, got2)
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 1e-5 * scale, ("up" if up else "down", nbytes)          # (up to 16384 products per output: summation order)
+        if nbytes:
+            assert fn_ws(p(src), p(w), p(got), B, C, M, D, H, W, p(ws), nbytes - 4, s) == -3          # DN_E_WORKSPACE
