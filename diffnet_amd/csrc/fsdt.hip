@@ -633,9 +633,12 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     // round 4: the assembled-stencil form (fsdt_st.hip) is the default; dn_config_set("FSDT_FORM", "elem"), "FSDT_GENERIC" or a chained
     // launch plan ("PLAN_FSDT" "64,R,W") keep the element form of rounds 1-3
     const char* form = config(CFG_FSDT_FORM);
-    // (Q3 with Dirichlet value FIELDS stays on the element form: that instantiation of the stencil kernel needs 314 registers, spills into the accumulation
-    // registers and came out wrong on the GPU -- gpurun_out/t3_dbg.txt of the round; every other instantiation is below 256)
-    const bool stencil = !(form && form[0] == 'e') && config(CFG_FSDT_GENERIC) == nullptr && g.W == 1 && !(m->degree == 3 && any_bcf);
+    // Q3 stays on the element form unless "FSDT_FORM" = "stencil" asks for the other: measured slower there (766^2 Q3: B = 8 69.0 vs 55.2 us, B = 4 47.1 vs
+    // 36.7 -- 226-244 registers, one node row per phase; profiles/r4_fsdt_stencil.txt section 7), and its instantiation with Dirichlet value FIELDS needs 314
+    // registers, spills into the accumulation registers and came out wrong on the GPU (never run: section 6).  Q1 and Q2 are faster in the stencil form at
+    // every size measured (1024^2 Q1 B = 8: 66 vs 109 us).
+    const bool ask_st = form && form[0] == 's';
+    const bool stencil = !(form && form[0] == 'e') && config(CFG_FSDT_GENERIC) == nullptr && g.W == 1 && (m->degree <= 2 || (ask_st && !any_bcf));
     const int64_t nwg = stencil ? fsdt_st_workgroups(m) : (int64_t)g.chunks * g.strips * m->batch;
     if (want_red && (!a->workspace || a->workspace_bytes < FSDT_WS_HEADER + (int64_t)(3 * sizeof(double)) * nwg)) return DN_E_WORKSPACE;
 

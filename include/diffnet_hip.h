@@ -51,7 +51,7 @@ extern "C" {
  *   dn_conv2d_k4s2_wrw launch aims at when it splits K; default 1024), "Q1_3D_N2" (non-empty: the round-3 per-Gauss-point form of the 3-D Q1
  *   two-element kernel also where the closed-form-in-z kernel of round 4, csrc/poisson3d_q1_cf.hip, applies),
  *   "FSDT_FORM" ("elem": dn_fsdt_apply runs the element form of rounds 1-3, csrc/fsdt.hip, instead of the assembled-stencil form of round 4,
- *   csrc/fsdt_st.hip).  value NULL or "" clears the switch.
+ *   csrc/fsdt_st.hip, which is the default for Q1 and Q2 meshes; "stencil": the stencil form also for Q3 meshes, where the element form is the default).  value NULL or "" clears the switch.
  * Returns 0, or DN_E_BADARG for an unknown key / over-long value.  Not thread-safe against concurrent launches.
  * No reference counterpart (the reference has no tuning surface). */
 int dn_config_set(const char *key, const char *value);

@@ -22,12 +22,15 @@ def cfg(key, value):
 
 
 def both_forms(fn):
+    """(element form, stencil form) -- the stencil form asked for explicitly: Q3 meshes run the element form by default"""
     cfg("FSDT_FORM", "elem")
     try:
         ref = fn()
+        cfg("FSDT_FORM", "stencil")
+        got = fn()
     finally:
         cfg("FSDT_FORM", "")
-    return ref, fn()
+    return ref, got
 
 
 # element columns per row: 61, 62, 63 (one chunk / the closing column on a ghost lane / two chunks), 124, 125 (two / three chunks), 187
@@ -69,7 +72,17 @@ def test_stencil_form_equals_element_form(deg, ngp, nelx, nely, B):
 
 @pytest.mark.parametrize("deg,ngp,n", [(1, 2, 40), (2, 3, 129), (2, 2, 33), (3, 4, 190)])
 def test_stencil_form_vs_oracle(deg, ngp, n):
-    """The default launch against the oracle's per-Gauss-point reference formulation and its autograd VJP (two chunks / four at Q3)."""
+    """The stencil form against the oracle's per-Gauss-point reference formulation and its autograd VJP (two chunks / four at Q3)."""
+    from diffnet_amd.elasticity import fsdt_loss, fsdt_residuals
+    from oracle.fem_oracle import Oracle
+    cfg("FSDT_FORM", "stencil")
+    try:
+        _stencil_vs_oracle(deg, ngp, n)
+    finally:
+        cfg("FSDT_FORM", "")
+
+
+def _stencil_vs_oracle(deg, ngp, n):
     from diffnet_amd.elasticity import fsdt_loss, fsdt_residuals
     from oracle.fem_oracle import Oracle
     kw = dict(domain_size=n, fem_basis_deg=deg, ngp_1d=ngp)
@@ -144,7 +157,7 @@ def test_deferred_norms_equal_in_kernel_norms(deg, ngp, n, B, form):
     flds = [cu(seeded(shape, 5 + i)) for i in range(3)]
     bc = boundary_mask(shape).to(dev())
     wts = torch.tensor([1.0, 2.0, 0.5], device=dev())
-    cfg("FSDT_FORM", form)
+    cfg("FSDT_FORM", form or "stencil")
     try:
         R, _, norms = ops.fsdt_apply(m.geom, *flds, bc, (0.1, -0.2, 0.3), want_sums=False, want_norms=True, **CONSTS)
         vconsts = dict(CONSTS, q=0.0)
