@@ -44,22 +44,64 @@ __global__ void __launch_bounds__(64) poisson3d_gen_elem_kernel(const PoissonPar
     float* const U = lds + lane;
     float* const N = lds + NBF * 64 + lane;
     float* const F = lds + 2 * NBF * 64 + lane;
+    // The element's nodal values into LDS.  Every optional array is handled in a loop of its own, the wave-uniform test OUTSIDE the loop: the NBF loads of a
+    // loop are in flight together (round 4; with the tests inside one loop over the nodes the compiler waited for every load at every branch join -- ~27 x 3
+    // memory latencies per element at 2 waves per SIMD: 91 us of the 129^3 Q2 call).  Same values, same order of the Dirichlet conditions.
+    const unsigned off0 = ((unsigned)(ez * P) * (unsigned)p.ny + (unsigned)(ey * P)) * (unsigned)p.nx + (unsigned)(ex * P);
+    const unsigned sy = (unsigned)p.nx, sz = (unsigned)p.nx * (unsigned)p.ny;
+    auto node_off = [&](int a) { return off0 + (unsigned)(a / (NB * NB)) * sz + (unsigned)((a / NB) % NB) * sy + (unsigned)(a % NB); };
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb)
+    for (int a = 0; a < NBF; ++a) U[a * 64] = sb.u[node_off(a)];
+    if (sb.nu) {
 #pragma unroll
-        for (int jb = 0; jb < NB; ++jb)
+        for (int a = 0; a < NBF; ++a) N[a * 64] = sb.nu[node_off(a)];
+    } else {
 #pragma unroll
-            for (int ib = 0; ib < NB; ++ib) {
-                const unsigned off = ((unsigned)(ez * P + kb) * (unsigned)p.ny + (unsigned)(ey * P + jb)) * (unsigned)p.nx + (unsigned)(ex * P + ib);
-                float u = sb.u[off];
+        for (int a = 0; a < NBF; ++a) N[a * 64] = 1.f;
+    }
+    if (!FGP && sb.f) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    if (gen_mask_set(p, sb, k, off)) u = sb.field[k] ? sb.field[k][off] : p.bc[k].value;
-                const int a = (kb * NB + jb) * NB + ib;
-                U[a * 64] = u;
-                N[a * 64] = sb.nu ? sb.nu[off] : 1.f;
-                F[a * 64] = (!FGP && sb.f) ? sb.f[off] : 0.f;
+        for (int a = 0; a < NBF; ++a) F[a * 64] = sb.f[node_off(a)];
+    } else {
+#pragma unroll
+        for (int a = 0; a < NBF; ++a) F[a * 64] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (sb.mask[k] == nullptr) continue;
+        unsigned bits = 0u;          // NBF <= 64 nodes: two words
+        unsigned bits_hi = 0u;
+        if (p.bc[k].mask_is_u8) {
+            const uint8_t* mk = reinterpret_cast<const uint8_t*>(sb.mask[k]);
+#pragma unroll
+            for (int a = 0; a < NBF; ++a) {
+                const unsigned bit = mk[node_off(a)] != 0 ? 1u : 0u;
+                if (a < 32) bits |= bit << (a & 31); else bits_hi |= bit << (a & 31);
             }
+        } else {
+            const float* mk = reinterpret_cast<const float*>(sb.mask[k]);
+#pragma unroll
+            for (int a = 0; a < NBF; ++a) {
+                const unsigned bit = mk[node_off(a)] > 0.5f ? 1u : 0u;
+                if (a < 32) bits |= bit << (a & 31); else bits_hi |= bit << (a & 31);
+            }
+        }
+        if (sb.field[k]) {
+#pragma unroll
+            for (int a = 0; a < NBF; ++a) {
+                const float v = sb.field[k][node_off(a)];
+                const bool set = ((a < 32 ? bits : bits_hi) >> (a & 31)) & 1u;
+                U[a * 64] = set ? v : U[a * 64];
+            }
+        } else {
+            const float v = p.bc[k].value;
+#pragma unroll
+            for (int a = 0; a < NBF; ++a) {
+                const bool set = ((a < 32 ? bits : bits_hi) >> (a & 31)) & 1u;
+                U[a * 64] = set ? v : U[a * 64];
+            }
+        }
+    }
     const float* fg = nullptr;
     if constexpr (FGP) fg = p.fgp + ((long long)(p.f_batched ? b : 0) * (NGP * NGP * NGP)) * q.nel + el;      // f_gp[b][g][element]
 
@@ -195,17 +237,24 @@ __global__ void __launch_bounds__(256) poisson3d_gen_node_kernel(const PoissonPa
             cnt[d] = (l == 0 && e > 0) ? 2 : 1;
         }
         const float* const src = q.elem + ((long long)b * NBF) * q.nel;
+        // the <= 8 element vectors, branch-free: all eight candidates are requested together (clamped, always valid addresses), then added in the fixed
+        // order -- lower element first, x fastest -- with the absent ones skipped (round 4: the loops over 1 or 2 elements per axis issued one load at a time)
+        float v[8];
+        bool ok[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int kx = c & 1, ky = (c >> 1) & 1, kz = c >> 2;               // per axis: 0 = lower element (local node P), 1 = the node's own element
+            const bool two_x = cnt[0] == 2, two_y = cnt[1] == 2, two_z = cnt[2] == 2;
+            ok[c] = (kx == 1 || two_x) && (ky == 1 || two_y) && (kz == 1 || two_z);
+            const int ex = (kx == 0 && two_x) ? e0[0] - 1 : e0[0], lx = (kx == 0 && two_x) ? P : l0[0];
+            const int ey = (ky == 0 && two_y) ? e0[1] - 1 : e0[1], ly = (ky == 0 && two_y) ? P : l0[1];
+            const int ez = (kz == 0 && two_z) ? e0[2] - 1 : e0[2], lz = (kz == 0 && two_z) ? P : l0[2];
+            const long long el = ((long long)ez * p.nely + ey) * p.nelx + ex;
+            v[c] = src[(long long)((lz * NB + ly) * NB + lx) * q.nel + el];
+        }
         float t = 0.f;
-        for (int kz = 0; kz < cnt[2]; ++kz)
-            for (int ky = 0; ky < cnt[1]; ++ky)
-                for (int kx = 0; kx < cnt[0]; ++kx) {
-                    // the second pass along an axis is the LOWER element (e - 1, local node P): lower element first
-                    const int ez = cnt[2] == 2 ? e0[2] - 1 + kz : e0[2], lz = (cnt[2] == 2 && kz == 0) ? P : l0[2];
-                    const int ey = cnt[1] == 2 ? e0[1] - 1 + ky : e0[1], ly = (cnt[1] == 2 && ky == 0) ? P : l0[1];
-                    const int ex = cnt[0] == 2 ? e0[0] - 1 + kx : e0[0], lx = (cnt[0] == 2 && kx == 0) ? P : l0[0];
-                    const long long el = ((long long)ez * p.nely + ey) * p.nelx + ex;
-                    t += src[(long long)((lz * NB + ly) * NB + lx) * q.nel + el];
-                }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) t = ok[c] ? t + v[c] : t;
         const unsigned off = (unsigned)n;
         const bool fixed = gen_mask_set(p, sb, 0, off) || gen_mask_set(p, sb, 1, off);
         t = fixed ? 0.f : t;
@@ -222,9 +271,23 @@ __global__ void __launch_bounds__(256) poisson3d_gen_node_kernel(const PoissonPa
 
 __global__ void __launch_bounds__(256) poisson3d_gen_finish_kernel(const PoissonParams p, const Gen3DParams q) {
     __shared__ double re[256], rs[256];
+    // the partials are requested eight at a time before any is added (a load-add loop is one memory round trip per partial: 14.3 us of the 129^3 Q2
+    // call); same per-thread order of additions
     double e = 0.0, s = 0.0;
-    for (int i = threadIdx.x; i < q.n1; i += 256) e += q.part_e[i];
-    for (int i = threadIdx.x; i < q.n2; i += 256) s += q.part_s[i];
+    auto strided_sum = [&](const double* part, int n, double& acc) {
+        for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * 256;
+                v[j] = part[i < n ? i : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (i0 + j * 256 < n) ? v[j] : 0.0;
+        }
+    };
+    strided_sum(q.part_e, q.n1, e);
+    strided_sum(q.part_s, q.n2, s);
     re[threadIdx.x] = e; rs[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
