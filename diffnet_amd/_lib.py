@@ -51,7 +51,7 @@ class DnFsdtArgs(C.Structure):
                 ("A55", C.c_float), ("q", C.c_float), ("wscale", C.c_float),
                 ("out", C.c_void_p * 3), ("sumsq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("in_scale", C.c_void_p), ("norms", C.c_void_p), ("in_num", C.c_void_p), ("in_den", C.c_void_p),
-                ("defer_sums", C.c_int32), ("reserved_", C.c_int32), ("den_workspace", C.c_void_p)]
+                ("defer_sums", C.c_int32), ("den_ticket", C.c_int32), ("den_workspace", C.c_void_p)]
 
 
 I32x3 = C.c_int32 * 3

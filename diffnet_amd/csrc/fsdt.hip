@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(CH ? 64 * FS_CH_MAXW : 256) fsdt2d_kernel(cons
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float den = p.den_part ? den3[k] : p.in_den[k];
-            fscale[k] = den > 0.f ? p.in_num[k] / den : 0.f;
+            fscale[k] = den > 0.f ? p.in_num[k] / den : (den == den ? 0.f : den);          // (a NaN norm -- stale deferred partials -- stays NaN)
         }
     }
 
@@ -666,7 +666,8 @@ extern "C" int dn_fsdt_apply(const dn_mesh* m, const dn_fsdt_args* a, void* stre
     pp.nelx = (m->nx - 1) / m->degree; pp.nely = (m->ny - 1) / m->degree;
     pp.rows_per_strip = g.R;
     pp.want_sums = want_red ? 1 : 0;
-    pp.defer_sums = a->defer_sums ? 1 : 0;
+    pp.defer_sums = a->defer_sums;
+    pp.den_ticket = a->den_ticket;
     pp.den_counter = reinterpret_cast<const unsigned*>(a->den_workspace);
     pp.den_part = a->den_workspace ? reinterpret_cast<const double*>(reinterpret_cast<const char*>(a->den_workspace) + FSDT_WS_HEADER) : nullptr;
     pp.spin_limit = config(CFG_HANDOVER_SPIN_LIMIT) ? std::atoi(config(CFG_HANDOVER_SPIN_LIMIT)) : 0;

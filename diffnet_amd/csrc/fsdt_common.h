@@ -24,12 +24,15 @@ struct FsdtParams {
     unsigned* counter;
     double* sumsq;                         // 3 doubles
     int nx, ny, nelx, nely, rows_per_strip, want_sums, spin_limit;
-    int defer_sums;                        // the launch stores its per-workgroup partials (and their count) and leaves the reduction to its consumer
+    int defer_sums;                        // != 0: the launch stores its per-workgroup partials (and their count) and leaves the reduction to its consumer;
+                                           // the value is the pair's ticket, left in the workspace header for the consumer to check
+    int den_ticket;                        // consumer: the ticket it expects there (a mismatch -- another reducing launch used the workspace in between -- gives NaN)
     const unsigned* den_counter;           // consumer: header of the producer's workspace (word 4: its number of workgroups) ...
     const double* den_part;                // ... and its partials [3][nblocks]
 };
 
 constexpr int FSDT_WS_NBLOCKS_WORD = 4;    // word of the workspace header in which a deferring launch leaves its number of workgroups
+constexpr int FSDT_WS_TICKET_WORD = 5;     // ... and its ticket (0 after any launch that reduced in the kernel)
 
 // Deterministic in-kernel final reduction of three scalars (same protocol as finish_sums in poisson_common.h).
 __device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&sq)[3], int tid, int nthreads, double* red, int* flag) {
@@ -87,7 +90,10 @@ __device__ __forceinline__ void finish_sums3(const FsdtParams& p, const float (&
                 if (p.norms) p.norms[k] = (float)sqrt(e);
             }
         }
-        if (tid == 0) __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.counter[FSDT_WS_TICKET_WORD] = 0u;          // the partials of an earlier deferring launch in this workspace are gone
+        }
     }
 }
 
@@ -100,7 +106,10 @@ __device__ __forceinline__ void store_partials3(const FsdtParams& p, const float
         const double s = block_sum((double)sq[k], red, tid, nthreads);
         if (tid == 0) p.part[(size_t)k * nblocks + blk] = s;
     }
-    if (tid == 0 && blk == 0) p.counter[FSDT_WS_NBLOCKS_WORD] = (unsigned)nblocks;
+    if (tid == 0 && blk == 0) {
+        p.counter[FSDT_WS_NBLOCKS_WORD] = (unsigned)nblocks;
+        p.counter[FSDT_WS_TICKET_WORD] = (unsigned)p.defer_sums;
+    }
 }
 
 // Consumer of a deferring launch: every workgroup forms the producer's three sums from its partials in the order finish_sums3 uses (thread-strided,
@@ -108,6 +117,7 @@ __device__ __forceinline__ void store_partials3(const FsdtParams& p, const float
 // Every thread of the workgroup must call it (block sums).
 __device__ __forceinline__ void den_from_partials(const FsdtParams& p, int tid, int nthreads, double* red, double* bc3, float (&den)[3]) {
     const int nb = (int)p.den_counter[FSDT_WS_NBLOCKS_WORD];
+    const bool stale = p.den_counter[FSDT_WS_TICKET_WORD] != (unsigned)p.den_ticket;      // not the partials this call was paired with: never silent
     // at the start of EVERY workgroup of the consumer: the partials are requested eight per sum at a time before any is added (one L2 round trip per 24
     // loads; a load-add loop cost the B = 8 launch 29 us), and the three block sums share one LDS exchange (wave sums, then the waves in order: the
     // additions of block_sum)
@@ -141,14 +151,14 @@ __device__ __forceinline__ void den_from_partials(const FsdtParams& p, int tid, 
             for (int w = 0; w < nw; ++w) e += red[k * nw + w];
             bc3[k] = e;
             if (first) {
-                if (p.sumsq) p.sumsq[k] = e;
-                if (p.norms) p.norms[k] = (float)sqrt(e);
+                if (p.sumsq) p.sumsq[k] = stale ? __builtin_nan("") : e;
+                if (p.norms) p.norms[k] = stale ? __builtin_nanf("") : (float)sqrt(e);
             }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 3; ++k) den[k] = (float)sqrt(bc3[k]);
+    for (int k = 0; k < 3; ++k) den[k] = stale ? __builtin_nanf("") : (float)sqrt(bc3[k]);
 }
 
 // fsdt_st.hip: the assembled-stencil form

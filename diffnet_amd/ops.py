@@ -1087,8 +1087,14 @@ class DeferredNorms:
     `norms_from` to the NEXT FSDT launch on that stream, which forms the norms itself.  Any other reducing FSDT launch in between overwrites the
     partials -- the pair is meant to be issued back to back (elasticity.fsdt_loss_and_grad, FsdtPlan)."""
 
-    def __init__(self, ws):
+    _next = [1]
+
+    def __init__(self, ws, ticket=None):
         self.ws = ws
+        if ticket is None:                     # a fresh ticket per deferring launch (1 .. 2^31 - 1)
+            ticket = DeferredNorms._next[0]
+            DeferredNorms._next[0] = ticket % 0x7FFFFFFE + 1
+        self.ticket = ticket
 
 
 def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.0, D12=0.0, D22=1.0, D66=1.0, A44=1.0, A55=1.0,
@@ -1155,11 +1161,16 @@ def fsdt_apply(geom, w, phi_x, phi_y, bc=None, bc_values=(0.0, 0.0, 0.0), D11=1.
             args.sumsq = sums.data_ptr()
         if want_norms:
             args.norms = norms.data_ptr()
+        if defer_norms:
+            handle = DeferredNorms(ent[6])
+            args.defer_sums = handle.ticket
+        if norms_from is not None:
+            args.den_ticket = norms_from.ticket
         rc = _lib.lib().dn_fsdt_apply(mref, aref, _stream(w))
     if rc:
         _lib.check(rc, "dn_fsdt_apply")
     if defer_norms:
-        return outs, None, DeferredNorms(ent[6])
+        return outs, None, handle
     return (outs, sums, norms) if want_norms else (outs, sums)
 
 
@@ -1213,8 +1224,9 @@ def _prepare_fsdt(geom, w, phi_x, phi_y, bc, bc_values, consts, in_scale, in_num
         raise ValueError("fsdt_apply: in_num and in_den (or norms_from) go together, and not with in_scale")
     if norms_from is not None:
         args.den_workspace = norms_from.ws.data_ptr()
+        args.den_ticket = norms_from.ticket
         keep.append(norms_from.ws)
-    args.defer_sums = 1 if defer else 0
+    args.defer_sums = 1 if defer else 0          # (the caller patches the pair's ticket in: fsdt_apply per call, FsdtPlan once)
     if want_red:
         key = (mesh.nx, mesh.ny, mesh.degree, mesh.ngp, B)
         nbytes = _FSDT_WS_BYTES.get(key)
@@ -1259,11 +1271,12 @@ class FsdtPlan:
             vconsts = consts[:6] + (0.0, consts[7])          # J = M K M, K symmetric: the VJP is the operator itself on the masked cotangents, q = 0
             R = list(self.residuals.unbind(0))
             # the first launch defers its sums: the second forms the norms from its partials (dn_fsdt_args.defer_sums / den_workspace) and writes them
+            pair = DeferredNorms(next(t for t in self.keep if t.data_ptr() == self.args.workspace))
             self.vmesh, self.vargs, vkeep, _ = _prepare_fsdt(geom, R[0], R[1], R[2], bc, (0.0, 0.0, 0.0), vconsts, None, self.weights, None, False,
-                                                             False, DeferredNorms(next(t for t in self.keep if t.data_ptr() == self.args.workspace)))
+                                                             False, pair)
             self.vargs.norms = self.norms.data_ptr()
             self.args.norms = None
-            self.args.defer_sums = 1
+            self.args.defer_sums = pair.ticket
             self.keep += vkeep
             self.grads = torch.empty((3, *shape), dtype=torch.float32, device=dev)
             for k in range(3):

@@ -281,8 +281,10 @@ typedef struct dn_fsdt_args {
                               in_num = cotangents of the norms, in_den = the norms (torch's zero subgradient at a zero norm) */
     int32_t defer_sums;    /* (round 4) non-zero: the launch leaves its per-workgroup partial sums of squares in `workspace` and does NOT form
                               sumsq / norms (the arrival protocol and the last workgroup's reduction are 4.5-6.6 us at the end of every launch:
-                              a third of the 1025^2 Q2 launch at one sample); sumsq and norms are ignored */
-    int32_t reserved_;
+                              a third of the 1025^2 Q2 launch at one sample); sumsq and norms are ignored.  The value is the pair's TICKET: it is
+                              left in the workspace next to the partials, and any launch that reduces in the kernel clears it */
+    int32_t den_ticket;    /* with den_workspace: the ticket the producer was launched with; if the workspace holds another one (some other reducing
+                              launch used it in between) the scales, this call's outputs and the norms come out NaN -- never silently stale */
     const void *den_workspace; /* (round 4) the `workspace` of an earlier launch with defer_sums on the same mesh, stream and launch plan: every
                               workgroup of THIS launch reduces those partials (fixed order: bitwise the sums the producer would have formed)
                               and uses their square roots where it would have read in_den (in_num required, in_den NULL); if sumsq / norms of

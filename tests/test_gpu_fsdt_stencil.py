@@ -176,6 +176,17 @@ def test_deferred_norms_equal_in_kernel_norms(deg, ngp, n, B, form):
         assert bool(torch.isfinite(n3).all()) and all(bool(torch.isfinite(t).all()) for t in g3)
     finally:
         cfg("FSDT_FORM", "")
+    # a consumer whose partials are gone is never silent: another reducing launch in between clears the ticket, a newer deferring launch replaces it
+    vconsts = dict(CONSTS, q=0.0)
+    R3, _, h1 = ops.fsdt_apply(m.geom, *flds, bc, (0.1, -0.2, 0.3), want_sums=False, defer_norms=True, **CONSTS)
+    ops.fsdt_apply(m.geom, *flds, bc, (0.1, -0.2, 0.3), want_out=False, want_sums=True, **CONSTS)                 # reduces in the kernel, same workspace
+    g5, _, n5 = ops.fsdt_apply(m.geom, *R3, bc, (0.0, 0.0, 0.0), want_sums=False, want_norms=True, in_num=wts, norms_from=h1, **vconsts)
+    assert bool(torch.isnan(n5).all()) and bool(torch.isnan(g5[0][0, 0, 1, 1]))
+    R4, _, h2 = ops.fsdt_apply(m.geom, *flds, bc, (0.1, -0.2, 0.3), want_sums=False, defer_norms=True, **CONSTS)
+    R5, _, h3 = ops.fsdt_apply(m.geom, *flds, bc, (0.1, -0.2, 0.3), want_sums=False, defer_norms=True, **CONSTS)
+    _, _, n6 = ops.fsdt_apply(m.geom, *R4, bc, (0.0, 0.0, 0.0), want_sums=False, want_norms=True, in_num=wts, norms_from=h2, **vconsts)   # stale ticket
+    _, _, n7 = ops.fsdt_apply(m.geom, *R5, bc, (0.0, 0.0, 0.0), want_sums=False, want_norms=True, in_num=wts, norms_from=h3, **vconsts)   # the live one
+    assert bool(torch.isnan(n6).all()) and torch.allclose(n7, norms, rtol=1e-6)          # (default form here; `norms` may come from the element form)
     with pytest.raises(ValueError):
         ops.fsdt_apply(m.geom, *flds, bc, in_num=wts, in_den=norms, norms_from=h)
     with pytest.raises(ValueError):
