@@ -311,6 +311,35 @@ def device_us(fn, n=40, warm=3, settle_s=0.04):
     return a.elapsed_time(b) / n * 1e3, host_us, "behind-blocker"
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32 matrix-core peak (v_mfma_f32_*: the precision the reference trains in)
+
+
+def conv_step_flops(net, x):
+    """FLOPs of one training step's convolutions (forward + input gradient + weight gradient = 3 x forward), counted by forward hooks on every
+    Conv / ConvTranspose module of `net` during one forward of x: 2 * Cout * (Cin / groups) * prod(kernel) * B * prod(output positions) per
+    Conv, the same with the INPUT positions per ConvTranspose.  Functional convolutions (the fused output blocks) are not modules and are not
+    counted: the figure is a lower bound."""
+    from torch import nn
+    total = [0]
+
+    def hook(mod, inp, out):
+        k = 1
+        for v in mod.kernel_size:
+            k *= v
+        pos = (inp[0] if isinstance(mod, (nn.ConvTranspose2d, nn.ConvTranspose3d)) else out)
+        npos = pos.shape[0]
+        for v in pos.shape[2:]:
+            npos *= v
+        total[0] += 2 * mod.out_channels * (mod.in_channels // mod.groups) * k * npos
+
+    hs = [m_.register_forward_hook(hook) for m_ in net.modules() if isinstance(m_, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d, nn.ConvTranspose3d))]
+    with torch.no_grad():
+        net(x)
+    for h in hs:
+        h.remove()
+    return 3 * total[0]
+
+
 def config_rows(dev, budget_s=150.0):
     """One row per BASELINE.json config (and the batch sizes SURVEY 8(d) names): us per evaluation of the loss + gradient in steady
     state, fraction of the HBM peak on the config's algorithmic bytes, work units per second.  Inputs larger
@@ -450,8 +479,12 @@ def config_rows(dev, budget_s=150.0):
             fn()
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / k * 1e6
+        flops = conv_step_flops(net, x)
         add(name, us, us, ALG_BYTES_PER_NODE * B * n * n, B * fem.geom.nelem_total * fem.geom.ngp_total,
             "whole training step (UNet forward + FEM loss + backward + Adam), wall clock; frac counts the FEM bytes only")
+        rows[-1]["network"] = {"bound": "mfma", "achieved": round(flops / us / 1e6, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(flops / us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "conv_gflop_per_step": round(flops / 1e9, 1),
+                               "note": "module convolutions, forward + both gradients, over the WHOLE step time (norms, activations, FEM loss, Adam included)"}
 
     def gen3d(name, n, B):
         if time.perf_counter() - t_start > budget_s:
@@ -480,8 +513,12 @@ def config_rows(dev, budget_s=150.0):
             fn()
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / k * 1e6
+        flops = conv_step_flops(net, nu)
         add(name, us, us, ALG_BYTES_PER_NODE * B * n ** 3, B * fem.geom.nelem_total * fem.geom.ngp_total,
             "whole training step (GoodGenerator forward + FEM loss + backward + Adam: IBN_3D.py:114-136, wgan3d.py:23-98), wall clock; frac counts the FEM bytes only")
+        rows[-1]["network"] = {"bound": "mfma", "achieved": round(flops / us / 1e6, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(flops / us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "conv_gflop_per_step": round(flops / 1e9, 1),
+                               "note": "module convolutions, forward + both gradients, over the WHOLE step time"}
 
     poisson("cfg1 2-D 64^2 Q1 2x2 B=1 energy c=1/2", 2, 64, 2, 1, 0.5)
     poisson("cfg2 2-D 512^2 Q1 3x3 B=1", 2, 512, 3, 1, 1.0)
