@@ -43,9 +43,10 @@ struct FsdtMats {
 enum { ST_M = 0, ST_K = 1, ST_C = 2 };
 
 #ifndef DN_ST_VEC2
-#define DN_ST_VEC2 0              // 1 (Q2 only): the two own nodes of a row as ONE 8-byte access (4-byte aligned on rows of an odd number of nodes: the hardware
-#endif                            // takes it) instead of two 4-byte ones -- measured equal at eight samples (55.1 vs 55.4 us without sums), slower at one with a
-                                  // uint8 mask (14.7 vs 20.5 us: 2-byte accesses at odd addresses), profiles/r4_fsdt_stencil.txt section 4: off
+#define DN_ST_VEC2 1              // (Q2) the two own nodes of a row as ONE 8-byte access (4-byte aligned on rows of an odd number of nodes: the hardware takes it)
+#endif                            // instead of two 4-byte ones.  Equal where the arrays come out of the 256 MB cache (single launches re-run on the same buffers:
+                                  // 55.1 vs 55.4 us at eight samples), 11-15 % faster where they come from HBM -- the loss + gradient pair at eight samples:
+                                  // 130 -> 116 us with fp32 masks, 127 -> 109 us with uint8 masks (profiles/r4_fsdt_stencil.txt sections 4 and 9)
 // The thread's own nodes of a row.  NW == 2 with DN_ST_VEC2: one access of two elements at min(x0, nx - 2); the closing column (x0 == nx - 1) takes the second half.
 template <int NW, typename T>
 __device__ __forceinline__ void st_load_own(const T* __restrict__ base, unsigned rowoff, int x0, int nx, T (&dst)[NW]) {
